@@ -1,0 +1,58 @@
+"""Build the C-ABI shared library (hipcc, gfx950 only) in-tree: gnss-sdr-rs_amd/lib/libgnss_mi355x.so.
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED: the reference-faithful
+products (carrier mix, x conj(code), per-sample tracking arithmetic) must round like rustc's
+(no implicit FMA); FFT butterflies call __builtin_fmaf explicitly.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libgnss_mi355x.so")
+SOURCES = ["acq_kernels.hip", "trk_kernels.hip", "gm_api.hip"]
+HEADERS = ["fft_core.h", "fft_plans.h", "gm_internal.h", os.path.join("..", "..", "include", "gnss_mi355x.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src + ".o")
+        if force or _stale(o, [s] + hdrs):
+            jobs.append(["hipcc", *FLAGS, "-c", s, "-o", o])
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout)
+        return r.stdout
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, s + ".o") for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        # exported symbols: exactly the gm_* entry points of include/gnss_mi355x.h
+        run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
+             "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,402 @@
+// acq_kernels.hip — acquisition kernels for gfx950 (CDNA4, wave64).
+//
+// Replaces the per-PRN loop of AcquisitionWorker::search_satellite
+// (src/acquisition/do_acquisition.rs:158-226) with two kernels:
+//
+//   stage F  acq_mix_fft_kernel  : one workgroup per (Doppler bin d, ms block m):
+//            out = s * table[d]  (apply_doppler_shift, doppler_shift.rs:25-58, same rounding sequence)
+//            fused into pass 0 of the forward FFT (:182); spectrum[d][m][k] written coalesced.
+//            The reference recomputes this for every PRN (32x redundant); it does not depend on the PRN.
+//   stage C  acq_corr_kernel     : one workgroup per (worker p, Doppler bin d), looping over the M
+//            integrations: X[d][m][k] * conj(C[p][k]) (:184-186) fused into pass 0 of the inverse
+//            FFT (:188); |.|^2 accumulated in registers across m (:190-192); finally the first strict
+//            argmax / max (:195-202) and the plane sum (:229-235) by wavefront shuffles.
+//            conj(C[p]) stays in registers across the m loop, the transform lives in one LDS buffer.
+//
+// HBM/L2 layout: spectra [D][M][N] c32 contiguous in k (8 B per lane, 512 B per wave-instruction);
+// code spectra [P][N].  Algorithmic bytes per dwell: D*M*N*(b_in+8) + P*D*M*N*16.
+//
+// Compiled with -ffp-contract=off: the "faithful" products below must round like rustc's
+// (no FMA); the FFT butterflies use explicit __builtin_fmaf.
+#include "gm_internal.h"
+#include "fft_plans.h"
+
+namespace gm {
+
+template <class PL, bool INV, int S> struct MiddlePasses {
+    static __device__ __forceinline__ void run(cf* lds, const cf* tw, int tid) {
+        if constexpr (S <= PL::NP - 2) {
+            cf u[PL::IT(S)][PL::R[S]];
+            Fft<PL, INV>::template gather<S>(u, lds, tw, tid);
+            __syncthreads();
+            Fft<PL, INV>::template scatter<S>(u, lds, tid);
+            __syncthreads();
+            MiddlePasses<PL, INV, S + 1>::run(lds, tw, tid);
+        }
+    }
+};
+
+template <class PL> __device__ __forceinline__ void load_twiddles(cf* tw_lds, const cf* tw_g, int tid) {
+    for (int i = tid; i < PL::TW_TOTAL; i += PL::T) tw_lds[i] = tw_g[i];
+}
+
+__device__ __forceinline__ cf load_sample(const void* samples, int fmt, size_t idx) {
+    if (fmt == GM_FMT_C32) return reinterpret_cast<const cf*>(samples)[idx];
+    if (fmt == GM_FMT_I8_IQ) {
+        const char2 v = reinterpret_cast<const char2*>(samples)[idx];
+        return cf_make(float(v.x), float(v.y));
+    }
+    return cf_make(float(reinterpret_cast<const int8_t*>(samples)[idx]), 0.0f);
+}
+
+// ------------------------------------------------------------------------------------ stage F
+template <class PL>
+__global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restrict__ samples, int fmt,
+                                                            const cf* __restrict__ tables,
+                                                            const cf* __restrict__ tw_fwd,
+                                                            cf* __restrict__ spectra, int n_int) {
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    const int d = blockIdx.x / n_int, m = blockIdx.x % n_int;
+    load_twiddles<PL>(tw, tw_fwd, tid);
+
+    cf in[PL::IT0][PL::R0];
+    const size_t sbase = size_t(m) * PL::N, tbase = size_t(d) * PL::N;
+#pragma unroll
+    for (int it = 0; it < PL::IT0; ++it) {
+        const int b = tid + it * PL::T;
+        if (b < PL::NB(0)) {
+#pragma unroll
+            for (int r = 0; r < PL::R0; ++r) {
+                const int idx = b + r * PL::NB(0);
+                const cf s = load_sample(samples, fmt, sbase + idx);
+                const cf t = tables[tbase + idx];
+                // multiply_simd_block (doppler_shift.rs:43-58): a*c + (b*d*(-1)), a*d + (b*c*(+1))
+                in[it][r] = cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);
+            }
+        }
+    }
+    Fft<PL, false>::scatter0(in, lds, tid);
+    __syncthreads();
+    MiddlePasses<PL, false, 1>::run(lds, tw, tid);
+    cf out[PL::ITL][PL::RL];
+    Fft<PL, false>::gather_last(out, lds, tw, tid);
+    cf* dst = spectra + size_t(blockIdx.x) * PL::N;   // [d][m][k]
+    constexpr int NBL = PL::NB(PL::NP - 1);
+#pragma unroll
+    for (int it = 0; it < PL::ITL; ++it) {
+        const int b = tid + it * PL::T;
+        if (b < NBL) {
+#pragma unroll
+            for (int r = 0; r < PL::RL; ++r) dst[b + r * NBL] = out[it][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ stage C
+// (value, index) reduction: larger value wins, equal values -> lower index (first strict maximum)
+__device__ __forceinline__ void take_better(float& bv, uint32_t& bi, float v, uint32_t i) {
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+
+template <class PL, bool KEEP_CODE>
+__global__ __launch_bounds__(PL::T) void acq_corr_kernel(const cf* __restrict__ spectra,
+                                                         const cf* __restrict__ code_fft,
+                                                         const cf* __restrict__ tw_inv,
+                                                         float* __restrict__ mmax, uint32_t* __restrict__ margmax,
+                                                         float* __restrict__ msum,
+                                                         const uint32_t* __restrict__ worker_list, int n_workers,
+                                                         int n_bins, int n_int) {
+    // XCD-aware tile map: blocks b and b+8 share an XCD (round-robin dispatch, speed only).  All
+    // workers of one Doppler bin go to one XCD so that bin's M spectra (M*8N bytes) stay in its L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int d = xcd + 8 * (slot / n_workers);
+    if (d >= n_bins) return;
+    const int p = int(worker_list[slot % n_workers]);
+
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    load_twiddles<PL>(tw, tw_inv, tid);
+
+    // conj(code spectrum) for this thread's pass-0 elements: resident in registers across the m
+    // loop when the register budget allows (KEEP_CODE), else re-read from L2 next to the spectrum
+    cf cc[KEEP_CODE ? PL::IT0 : 1][KEEP_CODE ? PL::R0 : 1];
+    const cf* cptr = code_fft + size_t(p) * PL::N;
+    if constexpr (KEEP_CODE) {
+#pragma unroll
+        for (int it = 0; it < PL::IT0; ++it) {
+            const int b = tid + it * PL::T;
+            if (b < PL::NB(0)) {
+#pragma unroll
+                for (int r = 0; r < PL::R0; ++r) {
+                    const cf c = cptr[b + r * PL::NB(0)];
+                    cc[it][r] = cf_make(c.x, -c.y);
+                }
+            }
+        }
+    }
+    float acc[PL::ITL][PL::RL];
+#pragma unroll
+    for (int it = 0; it < PL::ITL; ++it)
+#pragma unroll
+        for (int r = 0; r < PL::RL; ++r) acc[it][r] = 0.0f;
+
+    constexpr int NBL = PL::NB(PL::NP - 1);
+    const cf* xptr = spectra + size_t(d) * n_int * PL::N;
+    for (int m = 0; m < n_int; ++m, xptr += PL::N) {
+        cf in[PL::IT0][PL::R0];
+#pragma unroll
+        for (int it = 0; it < PL::IT0; ++it) {
+            const int b = tid + it * PL::T;
+            if (b < PL::NB(0)) {
+#pragma unroll
+                for (int r = 0; r < PL::R0; ++r) {
+                    const cf a = xptr[b + r * PL::NB(0)];
+                    cf c;
+                    if constexpr (KEEP_CODE) c = cc[it][r];
+                    else { const cf g = cptr[b + r * PL::NB(0)]; c = cf_make(g.x, -g.y); }
+                    // result_buf[i] *= conj(code[i])  (:184-186), num-complex Mul, no FMA
+                    in[it][r] = cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
+                }
+            }
+        }
+        __syncthreads();   // previous transform's last gather (and the twiddle load) is complete
+        Fft<PL, true>::scatter0(in, lds, tid);
+        __syncthreads();
+        MiddlePasses<PL, true, 1>::run(lds, tw, tid);
+        cf out[PL::ITL][PL::RL];
+        Fft<PL, true>::gather_last(out, lds, tw, tid);
+#pragma unroll
+        for (int it = 0; it < PL::ITL; ++it)
+#pragma unroll
+            for (int r = 0; r < PL::RL; ++r) {
+                const cf v = out[it][r];
+                acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y);   // += norm_sqr() (:190-192)
+            }
+    }
+
+    // per-thread: first strict maximum + partial sum
+    float bv = 0.0f, sum = 0.0f;
+    uint32_t bi = 0xffffffffu;
+#pragma unroll
+    for (int it = 0; it < PL::ITL; ++it) {
+        const int b = tid + it * PL::T;
+        if (b < NBL) {
+#pragma unroll
+            for (int r = 0; r < PL::RL; ++r) {
+                take_better(bv, bi, acc[it][r], uint32_t(b + r * NBL));
+                sum += acc[it][r];
+            }
+        }
+    }
+    // wavefront (64 lanes) butterfly reduction
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const uint32_t oi = uint32_t(__shfl_xor(int(bi), off, 64));
+        const float os = __shfl_xor(sum, off, 64);
+        take_better(bv, bi, ov, oi);
+        sum += os;
+    }
+    __syncthreads();   // everyone is done with the LDS transform buffer: reuse it as scratch
+    float* sv = reinterpret_cast<float*>(lds);
+    uint32_t* si = reinterpret_cast<uint32_t*>(lds) + 64;
+    float* ss = reinterpret_cast<float*>(lds) + 128;
+    const int wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = PL::T / 64;
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; ss[wave] = sum; }
+    __syncthreads();
+    if (tid == 0) {
+        float fv = sv[0], fs = ss[0];
+        uint32_t fi = si[0];
+        for (int w = 1; w < NW; ++w) { take_better(fv, fi, sv[w], si[w]); fs += ss[w]; }
+        if (fi == 0xffffffffu) fi = 0;   // all-NaN plane: the reference keeps (0.0, 0)
+        const size_t o = size_t(p) * n_bins + d;
+        mmax[o] = fv; margmax[o] = fi; msum[o] = fs;
+    }
+}
+
+// ------------------------------------------------------------------------------------ replica spectrum
+template <class PL>
+__global__ __launch_bounds__(PL::T) void acq_code_fft_kernel(const int8_t* __restrict__ code_samples,
+                                                             const cf* __restrict__ tw_fwd,
+                                                             cf* __restrict__ code_fft) {
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    load_twiddles<PL>(tw, tw_fwd, tid);
+    const int8_t* src = code_samples + size_t(blockIdx.x) * PL::N;
+    cf in[PL::IT0][PL::R0];
+#pragma unroll
+    for (int it = 0; it < PL::IT0; ++it) {
+        const int b = tid + it * PL::T;
+        if (b < PL::NB(0)) {
+#pragma unroll
+            for (int r = 0; r < PL::R0; ++r) in[it][r] = cf_make(float(src[b + r * PL::NB(0)]), 0.0f);
+        }
+    }
+    Fft<PL, false>::scatter0(in, lds, tid);
+    __syncthreads();
+    MiddlePasses<PL, false, 1>::run(lds, tw, tid);
+    cf out[PL::ITL][PL::RL];
+    Fft<PL, false>::gather_last(out, lds, tw, tid);
+    cf* dst = code_fft + size_t(blockIdx.x) * PL::N;
+    constexpr int NBL = PL::NB(PL::NP - 1);
+#pragma unroll
+    for (int it = 0; it < PL::ITL; ++it) {
+        const int b = tid + it * PL::T;
+        if (b < NBL) {
+#pragma unroll
+            for (int r = 0; r < PL::RL; ++r) dst[b + r * NBL] = out[it][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ plain batched FFT
+template <class PL, bool INV>
+__global__ __launch_bounds__(PL::T) void fft_batch_kernel(cf* __restrict__ data, const cf* __restrict__ tw_g) {
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    load_twiddles<PL>(tw, tw_g, tid);
+    cf* x = data + size_t(blockIdx.x) * PL::N;
+    cf in[PL::IT0][PL::R0];
+#pragma unroll
+    for (int it = 0; it < PL::IT0; ++it) {
+        const int b = tid + it * PL::T;
+        if (b < PL::NB(0)) {
+#pragma unroll
+            for (int r = 0; r < PL::R0; ++r) in[it][r] = x[b + r * PL::NB(0)];
+        }
+    }
+    Fft<PL, INV>::scatter0(in, lds, tid);
+    __syncthreads();
+    MiddlePasses<PL, INV, 1>::run(lds, tw, tid);
+    cf out[PL::ITL][PL::RL];
+    Fft<PL, INV>::gather_last(out, lds, tw, tid);
+    constexpr int NBL = PL::NB(PL::NP - 1);
+#pragma unroll
+    for (int it = 0; it < PL::ITL; ++it) {
+        const int b = tid + it * PL::T;
+        if (b < NBL) {
+#pragma unroll
+            for (int r = 0; r < PL::RL; ++r) x[b + r * NBL] = out[it][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+template <class PL> struct Launch {
+    static void fill_tw(cf* tw, bool inverse) {
+        fill_twiddles<PL>(tw, inverse, [](double a) { return ::cos(a); }, [](double a) { return ::sin(a); });
+    }
+    static void mix_fft(hipStream_t st, const void* samples, int fmt, const cf* tables, const cf* tw_fwd,
+                        cf* spectra, int n_bins, int n_int) {
+        hipLaunchKernelGGL(acq_mix_fft_kernel<PL>, dim3(n_bins * n_int), dim3(PL::T), 0, st, samples, fmt,
+                           tables, tw_fwd, spectra, n_int);
+    }
+    static void corr(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
+                     uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
+                     int n_int) {
+        if (n_workers <= 0) return;
+        const int groups = (n_bins + 7) / 8;
+        hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE>), dim3(8 * groups * n_workers), dim3(PL::T), 0, st, spectra,
+                           code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int);
+    }
+    static void code_fft(hipStream_t st, const int8_t* code_samples, const cf* tw_fwd, cf* out, int n_codes) {
+        hipLaunchKernelGGL(acq_code_fft_kernel<PL>, dim3(n_codes), dim3(PL::T), 0, st, code_samples, tw_fwd, out);
+    }
+    static void fft_batch(hipStream_t st, cf* data, const cf* tw, int inverse, int batch) {
+        if (inverse) hipLaunchKernelGGL((fft_batch_kernel<PL, true>), dim3(batch), dim3(PL::T), 0, st, data, tw);
+        else hipLaunchKernelGGL((fft_batch_kernel<PL, false>), dim3(batch), dim3(PL::T), 0, st, data, tw);
+    }
+    static constexpr PlanOps ops() {
+        return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL),
+                       &fill_tw, &mix_fft, &corr, &code_fft, &fft_batch};
+    }
+};
+
+#define GM_PLAN_ENTRY(PL) Launch<PL>::ops(),
+static const PlanOps g_plans[] = {GM_FOR_EACH_PLAN(GM_PLAN_ENTRY)};
+
+const PlanOps* find_plan(int n) {
+    for (const PlanOps& p : g_plans)
+        if (p.n == n) return &p;
+    return nullptr;
+}
+int list_plans(uint32_t* sizes, int cap) {
+    int k = 0;
+    for (const PlanOps& p : g_plans) {
+        if (k < cap && sizes) sizes[k] = uint32_t(p.n);
+        ++k;
+    }
+    return k;
+}
+
+// ------------------------------------------------------------------------------------ elementwise
+__global__ void apply_doppler_kernel(const cf* __restrict__ s, const cf* __restrict__ t, cf* __restrict__ out,
+                                     size_t n4) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += size_t(gridDim.x) * blockDim.x) {
+        const cf a = s[i], b = t[i];
+        out[i] = cf_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    }
+}
+void launch_apply_doppler(hipStream_t st, const cf* s, const cf* t, cf* out, size_t n) {
+    const size_t n4 = (n / 4) * 4;   // doppler_shift.rs:26: only whole groups of four
+    if (!n4) return;
+    const int blocks = int((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(apply_doppler_kernel, dim3(blocks), dim3(256), 0, st, s, t, out, n4);
+}
+
+__global__ void power_kernel(const cf* __restrict__ x, float* __restrict__ p, size_t n) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const cf v = x[i];
+        p[i] = v.x * v.x + v.y * v.y;
+    }
+}
+void launch_power(hipStream_t st, const cf* x, float* p, size_t n) {
+    if (!n) return;
+    const int blocks = int((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(power_kernel, dim3(blocks), dim3(256), 0, st, x, p, n);
+}
+
+// ------------------------------------------------------------------------------------ decision replay
+__global__ void decide_kernel(DecideArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_prn) return;
+    gm_acq_result r;
+    r.prn = a.prn_ids[p]; r.code_phase_samples = 0; r.code_phase_chips = 0.f; r.carrier_freq = 0.f;
+    r.fs = 0.f; r.mag_relative = 0.f; r.sample_global_index = 0; r.doppler_bin = -1;   // AcquisitionResult::new
+    uint8_t found = 0;
+    const bool searched = (p >= 64) || ((a.mask_lo >> p) & 1ull);
+    if (searched) {
+        float gmax = 0.0f, bfreq = 0.0f, bsum = 0.0f;      // best plane starts all-zero (:168)
+        uint32_t bphase = 0;
+        int bbin = -1;
+        const float nm1 = float(a.fft_size - 1);
+        for (int d = 0; d < a.n_bins; ++d) {               // ascending Doppler (:171)
+            const size_t o = size_t(p) * a.n_bins + d;
+            const float lm = a.mmax[o];
+            if (lm > gmax) { gmax = lm; bfreq = a.table_freq[d]; bphase = a.margmax[o]; bsum = a.msum[o]; bbin = d; }
+            const float avg = __fdiv_rn(bsum - gmax, nm1);  // (sum - max) / (N-1)  (:236)
+            if (__fdiv_rn(gmax, avg) > a.threshold) {       // max/avg > 7.0       (:237)
+                r.code_phase_samples = bphase;
+                r.code_phase_chips = __fdiv_rn(float(bphase) * a.code_rate, a.fs);   // (:215-216)
+                r.carrier_freq = bfreq; r.fs = a.fs; r.mag_relative = gmax;
+                r.sample_global_index = a.local_tail + bphase; r.doppler_bin = bbin;
+                found = 1;
+                break;                                       // early exit (:211-222)
+            }
+        }
+    }
+    a.results[p] = r;
+    a.found[p] = found;
+}
+void launch_decide(hipStream_t st, const DecideArgs& a) {
+    if (a.n_prn <= 0) return;
+    hipLaunchKernelGGL(decide_kernel, dim3((a.n_prn + 63) / 64), dim3(64), 0, st, a);
+}
+
+}  // namespace gm

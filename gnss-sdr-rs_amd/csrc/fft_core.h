@@ -1,0 +1,393 @@
+// fft_core.h — in-LDS mixed-radix Stockham FFT for gfx950 (wave64), register-in / register-out.
+//
+// Replaces the rustfft 6.1.0 plans used at src/acquisition/do_acquisition.rs:132-143,182,188
+// (forward = sum x[n] e^{-j2pi kn/N}, inverse = e^{+...}, neither normalised).
+//
+// Shape: one workgroup of T threads owns one length-N transform whose working set lives in
+// ONE LDS buffer (N complex f32 = 64 KB at N = 8000, so two workgroups share a CU's 160 KB).
+//   pass 0     : inputs arrive in registers (the caller fuses its global loads / carrier mix /
+//                x conj(code spectrum) into them), butterfly, scatter to LDS
+//   pass 1..   : gather from LDS (stride-1 across lanes -> conflict-free ds_read_b64),
+//                twiddle (one LDS-resident base twiddle per butterfly + power tree in registers),
+//                butterfly in registers, scatter back
+//   last pass  : outputs stay in registers in natural order (the caller fuses |.|^2 accumulation
+//                or the coalesced store)
+// Radices are compile-time; composite radices (16, 20, 25, 33, ...) are built in registers by
+// Cooley-Tukey or Good-Thomas (coprime factors: no inner twiddles) with constexpr trig constants.
+//
+// The header is host/device portable on purpose: tests/cpu emulate the T threads and the barriers
+// phase by phase with g++ to validate index maps and butterflies without a GPU.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GM_HD __host__ __device__ __forceinline__
+#else
+#define GM_HD inline __attribute__((always_inline))
+#endif
+
+namespace gm {
+
+struct alignas(8) cf {
+    float x, y;
+};
+
+GM_HD cf cf_make(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+GM_HD cf cf_add(cf a, cf b) { return cf_make(a.x + b.x, a.y + b.y); }
+GM_HD cf cf_sub(cf a, cf b) { return cf_make(a.x - b.x, a.y - b.y); }
+// complex multiply with 2 mul + 2 fma (FFT-internal: not a "faithful" reference op)
+GM_HD cf cf_mul(cf a, cf b) {
+    return cf_make(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+}
+// multiply by -j (forward) or +j (inverse)
+template <bool INV> GM_HD cf cf_mulj(cf a) {
+    if constexpr (!INV) return cf_make(a.y, -a.x);
+    else return cf_make(-a.y, a.x);
+}
+
+// ------------------------------------------------------------------ constexpr trigonometry
+namespace ct {
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double tsin(double x) {  // |x| <= pi/4
+    double x2 = x * x, term = x, sum = x;
+    for (int i = 1; i < 14; ++i) { term *= -x2 / double((2 * i) * (2 * i + 1)); sum += term; }
+    return sum;
+}
+constexpr double tcos(double x) {
+    double x2 = x * x, term = 1.0, sum = 1.0;
+    for (int i = 1; i < 14; ++i) { term *= -x2 / double((2 * i - 1) * (2 * i)); sum += term; }
+    return sum;
+}
+struct cs { double c, s; };
+// cos/sin(2*pi*a/b), exact quadrant reduction in integers
+constexpr cs cossin2pi(long a, long b) {
+    a %= b;
+    if (a < 0) a += b;
+    long q = (4 * a) / b, rem = 4 * a - q * b;  // angle = q*pi/2 + (pi/2)*rem/b
+    double c = 1.0, s = 0.0;
+    if (rem != 0) {
+        if (2 * rem <= b) { double f = (kPi / 2) * double(rem) / double(b); c = tcos(f); s = tsin(f); }
+        else { double f = (kPi / 2) * double(b - rem) / double(b); c = tsin(f); s = tcos(f); }
+    }
+    switch (q) {
+        case 0: return {c, s};
+        case 1: return {-s, c};
+        case 2: return {-c, -s};
+        default: return {s, -c};
+    }
+}
+constexpr long gcd(long a, long b) { return b == 0 ? a : gcd(b, a % b); }
+constexpr long modinv(long a, long m) {  // a^{-1} mod m, gcd == 1
+    a %= m;
+    for (long x = 1; x < m; ++x) if ((a * x) % m == 1) return x;
+    return 1;
+}
+}  // namespace ct
+
+// w_b^a = exp(-/+ j 2 pi a / b) as a compile-time constant
+template <bool INV, long A, long B> GM_HD cf wconst() {
+    constexpr ct::cs v = ct::cossin2pi(A, B);
+    constexpr float c = float(v.c);
+    constexpr float s = float(INV ? v.s : -v.s);
+    return cf_make(c, s);
+}
+// u * w_B^A with the trivial cases folded
+template <bool INV, long A, long B> GM_HD cf mul_wconst(cf u) {
+    constexpr long a = ((A % B) + B) % B;
+    if constexpr (a == 0) return u;
+    else if constexpr (4 * a == B) return cf_mulj<INV>(u);                   // -j / +j
+    else if constexpr (2 * a == B) return cf_make(-u.x, -u.y);               // -1
+    else if constexpr (4 * a == 3 * B) return cf_mulj<!INV>(u);              // +j / -j
+    else return cf_mul(u, wconst<INV, a, B>());
+}
+
+// ------------------------------------------------------------------ small butterflies (in place, natural order)
+template <int R, bool INV> struct Dft;
+
+template <bool INV> struct Dft<1, INV> { static GM_HD void run(cf (&)[1]) {} };
+
+template <bool INV> struct Dft<2, INV> {
+    static GM_HD void run(cf (&u)[2]) {
+        cf a = u[0], b = u[1];
+        u[0] = cf_add(a, b); u[1] = cf_sub(a, b);
+    }
+};
+
+template <bool INV> struct Dft<3, INV> {
+    static GM_HD void run(cf (&u)[3]) {
+        constexpr float s3 = 0.86602540378443864676f;
+        cf t1 = cf_add(u[1], u[2]);
+        cf m = cf_make(__builtin_fmaf(-0.5f, t1.x, u[0].x), __builtin_fmaf(-0.5f, t1.y, u[0].y));
+        cf d = cf_sub(u[1], u[2]);
+        cf js = cf_mulj<INV>(cf_make(s3 * d.x, s3 * d.y));
+        u[0] = cf_add(u[0], t1); u[1] = cf_add(m, js); u[2] = cf_sub(m, js);
+    }
+};
+
+template <bool INV> struct Dft<4, INV> {
+    static GM_HD void run(cf (&u)[4]) {
+        cf t0 = cf_add(u[0], u[2]), t1 = cf_sub(u[0], u[2]);
+        cf t2 = cf_add(u[1], u[3]), t3 = cf_mulj<INV>(cf_sub(u[1], u[3]));
+        u[0] = cf_add(t0, t2); u[1] = cf_add(t1, t3); u[2] = cf_sub(t0, t2); u[3] = cf_sub(t1, t3);
+    }
+};
+
+template <bool INV> struct Dft<5, INV> {
+    static GM_HD void run(cf (&u)[5]) {
+        constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+        constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+        cf t1 = cf_add(u[1], u[4]), t2 = cf_add(u[2], u[3]);
+        cf t3 = cf_sub(u[1], u[4]), t4 = cf_sub(u[2], u[3]);
+        cf a1 = cf_make(__builtin_fmaf(c2, t2.x, __builtin_fmaf(c1, t1.x, u[0].x)),
+                        __builtin_fmaf(c2, t2.y, __builtin_fmaf(c1, t1.y, u[0].y)));
+        cf a2 = cf_make(__builtin_fmaf(c1, t2.x, __builtin_fmaf(c2, t1.x, u[0].x)),
+                        __builtin_fmaf(c1, t2.y, __builtin_fmaf(c2, t1.y, u[0].y)));
+        cf b1 = cf_make(__builtin_fmaf(s2, t4.x, s1 * t3.x), __builtin_fmaf(s2, t4.y, s1 * t3.y));
+        cf b2 = cf_make(__builtin_fmaf(-s1, t4.x, s2 * t3.x), __builtin_fmaf(-s1, t4.y, s2 * t3.y));
+        cf jb1 = cf_mulj<INV>(b1), jb2 = cf_mulj<INV>(b2);
+        u[0] = cf_make(u[0].x + t1.x + t2.x, u[0].y + t1.y + t2.y);
+        u[1] = cf_add(a1, jb1); u[4] = cf_sub(a1, jb1);
+        u[2] = cf_add(a2, jb2); u[3] = cf_sub(a2, jb2);
+    }
+};
+
+// odd prime R by the symmetric real-coefficient form: (R-1)^2 real FMAs
+template <int R, bool INV> struct DftPrime {
+    template <int Q, int J> static GM_HD void acc(const cf (&a)[(R - 1) / 2 + 1], const cf (&b)[(R - 1) / 2 + 1],
+                                                 cf& ca, cf& sb) {
+        if constexpr (J <= (R - 1) / 2) {
+            constexpr ct::cs v = ct::cossin2pi(long(J) * Q, R);
+            constexpr float c = float(v.c), s = float(v.s);
+            ca.x = __builtin_fmaf(c, a[J].x, ca.x); ca.y = __builtin_fmaf(c, a[J].y, ca.y);
+            sb.x = __builtin_fmaf(s, b[J].x, sb.x); sb.y = __builtin_fmaf(s, b[J].y, sb.y);
+            acc<Q, J + 1>(a, b, ca, sb);
+        }
+    }
+    template <int Q> static GM_HD void outq(const cf u0, const cf (&a)[(R - 1) / 2 + 1],
+                                            const cf (&b)[(R - 1) / 2 + 1], cf (&y)[R]) {
+        if constexpr (Q <= (R - 1) / 2) {
+            cf ca = u0, sb = cf_make(0.f, 0.f);
+            acc<Q, 1>(a, b, ca, sb);
+            // forward: y[q] = ca - j*sb ; y[R-q] = ca + j*sb   (w = c - j s)
+            cf jsb = cf_mulj<INV>(sb);
+            y[Q] = cf_add(ca, jsb); y[R - Q] = cf_sub(ca, jsb);
+            outq<Q + 1>(u0, a, b, y);
+        }
+    }
+    static GM_HD void run(cf (&u)[R]) {
+        constexpr int H = (R - 1) / 2;
+        cf a[H + 1], b[H + 1], y[R];
+        cf s0 = u[0];
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            a[j] = cf_add(u[j], u[R - j]); b[j] = cf_sub(u[j], u[R - j]);
+            s0 = cf_add(s0, a[j]);
+        }
+        a[0] = b[0] = cf_make(0.f, 0.f);
+        y[0] = s0;
+        outq<1>(u[0], a, b, y);
+#pragma unroll
+        for (int j = 0; j < R; ++j) u[j] = y[j];
+    }
+};
+template <bool INV> struct Dft<7, INV> { static GM_HD void run(cf (&u)[7]) { DftPrime<7, INV>::run(u); } };
+template <bool INV> struct Dft<11, INV> { static GM_HD void run(cf (&u)[11]) { DftPrime<11, INV>::run(u); } };
+template <bool INV> struct Dft<13, INV> { static GM_HD void run(cf (&u)[13]) { DftPrime<13, INV>::run(u); } };
+template <bool INV> struct Dft<31, INV> { static GM_HD void run(cf (&u)[31]) { DftPrime<31, INV>::run(u); } };
+
+// Cooley-Tukey in registers: R = A*B, n = n2 + B*n1, k = k1 + A*k2
+template <int A, int B, bool INV> struct DftCT {
+    template <int N2, int K1> static GM_HD void tw_row(cf (&t)[A]) {
+        if constexpr (K1 < A) {
+            t[K1] = mul_wconst<INV, long(N2) * K1, long(A) * B>(t[K1]);
+            tw_row<N2, K1 + 1>(t);
+        }
+    }
+    template <int N2> static GM_HD void step1(const cf (&u)[A * B], cf (&v)[B][A]) {
+        if constexpr (N2 < B) {
+            cf t[A];
+#pragma unroll
+            for (int n1 = 0; n1 < A; ++n1) t[n1] = u[N2 + B * n1];
+            Dft<A, INV>::run(t);
+            tw_row<N2, 1>(t);
+#pragma unroll
+            for (int k1 = 0; k1 < A; ++k1) v[N2][k1] = t[k1];
+            step1<N2 + 1>(u, v);
+        }
+    }
+    static GM_HD void run(cf (&u)[A * B]) {
+        cf v[B][A];
+        step1<0>(u, v);
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) {
+            cf t[B];
+#pragma unroll
+            for (int n2 = 0; n2 < B; ++n2) t[n2] = v[n2][k1];
+            Dft<B, INV>::run(t);
+#pragma unroll
+            for (int k2 = 0; k2 < B; ++k2) u[k1 + A * k2] = t[k2];
+        }
+    }
+};
+
+// Good-Thomas (prime factor) in registers: gcd(A,B) = 1, no inner twiddles
+//   n = (B*n1 + A*n2) mod N ; k = (k1*B*(B^-1 mod A) + k2*A*(A^-1 mod B)) mod N
+template <int A, int B, bool INV> struct DftPFA {
+    static GM_HD void run(cf (&u)[A * B]) {
+        constexpr int N = A * B;
+        constexpr int EA = int(B * ct::modinv(B, A)), EB = int(A * ct::modinv(A, B));
+        cf v[B][A], y[N];
+#pragma unroll
+        for (int n2 = 0; n2 < B; ++n2) {
+            cf t[A];
+#pragma unroll
+            for (int n1 = 0; n1 < A; ++n1) t[n1] = u[(B * n1 + A * n2) % N];
+            Dft<A, INV>::run(t);
+#pragma unroll
+            for (int k1 = 0; k1 < A; ++k1) v[n2][k1] = t[k1];
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) {
+            cf t[B];
+#pragma unroll
+            for (int n2 = 0; n2 < B; ++n2) t[n2] = v[n2][k1];
+            Dft<B, INV>::run(t);
+#pragma unroll
+            for (int k2 = 0; k2 < B; ++k2) y[(k1 * EA + k2 * EB) % N] = t[k2];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) u[k] = y[k];
+    }
+};
+
+template <bool INV> struct Dft<8, INV> { static GM_HD void run(cf (&u)[8]) { DftCT<2, 4, INV>::run(u); } };
+template <bool INV> struct Dft<10, INV> { static GM_HD void run(cf (&u)[10]) { DftPFA<2, 5, INV>::run(u); } };
+template <bool INV> struct Dft<16, INV> { static GM_HD void run(cf (&u)[16]) { DftCT<4, 4, INV>::run(u); } };
+template <bool INV> struct Dft<20, INV> { static GM_HD void run(cf (&u)[20]) { DftPFA<4, 5, INV>::run(u); } };
+template <bool INV> struct Dft<25, INV> { static GM_HD void run(cf (&u)[25]) { DftCT<5, 5, INV>::run(u); } };
+template <bool INV> struct Dft<32, INV> { static GM_HD void run(cf (&u)[32]) { DftCT<4, 8, INV>::run(u); } };
+template <bool INV> struct Dft<33, INV> { static GM_HD void run(cf (&u)[33]) { DftPFA<3, 11, INV>::run(u); } };
+
+// ------------------------------------------------------------------ the plan
+template <int N_, int T_, int... Rs> struct Plan {
+    static constexpr int N = N_, T = T_, NP = int(sizeof...(Rs));
+    static constexpr int R[NP] = {Rs...};
+    static constexpr int P(int s) { int p = 1; for (int i = 0; i < s; ++i) p *= R[i]; return p; }
+    static constexpr int NB(int s) { return N / R[s]; }
+    static constexpr int IT(int s) { return (NB(s) + T - 1) / T; }
+    static constexpr int TWOFF(int s) { int o = 0; for (int i = 1; i < s; ++i) o += P(i); return o; }
+    static constexpr int TW_TOTAL = TWOFF(NP);
+    // pad the pass0 -> pass1 image by one element per R0 when R0 is even (stride-R0 scatter would
+    // otherwise land 16 lanes on few banks); later scatters are runs of P >= R0 contiguous elements
+    static constexpr int PAD_Q = (R[0] % 2 == 0) ? R[0] : 0;
+    static constexpr int LDS_ELEMS = N + (PAD_Q ? N / PAD_Q : 0);
+    static constexpr int R0 = R[0], IT0 = IT(0), RL = R[NP - 1], ITL = IT(NP - 1);
+    // correlation kernel: keep conj(code spectrum) in registers across the integrations loop
+    // (IT0*R0 complex VGPR pairs) only when it does not push the kernel past its VGPR budget
+    static constexpr bool KEEP_CODE = (IT0 * R0 + ITL * RL) <= 24;
+    static constexpr bool check() { int p = 1; for (int i = 0; i < NP; ++i) p *= R[i]; return p == N && NP >= 2; }
+    static_assert(check(), "radices must multiply to N and there must be >= 2 passes");
+};
+
+// host-side: fill the base-twiddle table (TW_TOTAL entries): pass s >= 1, k in [0,P(s)):
+//   tw[TWOFF(s) + k] = exp(-/+ j 2 pi k / (P(s) * R[s]))
+template <class PL> inline void fill_twiddles(cf* tw, bool inverse, double (*cosfn)(double), double (*sinfn)(double)) {
+    for (int s = 1; s < PL::NP; ++s) {
+        const int p = PL::P(s), pr = p * PL::R[s];
+        for (int k = 0; k < p; ++k) {
+            double a = 2.0 * ct::kPi * double(k) / double(pr);
+            tw[PL::TWOFF(s) + k] = cf_make(float(cosfn(a)), float(inverse ? sinfn(a) : -sinfn(a)));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ per-thread phases
+// A transform is run by every thread calling, in order, with a workgroup barrier at each '|':
+//   scatter0 | gather<1> scatter<1> (barrier between them) | ... | gather_last
+// The split into phases is what lets the CPU emulation interleave "threads".
+template <class PL, bool INV> struct Fft {
+    static constexpr int NP = PL::NP;
+
+    static GM_HD int map01(int e) {
+        if constexpr (PL::PAD_Q != 0) return e + e / PL::PAD_Q;
+        else return e;
+    }
+
+    // powers w^1..w^(R-1) by a balanced product tree (<= ~log2(R)+1 roundings each)
+    template <int R> static GM_HD void twiddle(cf (&u)[R], cf w1) {
+        cf w[R];
+        w[1] = w1;
+#pragma unroll
+        for (int r = 2; r < R; ++r) w[r] = cf_mul(w[r / 2], w[r - r / 2]);
+#pragma unroll
+        for (int r = 1; r < R; ++r) u[r] = cf_mul(u[r], w[r]);
+    }
+
+    // pass 0: butterfly the caller's registers (element (it, r) is input index (tid + it*T) + r*NB(0))
+    // and scatter to LDS.  Call after the barrier that ends the previous transform's last gather.
+    static GM_HD void scatter0(cf (&in)[PL::IT0][PL::R0], cf* lds, int tid) {
+        constexpr int R = PL::R0, NB = PL::NB(0);
+#pragma unroll
+        for (int it = 0; it < PL::IT0; ++it) {
+            const int b = tid + it * PL::T;
+            if (b < NB) {
+                Dft<R, INV>::run(in[it]);
+#pragma unroll
+                for (int r = 0; r < R; ++r) lds[map01(b * R + r)] = in[it][r];
+            }
+        }
+    }
+
+    // middle pass S (1 <= S <= NP-2): gather + twiddle + butterfly into registers
+    template <int S> static GM_HD void gather(cf (&u)[PL::IT(S)][PL::R[S]], const cf* lds, const cf* tw, int tid) {
+        constexpr int R = PL::R[S], NB = PL::NB(S), P = PL::P(S);
+#pragma unroll
+        for (int it = 0; it < PL::IT(S); ++it) {
+            const int b = tid + it * PL::T;
+            if (b < NB) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = b + r * NB;
+                    u[it][r] = lds[S == 1 ? map01(e) : e];
+                }
+                const int k = b % P;
+                twiddle<R>(u[it], tw[PL::TWOFF(S) + k]);
+                Dft<R, INV>::run(u[it]);
+            }
+        }
+    }
+    template <int S> static GM_HD void scatter(const cf (&u)[PL::IT(S)][PL::R[S]], cf* lds, int tid) {
+        constexpr int R = PL::R[S], NB = PL::NB(S), P = PL::P(S);
+#pragma unroll
+        for (int it = 0; it < PL::IT(S); ++it) {
+            const int b = tid + it * PL::T;
+            if (b < NB) {
+                const int k = b % P;
+                const int j = (b - k) * R + k;
+#pragma unroll
+                for (int r = 0; r < R; ++r) lds[j + r * P] = u[it][r];
+            }
+        }
+    }
+    // last pass: outputs in registers, element (it, r) is output index (tid + it*T) + r*NB(last)
+    static GM_HD void gather_last(cf (&out)[PL::ITL][PL::RL], const cf* lds, const cf* tw, int tid) {
+        constexpr int S = NP - 1;
+        constexpr int R = PL::RL, NB = PL::NB(S), P = PL::P(S);
+        static_assert(P == NB, "last pass has P == N/R");
+#pragma unroll
+        for (int it = 0; it < PL::ITL; ++it) {
+            const int b = tid + it * PL::T;
+            if (b < NB) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = b + r * NB;
+                    out[it][r] = lds[S == 1 ? map01(e) : e];
+                }
+                twiddle<R>(out[it], tw[PL::TWOFF(S) + b]);
+                Dft<R, INV>::run(out[it]);
+            }
+        }
+    }
+};
+
+}  // namespace gm

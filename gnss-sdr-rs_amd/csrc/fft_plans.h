@@ -1,0 +1,27 @@
+// fft_plans.h — the transform sizes the library ships kernels for, and their radix plans.
+// N = samples per code period = round(fs / 1 kHz) for GPS L1 C/A (do_acquisition.rs:249-251).
+//   8000  : 8 Msps            (BASELINE config 2, the bench workload)    2^6 * 5^3
+//   16368 : 16.3676 Msps      (BASELINE config 1, the reference's test capture geometry) 2^4*3*11*31
+//   4096  : 4.096 Msps        (the reference's synthetic tracking tests, do_tracking.rs:467)
+//   2048, 1024 : small parity cases
+//   4000, 10000, 12000, 16000 : other common front-end rates (4, 10, 12, 16 Msps)
+// Plan<N, T, radices...>: first radix odd where possible (conflict-free stride-R scatter),
+// T >= N / R for every pass so each thread owns at most one butterfly per pass (except where noted).
+#pragma once
+#include "fft_core.h"
+
+namespace gm {
+using Plan8000 = Plan<8000, 512, 25, 20, 16>;
+using Plan16368 = Plan<16368, 576, 33, 31, 16>;   // last pass: 1023 butterflies -> 2 per thread
+using Plan4096 = Plan<4096, 256, 16, 16, 16>;
+using Plan2048 = Plan<2048, 256, 8, 16, 16>;
+using Plan1024 = Plan<1024, 128, 8, 8, 16>;
+using Plan4000 = Plan<4000, 256, 25, 16, 10>;
+using Plan10000 = Plan<10000, 512, 25, 20, 20>;
+using Plan12000 = Plan<12000, 512, 25, 3, 10, 16>;
+using Plan16000 = Plan<16000, 1024, 25, 20, 32>;
+}  // namespace gm
+
+#define GM_FOR_EACH_PLAN(X) \
+    X(gm::Plan8000) X(gm::Plan16368) X(gm::Plan4096) X(gm::Plan2048) X(gm::Plan1024) \
+    X(gm::Plan4000) X(gm::Plan10000) X(gm::Plan12000) X(gm::Plan16000)

@@ -1,0 +1,954 @@
+// gm_api.hip — the extern "C" boundary (include/gnss_mi355x.h) over the HIP kernels.
+// Host-side scalar pieces of the reference API (code table, Doppler table construction, manager,
+// loop-filter constants) are restated here in C++; everything that touches sample data runs on the GPU.
+// There is no CPU fallback for the compute entries: without a device they return GM_ERR_NO_DEVICE.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gm_internal.h"
+
+using gm::cf;
+
+namespace {
+
+thread_local std::string g_last_error;
+int g_device = -1;
+
+int set_err(int code, const char* what) {
+    g_last_error = what ? what : "";
+    return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", where, hipGetErrorString(e));
+    g_last_error = buf;
+    return GM_ERR_HIP;
+}
+#define HIPC(expr)                                         \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);  \
+    } while (0)
+
+int ensure_device(int dev) {
+    if (dev < 0) return set_err(GM_ERR_NO_DEVICE, "gm_init() has not selected a HIP device");
+    HIPC(hipSetDevice(dev));
+    return GM_OK;
+}
+
+#define PI_F 3.14159265358979323846f
+const float CA_RATE = 1.023e6f, CA_LEN = 1023.0f;
+
+// ---- C/A code: IS-GPS-200 G1/G2 generator == GPS_CA_CODE_32_PRN (gps_ca_constants.rs)
+const uint16_t kG2Delay[32] = {5,   6,   7,   8,   17,  18,  139, 140, 141, 251, 252, 254, 255, 256, 257, 258,
+                               469, 470, 471, 472, 473, 474, 509, 512, 513, 514, 515, 516, 859, 860, 861, 862};
+struct CaTable {
+    int8_t rows[32][1023];
+    CaTable() {
+        uint8_t g1[1023], g2[1023];
+        uint16_t r1 = 0x3ff, r2 = 0x3ff;   // bit k-1 = stage k
+        for (int i = 0; i < 1023; ++i) {
+            g1[i] = (r1 >> 9) & 1;
+            g2[i] = (r2 >> 9) & 1;
+            const uint16_t f1 = ((r1 >> 2) ^ (r1 >> 9)) & 1;                                     // 3,10
+            const uint16_t f2 = ((r2 >> 1) ^ (r2 >> 2) ^ (r2 >> 5) ^ (r2 >> 7) ^ (r2 >> 8) ^ (r2 >> 9)) & 1;  // 2,3,6,8,9,10
+            r1 = uint16_t(((r1 << 1) | f1) & 0x3ff);
+            r2 = uint16_t(((r2 << 1) | f2) & 0x3ff);
+        }
+        for (int p = 0; p < 32; ++p)
+            for (int i = 0; i < 1023; ++i)
+                rows[p][i] = (g1[i] ^ g2[(i + 1023 - kG2Delay[p]) % 1023]) ? 1 : -1;
+    }
+};
+const CaTable& ca_table() {
+    static const CaTable t;
+    return t;
+}
+
+size_t num_samples_per_code(float code_rate, float fs, float len) {   // ca_code.rs:13-16
+    const float v = roundf(fs / (code_rate / len));
+    return v > 0.0f ? size_t(v) : 0;
+}
+
+// resample a +-1 chip sequence: idx = floor((i as f32 * code_rate) / fs)  (ca_code.rs:17-22)
+int resample_code(const int8_t* chips, size_t code_len, bool wrap, float code_rate, float fs, size_t n, int8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        const float f = floorf((float(i) * code_rate) / fs);
+        size_t ind = f > 0.0f ? size_t(f) : 0;
+        if (ind >= code_len) {
+            if (!wrap) return GM_ERR_OUT_OF_RANGE;   // ca_code[ind] panics in the reference
+            ind %= code_len;
+        }
+        out[i] = chips[ind];
+    }
+    return GM_OK;
+}
+
+void loop_filter_new(float bw, float zeta, float gain, float* tau1, float* tau2) {   // do_tracking.rs:59-65
+    const float w = bw * 8.0f * zeta / (4.0f * (zeta * zeta) + 1.0f);
+    *tau1 = gain / (w * w);
+    *tau2 = (2.0f * zeta) / w;
+}
+
+struct Timing {
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool on = false, valid = false;
+};
+
+}  // namespace
+
+// ====================================================================== acquisition handle
+struct gm_acq {
+    int device = -1;
+    gm_acq_cfg cfg{};
+    const gm::PlanOps* plan = nullptr;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t N = 0, D = 0, M = 0, P = 0;
+    float code_rate = CA_RATE;
+    std::vector<float> table_freq;
+    std::vector<uint8_t> prn_ids;
+    cf *d_tables = nullptr, *d_tw_fwd = nullptr, *d_tw_inv = nullptr, *d_code_fft = nullptr, *d_spectra = nullptr;
+    float* d_table_freq = nullptr;
+    int8_t* d_code_samples = nullptr;
+    void* d_samples = nullptr;
+    size_t samples_cap = 0;
+    uint32_t* d_metrics = nullptr;         // [3][P][D] words
+    uint32_t* d_worker_list = nullptr;
+    std::vector<uint32_t> worker_list;
+    uint64_t mask = ~0ull;
+    uint32_t n_workers = 0;
+    gm_acq_result* d_results = nullptr;
+    uint8_t *d_found = nullptr, *d_prn_ids = nullptr;
+    uint32_t results_cap = 0;
+    const void* last_metrics = nullptr;
+    Timing tm;
+};
+
+static int acq_set_mask(gm_acq* a, uint64_t mask) {
+    std::vector<uint32_t> wl;
+    for (uint32_t i = 0; i < a->P; ++i)
+        if (i >= 64 || ((mask >> i) & 1ull)) wl.push_back(i);
+    a->mask = mask;
+    if (wl != a->worker_list || a->n_workers != wl.size()) {
+        a->worker_list = wl;
+        a->n_workers = uint32_t(wl.size());
+        if (!wl.empty())
+            HIPC(hipMemcpyAsync(a->d_worker_list, a->worker_list.data(), wl.size() * sizeof(uint32_t),
+                                hipMemcpyHostToDevice, a->stream));
+        HIPC(hipStreamSynchronize(a->stream));
+    }
+    return GM_OK;
+}
+
+static int acq_reserve_results(gm_acq* a, uint32_t n) {
+    if (n <= a->results_cap) return GM_OK;
+    if (a->d_results) { hipFree(a->d_results); hipFree(a->d_found); hipFree(a->d_prn_ids); }
+    HIPC(hipMalloc(&a->d_results, sizeof(gm_acq_result) * n));
+    HIPC(hipMalloc(&a->d_found, n));
+    HIPC(hipMalloc(&a->d_prn_ids, n));
+    a->results_cap = n;
+    return GM_OK;
+}
+
+extern "C" {
+
+int gm_abi_version(void) { return GM_ABI_VERSION; }
+
+int gm_device_count(int* count) {
+    if (!count) return set_err(GM_ERR_INVALID_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return hip_fail(e, "hipGetDeviceCount"); }
+    *count = n;
+    return GM_OK;
+}
+
+int gm_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return set_err(GM_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return set_err(GM_ERR_INVALID_ARG, "device index out of range");
+    HIPC(hipSetDevice(device));
+    g_device = device;
+    return GM_OK;
+}
+
+const char* gm_last_error(void) { return g_last_error.c_str(); }
+
+const char* gm_status_string(int s) {
+    switch (s) {
+        case GM_OK: return "ok";
+        case GM_ERR_INVALID_ARG: return "invalid argument";
+        case GM_ERR_UNSUPPORTED_N: return "no FFT plan for this fft_size";
+        case GM_ERR_NO_DEVICE: return "no HIP device";
+        case GM_ERR_HIP: return "HIP runtime error";
+        case GM_ERR_OUT_OF_RANGE: return "index out of range";
+        case GM_ERR_ALIGNMENT: return "fft_size must be a multiple of 8";
+        case GM_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+// ---------------------------------------------------------------- code table / Doppler table (host)
+int gm_ca_code_row(int row, int8_t out[1023]) {
+    if (row < 0 || row > 31 || !out) return set_err(GM_ERR_OUT_OF_RANGE, "row must be 0..31");
+    memcpy(out, ca_table().rows[row], 1023);
+    return GM_OK;
+}
+
+int gm_generate_ca_code_samples(uint8_t prn, float code_rate, float fs, int8_t* out, size_t cap, size_t* n_out) {
+    if (prn < 1 || prn > 32) return set_err(GM_ERR_OUT_OF_RANGE, "prn must be 1..=32");
+    const size_t n = num_samples_per_code(code_rate, fs, CA_LEN);
+    if (n_out) *n_out = n;
+    std::vector<int8_t> tmp(n);
+    const int rc = resample_code(ca_table().rows[prn - 1], 1023, false, code_rate, fs, n, tmp.data());
+    if (rc) return set_err(rc, "chip index reached 1023 (the reference panics)");
+    if (out) memcpy(out, tmp.data(), n < cap ? n : cap);
+    return GM_OK;
+}
+
+int gm_doppler_table_new(float f_if, float doppler_hz, float fs, size_t n, float* freq_out, gm_c32* table) {
+    if (!table && n) return set_err(GM_ERR_INVALID_ARG, "table_out is null");
+    const float carr_freq = f_if + doppler_hz;               // doppler_shift.rs:13
+    const float phase_step = 2.0f * PI_F * carr_freq / fs;   // :14
+    for (size_t i = 0; i < n; ++i) {
+        const float phase = float(i) * phase_step;           // :17
+        table[i].re = cosf(phase);                           // :18
+        table[i].im = -sinf(phase);
+    }
+    if (freq_out) *freq_out = carr_freq;                     // :20
+    return GM_OK;
+}
+
+int gm_apply_doppler_shift(const gm_c32* samples, const gm_c32* table, gm_c32* output, size_t n) {
+    if (!samples || !table || !output) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (int rc = ensure_device(g_device)) return rc;
+    const size_t n4 = (n / 4) * 4;
+    if (!n4) return GM_OK;
+    cf *ds = nullptr, *dt = nullptr, *dout = nullptr;
+    HIPC(hipMalloc(&ds, n4 * 8)); HIPC(hipMalloc(&dt, n4 * 8)); HIPC(hipMalloc(&dout, n4 * 8));
+    HIPC(hipMemcpy(ds, samples, n4 * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(dt, table, n4 * 8, hipMemcpyHostToDevice));
+    gm::launch_apply_doppler(nullptr, ds, dt, dout, n);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpy(output, dout, n4 * 8, hipMemcpyDeviceToHost));   // tail n%4 untouched, like the reference
+    hipFree(ds); hipFree(dt); hipFree(dout);
+    return GM_OK;
+}
+
+// ---------------------------------------------------------------- FFT<T> / RealFFT<T>
+int gm_fft_supported_sizes(uint32_t* sizes, int cap) { return gm::list_plans(sizes, cap); }
+
+static int fft_run(size_t n, int dir, cf* d_data, size_t batch, hipStream_t st) {
+    const gm::PlanOps* pl = gm::find_plan(int(n));
+    if (!pl) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this length");
+    std::vector<cf> tw(size_t(pl->tw_total) + 1);
+    pl->fill_tw(tw.data(), dir != 0);
+    cf* d_tw = nullptr;
+    HIPC(hipMalloc(&d_tw, tw.size() * sizeof(cf)));
+    HIPC(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+    pl->fft_batch(st, d_data, d_tw, dir != 0, int(batch));
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(st));
+    hipFree(d_tw);
+    return GM_OK;
+}
+
+int gm_fft_c2c_f32(size_t n, int dir, gm_c32* inout, size_t batch) {
+    if (!inout || !n || !batch) return set_err(GM_ERR_INVALID_ARG, "null or empty");
+    if (int rc = ensure_device(g_device)) return rc;
+    if (!gm::find_plan(int(n))) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this length");
+    cf* d = nullptr;
+    HIPC(hipMalloc(&d, n * batch * 8));
+    HIPC(hipMemcpy(d, inout, n * batch * 8, hipMemcpyHostToDevice));
+    const int rc = fft_run(n, dir, d, batch, nullptr);
+    if (!rc) HIPC(hipMemcpy(inout, d, n * batch * 8, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return rc;
+}
+
+int gm_fft_power_spectrum_f32(size_t n, gm_c32* inout, float* power) {
+    if (!inout || !power || !n) return set_err(GM_ERR_INVALID_ARG, "null or empty");
+    if (int rc = ensure_device(g_device)) return rc;
+    if (!gm::find_plan(int(n))) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this length");
+    cf* d = nullptr; float* dp = nullptr;
+    HIPC(hipMalloc(&d, n * 8)); HIPC(hipMalloc(&dp, n * 4));
+    HIPC(hipMemcpy(d, inout, n * 8, hipMemcpyHostToDevice));
+    int rc = fft_run(n, 0, d, 1, nullptr);
+    if (!rc) {
+        gm::launch_power(nullptr, d, dp, n);
+        HIPC(hipGetLastError());
+        HIPC(hipMemcpy(inout, d, n * 8, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(power, dp, n * 4, hipMemcpyDeviceToHost));
+    }
+    hipFree(d); hipFree(dp);
+    return rc;
+}
+
+int gm_rfft_f32(size_t n, const float* in, gm_c32* out) {
+    if (!in || !out || !n) return set_err(GM_ERR_INVALID_ARG, "null or empty");
+    std::vector<gm_c32> buf(n);
+    for (size_t i = 0; i < n; ++i) { buf[i].re = in[i]; buf[i].im = 0.0f; }
+    const int rc = gm_fft_c2c_f32(n, 0, buf.data(), 1);
+    if (!rc) memcpy(out, buf.data(), (n / 2 + 1) * sizeof(gm_c32));
+    return rc;
+}
+
+// ---------------------------------------------------------------- acquisition
+int gm_acq_destroy(gm_acq* a) {
+    if (!a) return GM_OK;
+    if (a->device >= 0) hipSetDevice(a->device);
+    hipFree(a->d_tables); hipFree(a->d_tw_fwd); hipFree(a->d_tw_inv); hipFree(a->d_code_fft);
+    hipFree(a->d_spectra); hipFree(a->d_table_freq); hipFree(a->d_code_samples); hipFree(a->d_samples);
+    hipFree(a->d_metrics); hipFree(a->d_worker_list); hipFree(a->d_results); hipFree(a->d_found);
+    hipFree(a->d_prn_ids);
+    for (auto& e : a->tm.ev) if (e) hipEventDestroy(e);
+    if (a->own_stream && a->stream) hipStreamDestroy(a->stream);
+    delete a;
+    return GM_OK;
+}
+
+int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
+    if (!cfg || !out) return set_err(GM_ERR_INVALID_ARG, "null cfg/out");
+    *out = nullptr;
+    if (!cfg->fft_size || !cfg->n_integrations || !cfg->n_bins || !cfg->n_prn || !cfg->prn_ids)
+        return set_err(GM_ERR_INVALID_ARG, "fft_size, n_integrations, n_bins, n_prn, prn_ids are required");
+    if (!cfg->tables && !cfg->doppler_hz) return set_err(GM_ERR_INVALID_ARG, "doppler_hz or tables required");
+    if (cfg->tables && !cfg->table_freq) return set_err(GM_ERR_INVALID_ARG, "table_freq required with tables");
+    if (cfg->fft_size % 8) return set_err(GM_ERR_ALIGNMENT, "fft_size % 8 != 0");
+    const gm::PlanOps* pl = gm::find_plan(int(cfg->fft_size));
+    if (!pl) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this fft_size");
+    if (int rc = ensure_device(g_device)) return rc;
+
+    gm_acq* a = new gm_acq();
+    a->device = g_device;
+    a->cfg = *cfg;
+    a->plan = pl;
+    a->N = cfg->fft_size; a->D = cfg->n_bins; a->M = cfg->n_integrations; a->P = cfg->n_prn;
+    if (cfg->threshold == 0.0f) a->cfg.threshold = 7.0f;
+    a->code_rate = cfg->codes ? (cfg->code_rate > 0 ? cfg->code_rate : CA_RATE) : CA_RATE;
+    a->prn_ids.assign(cfg->prn_ids, cfg->prn_ids + a->P);
+    const size_t N = a->N, D = a->D, M = a->M, P = a->P;
+    int rc = GM_OK;
+    auto fail = [&](int code) { gm_acq_destroy(a); return code; };
+
+    // Doppler tables (do_acquisition.rs:252-262) — host glibc cosf/sinf like the reference
+    std::vector<gm_c32> tables(D * N);
+    a->table_freq.resize(D);
+    if (cfg->tables) {
+        memcpy(tables.data(), cfg->tables, D * N * sizeof(gm_c32));
+        memcpy(a->table_freq.data(), cfg->table_freq, D * sizeof(float));
+    } else {
+        for (size_t d = 0; d < D; ++d)
+            gm_doppler_table_new(cfg->f_if, cfg->doppler_hz[d], cfg->fs, N, &a->table_freq[d], &tables[d * N]);
+    }
+    // replica samples (AcquisitionWorker::new :132-135)
+    std::vector<int8_t> code_samples(P * N);
+    for (size_t p = 0; p < P; ++p) {
+        if (cfg->codes) {
+            if (!cfg->code_len) return fail(set_err(GM_ERR_INVALID_ARG, "code_len required with codes"));
+            rc = resample_code(cfg->codes + p * cfg->code_len, cfg->code_len, true, a->code_rate, cfg->fs, N,
+                               &code_samples[p * N]);
+        } else {
+            const uint8_t prn = a->prn_ids[p];
+            if (prn < 1 || prn > 32) return fail(set_err(GM_ERR_OUT_OF_RANGE, "prn must be 1..=32"));
+            // rustfft's process() panics unless the replica length equals fft_size (:135-137)
+            if (num_samples_per_code(CA_RATE, cfg->fs, CA_LEN) != N)
+                return fail(set_err(GM_ERR_INVALID_ARG, "fft_size != round(fs / 1 kHz)"));
+            rc = resample_code(ca_table().rows[prn - 1], 1023, false, CA_RATE, cfg->fs, N, &code_samples[p * N]);
+        }
+        if (rc) return fail(set_err(rc, "code resampling index out of range"));
+    }
+    std::vector<cf> twf(size_t(pl->tw_total) + 1), twi(size_t(pl->tw_total) + 1);
+    pl->fill_tw(twf.data(), false);
+    pl->fill_tw(twi.data(), true);
+
+#define HIPA(expr)                                                     \
+    do {                                                               \
+        hipError_t _e = (expr);                                        \
+        if (_e != hipSuccess) return fail(hip_fail(_e, #expr));        \
+    } while (0)
+    HIPA(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    a->own_stream = true;
+    HIPA(hipMalloc(&a->d_tables, D * N * 8));
+    HIPA(hipMalloc(&a->d_table_freq, D * 4));
+    HIPA(hipMalloc(&a->d_tw_fwd, twf.size() * 8));
+    HIPA(hipMalloc(&a->d_tw_inv, twi.size() * 8));
+    HIPA(hipMalloc(&a->d_code_samples, P * N));
+    HIPA(hipMalloc(&a->d_code_fft, P * N * 8));
+    HIPA(hipMalloc(&a->d_spectra, D * M * N * 8));
+    a->samples_cap = M * N * 8;
+    HIPA(hipMalloc(&a->d_samples, a->samples_cap));
+    HIPA(hipMalloc(&a->d_metrics, 3 * P * D * 4));
+    HIPA(hipMemset(a->d_metrics, 0, 3 * P * D * 4));
+    HIPA(hipMalloc(&a->d_worker_list, P * 4));
+    HIPA(hipMemcpy(a->d_tables, tables.data(), D * N * 8, hipMemcpyHostToDevice));
+    HIPA(hipMemcpy(a->d_table_freq, a->table_freq.data(), D * 4, hipMemcpyHostToDevice));
+    HIPA(hipMemcpy(a->d_tw_fwd, twf.data(), twf.size() * 8, hipMemcpyHostToDevice));
+    HIPA(hipMemcpy(a->d_tw_inv, twi.data(), twi.size() * 8, hipMemcpyHostToDevice));
+    HIPA(hipMemcpy(a->d_code_samples, code_samples.data(), P * N, hipMemcpyHostToDevice));
+    for (auto& e : a->tm.ev) HIPA(hipEventCreate(&e));
+    if ((rc = acq_reserve_results(a, uint32_t(P)))) return fail(rc);
+    HIPA(hipMemcpy(a->d_prn_ids, a->prn_ids.data(), P, hipMemcpyHostToDevice));
+    // replica spectra: forward FFT of the resampled code (:136-138)
+    pl->code_fft(a->stream, a->d_code_samples, a->d_tw_fwd, a->d_code_fft, int(P));
+    HIPA(hipGetLastError());
+    HIPA(hipStreamSynchronize(a->stream));
+    a->worker_list.clear();
+    a->n_workers = 0xffffffffu;   // force the first upload
+    if ((rc = acq_set_mask(a, ~0ull))) return fail(rc);
+#undef HIPA
+    *out = a;
+    return GM_OK;
+}
+
+int gm_acq_set_stream(gm_acq* a, void* s) {
+    if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (a->own_stream && a->stream) { hipStreamSynchronize(a->stream); hipStreamDestroy(a->stream); }
+    a->stream = reinterpret_cast<hipStream_t>(s);
+    a->own_stream = false;
+    return GM_OK;
+}
+
+int gm_acq_set_prn_mask(gm_acq* a, uint64_t mask) {
+    if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(a->device)) return rc;
+    return acq_set_mask(a, mask);
+}
+
+int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics) {
+    if (!a || !d_samples) return set_err(GM_ERR_INVALID_ARG, "null handle/samples");
+    if (fmt < GM_FMT_C32 || fmt > GM_FMT_I8_REAL) return set_err(GM_ERR_INVALID_ARG, "bad sample format");
+    if (int rc = ensure_device(a->device)) return rc;
+    uint32_t* met = d_metrics ? static_cast<uint32_t*>(d_metrics) : a->d_metrics;
+    const size_t PD = size_t(a->P) * a->D;
+    const bool t = a->tm.on;
+    if (t) HIPC(hipEventRecord(a->tm.ev[0], a->stream));
+    a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_fwd, a->d_spectra, int(a->D), int(a->M));
+    if (t) HIPC(hipEventRecord(a->tm.ev[1], a->stream));
+    a->plan->corr(a->stream, a->d_spectra, a->d_code_fft, a->d_tw_inv, reinterpret_cast<float*>(met), met + PD,
+                  reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M));
+    if (t) HIPC(hipEventRecord(a->tm.ev[2], a->stream));
+    HIPC(hipGetLastError());
+    a->last_metrics = met;
+    a->tm.valid = false;
+    return GM_OK;
+}
+
+int gm_acq_decide_dev(gm_acq* a, const void* d_metrics, uint32_t n_prn, const uint8_t* prn_ids, uint64_t local_tail) {
+    if (!a || !n_prn) return set_err(GM_ERR_INVALID_ARG, "null handle / n_prn == 0");
+    if (int rc = ensure_device(a->device)) return rc;
+    if (int rc = acq_reserve_results(a, n_prn)) return rc;
+    const uint32_t* met = d_metrics ? static_cast<const uint32_t*>(d_metrics) : a->d_metrics;
+    if (prn_ids) HIPC(hipMemcpyAsync(a->d_prn_ids, prn_ids, n_prn, hipMemcpyHostToDevice, a->stream));
+    else if (n_prn == a->P) HIPC(hipMemcpyAsync(a->d_prn_ids, a->prn_ids.data(), n_prn, hipMemcpyHostToDevice, a->stream));
+    else return set_err(GM_ERR_INVALID_ARG, "prn_ids required when n_prn differs from the handle's");
+    const size_t PD = size_t(n_prn) * a->D;
+    gm::DecideArgs da;
+    da.mmax = reinterpret_cast<const float*>(met);
+    da.margmax = met + PD;
+    da.msum = reinterpret_cast<const float*>(met + 2 * PD);
+    da.table_freq = a->d_table_freq;
+    da.prn_ids = a->d_prn_ids;
+    da.mask_lo = (d_metrics && n_prn != a->P) ? ~0ull : a->mask;
+    da.n_prn = int(n_prn); da.n_bins = int(a->D); da.fft_size = int(a->N);
+    da.fs = a->cfg.fs; da.threshold = a->cfg.threshold; da.code_rate = a->code_rate;
+    da.local_tail = local_tail;
+    da.results = a->d_results; da.found = a->d_found;
+    gm::launch_decide(a->stream, da);
+    if (a->tm.on) { HIPC(hipEventRecord(a->tm.ev[3], a->stream)); a->tm.valid = true; }
+    HIPC(hipGetLastError());
+    return GM_OK;
+}
+
+int gm_acq_synchronize(gm_acq* a) {
+    if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(a->device)) return rc;
+    HIPC(hipStreamSynchronize(a->stream));
+    return GM_OK;
+}
+
+int gm_acq_fetch_results(gm_acq* a, uint32_t n_prn, gm_acq_result* results, uint8_t* found) {
+    if (!a || !results || !found) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (n_prn > a->results_cap) return set_err(GM_ERR_INVALID_ARG, "n_prn exceeds the last decide call");
+    if (int rc = ensure_device(a->device)) return rc;
+    HIPC(hipStreamSynchronize(a->stream));
+    HIPC(hipMemcpy(results, a->d_results, sizeof(gm_acq_result) * n_prn, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(found, a->d_found, n_prn, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+int gm_acq_search(gm_acq* a, const void* samples, size_t n_samples, int fmt, uint64_t local_tail, uint64_t prn_mask,
+                  gm_acq_result* results, uint8_t* found) {
+    if (!a || !samples || !results || !found) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (fmt < GM_FMT_C32 || fmt > GM_FMT_I8_REAL) return set_err(GM_ERR_INVALID_ARG, "bad sample format");
+    const size_t need = size_t(a->M) * a->N;
+    if (n_samples < need) return set_err(GM_ERR_OUT_OF_RANGE, "samples_chunk shorter than num_integrations*fft_size");
+    if (int rc = ensure_device(a->device)) return rc;
+    const size_t bps = fmt == GM_FMT_C32 ? 8 : (fmt == GM_FMT_I8_IQ ? 2 : 1);
+    if (int rc = acq_set_mask(a, prn_mask)) return rc;
+    HIPC(hipMemcpyAsync(a->d_samples, samples, need * bps, hipMemcpyHostToDevice, a->stream));
+    if (int rc = gm_acq_search_dev(a, a->d_samples, fmt, nullptr)) return rc;
+    if (int rc = gm_acq_decide_dev(a, nullptr, a->P, nullptr, local_tail)) return rc;
+    return gm_acq_fetch_results(a, a->P, results, found);
+}
+
+int gm_acq_search_c32(gm_acq* a, const gm_c32* s, size_t n, uint64_t tail, uint64_t mask, gm_acq_result* r, uint8_t* f) {
+    return gm_acq_search(a, s, n, GM_FMT_C32, tail, mask, r, f);
+}
+int gm_acq_search_i8(gm_acq* a, const int8_t* s, size_t n, uint64_t tail, uint64_t mask, gm_acq_result* r, uint8_t* f) {
+    return gm_acq_search(a, s, n, GM_FMT_I8_IQ, tail, mask, r, f);
+}
+
+int gm_acq_metrics(gm_acq* a, float* mx, uint32_t* am, float* sm) {
+    if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(a->device)) return rc;
+    HIPC(hipStreamSynchronize(a->stream));
+    const size_t PD = size_t(a->P) * a->D;
+    const uint32_t* met = a->last_metrics ? static_cast<const uint32_t*>(a->last_metrics) : a->d_metrics;
+    if (mx) HIPC(hipMemcpy(mx, met, PD * 4, hipMemcpyDeviceToHost));
+    if (am) HIPC(hipMemcpy(am, met + PD, PD * 4, hipMemcpyDeviceToHost));
+    if (sm) HIPC(hipMemcpy(sm, met + 2 * PD, PD * 4, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+int gm_acq_code_fft(gm_acq* a, uint32_t worker, gm_c32* out) {
+    if (!a || !out || worker >= a->P) return set_err(GM_ERR_INVALID_ARG, "bad worker index");
+    if (int rc = ensure_device(a->device)) return rc;
+    HIPC(hipMemcpy(out, a->d_code_fft + size_t(worker) * a->N, size_t(a->N) * 8, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+int gm_acq_tables(gm_acq* a, gm_c32* tables, float* freq) {
+    if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(a->device)) return rc;
+    if (tables) HIPC(hipMemcpy(tables, a->d_tables, size_t(a->D) * a->N * 8, hipMemcpyDeviceToHost));
+    if (freq) memcpy(freq, a->table_freq.data(), a->D * sizeof(float));
+    return GM_OK;
+}
+
+int gm_acq_enable_timing(gm_acq* a, int on) {
+    if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    a->tm.on = on != 0;
+    a->tm.valid = false;
+    return GM_OK;
+}
+
+int gm_acq_last_timing(gm_acq* a, float* ms_mix, float* ms_corr, float* ms_decide) {
+    if (!a || !a->tm.on) return set_err(GM_ERR_INVALID_ARG, "timing not enabled");
+    if (int rc = ensure_device(a->device)) return rc;
+    HIPC(hipStreamSynchronize(a->stream));
+    float t = 0;
+    if (ms_mix) { HIPC(hipEventElapsedTime(&t, a->tm.ev[0], a->tm.ev[1])); *ms_mix = t; }
+    if (ms_corr) { HIPC(hipEventElapsedTime(&t, a->tm.ev[1], a->tm.ev[2])); *ms_corr = t; }
+    if (ms_decide) {
+        *ms_decide = 0;
+        if (a->tm.valid) { HIPC(hipEventElapsedTime(&t, a->tm.ev[2], a->tm.ev[3])); *ms_decide = t; }
+    }
+    return GM_OK;
+}
+
+int gm_acq_manager_mode_for(size_t n) { return n == 0 ? 0 : (n <= 4 ? 1 : 2); }   // update_mode :50-56
+
+int gm_acq_manager_pacing_and_list(int mode, uint32_t active, uint64_t* interval_ms, uint32_t* mask) {
+    if (!interval_ms || !mask) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    uint64_t interval; uint32_t size;                         // get_pacing_and_list :58-73
+    switch (mode) {
+        case 0: interval = 500; size = 32; break;
+        case 1: interval = 1000; size = 8; break;
+        case 2: interval = 2000; size = 5; break;
+        default: return set_err(GM_ERR_INVALID_ARG, "mode must be 0..2");
+    }
+    uint32_t m = 0, taken = 0;
+    for (uint32_t prn = 1; prn <= 32 && taken < size; ++prn)
+        if (!((active >> (prn - 1)) & 1u)) { m |= 1u << (prn - 1); ++taken; }
+    *interval_ms = interval; *mask = m;
+    return GM_OK;
+}
+
+}  // extern "C"
+
+// ====================================================================== ring mirror
+struct gm_ring {
+    int device = -1;
+    cf* d_buf = nullptr;
+    size_t size = 0, mask = 0;
+    uint64_t head = 0;
+};
+
+extern "C" {
+
+int gm_ring_create(size_t buf_size, gm_ring** out) {
+    if (!out) return set_err(GM_ERR_INVALID_ARG, "null out");
+    *out = nullptr;
+    if (!buf_size || (buf_size & (buf_size - 1))) return set_err(GM_ERR_INVALID_ARG, "Buffer size must be a power of two");
+    if (int rc = ensure_device(g_device)) return rc;
+    gm_ring* r = new gm_ring();
+    r->device = g_device; r->size = buf_size; r->mask = buf_size - 1;
+    hipError_t e = hipMalloc(&r->d_buf, buf_size * 8);
+    if (e == hipSuccess) e = hipMemset(r->d_buf, 0, buf_size * 8);
+    if (e != hipSuccess) { delete r; return hip_fail(e, "hipMalloc(ring)"); }
+    *out = r;
+    return GM_OK;
+}
+
+int gm_ring_destroy(gm_ring* r) {
+    if (!r) return GM_OK;
+    hipSetDevice(r->device);
+    hipFree(r->d_buf);
+    delete r;
+    return GM_OK;
+}
+
+int gm_ring_write_samples(gm_ring* r, const gm_c32* s, size_t n) {
+    if (!r || (!s && n)) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (n > r->size) return set_err(GM_ERR_OUT_OF_RANGE, "write larger than the ring");
+    if (int rc = ensure_device(r->device)) return rc;
+    const size_t start = size_t(r->head & r->mask);
+    if (start + n <= r->size) {
+        HIPC(hipMemcpy(r->d_buf + start, s, n * 8, hipMemcpyHostToDevice));
+    } else {
+        const size_t first = r->size - start;
+        HIPC(hipMemcpy(r->d_buf + start, s, first * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(r->d_buf, s + first, (n - first) * 8, hipMemcpyHostToDevice));
+    }
+    r->head += n;
+    return GM_OK;
+}
+
+int gm_ring_get_head(gm_ring* r, uint64_t* head) {
+    if (!r || !head) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    *head = r->head;
+    return GM_OK;
+}
+
+int gm_ring_copy_to_slice(gm_ring* r, uint64_t start, gm_c32* dest, size_t n) {
+    if (!r || (!dest && n)) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (n > r->size) return set_err(GM_ERR_OUT_OF_RANGE, "slice larger than the ring");
+    if (int rc = ensure_device(r->device)) return rc;
+    const size_t ps = size_t(start & r->mask);
+    if (ps + n <= r->size) {
+        HIPC(hipMemcpy(dest, r->d_buf + ps, n * 8, hipMemcpyDeviceToHost));
+    } else {
+        const size_t first = r->size - ps;
+        HIPC(hipMemcpy(dest, r->d_buf + ps, first * 8, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(dest + first, r->d_buf, (n - first) * 8, hipMemcpyDeviceToHost));
+    }
+    return GM_OK;
+}
+
+}  // extern "C"
+
+// ====================================================================== tracking handle
+struct gm_trk {
+    int device = -1;
+    gm_trk_cfg cfg{};
+    gm::TrkDevCfg dc{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t C = 0;
+    int slices = 1;
+    std::vector<int8_t> h_codes;
+    int8_t* d_codes = nullptr;
+    gm_trk_state* d_states = nullptr;
+    float* d_partials = nullptr;
+    uint8_t* d_ready = nullptr;
+    cf* d_scratch = nullptr; size_t scratch_cap = 0;
+    gm_trk_out* d_outs = nullptr; uint8_t *d_proc = nullptr, *d_lost = nullptr, *d_lostprn = nullptr;
+    uint32_t epochs_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false; uint32_t timed_launches = 0;
+};
+
+static int trk_reserve_epochs(gm_trk* t, uint32_t e) {
+    if (e <= t->epochs_cap) return GM_OK;
+    hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
+    const size_t n = size_t(e) * t->C;
+    HIPC(hipMalloc(&t->d_outs, n * sizeof(gm_trk_out)));
+    HIPC(hipMalloc(&t->d_proc, n)); HIPC(hipMalloc(&t->d_lost, n)); HIPC(hipMalloc(&t->d_lostprn, n));
+    t->epochs_cap = e;
+    return GM_OK;
+}
+
+extern "C" {
+
+int gm_loop_filter_new(float bw, float zeta, float gain, float* tau1, float* tau2) {
+    if (!tau1 || !tau2) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    loop_filter_new(bw, zeta, gain, tau1, tau2);
+    return GM_OK;
+}
+float gm_loop_filter_update(float tau1, float tau2, float d_err, float err, float dt) {   // :68-70
+    return d_err * (dt / tau1) + (d_err - err) * (tau2 / tau1);
+}
+
+int gm_trk_destroy(gm_trk* t) {
+    if (!t) return GM_OK;
+    if (t->device >= 0) hipSetDevice(t->device);
+    hipFree(t->d_codes); hipFree(t->d_states); hipFree(t->d_partials); hipFree(t->d_ready); hipFree(t->d_scratch);
+    hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
+    if (t->ev0) hipEventDestroy(t->ev0);
+    if (t->ev1) hipEventDestroy(t->ev1);
+    if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
+    delete t;
+    return GM_OK;
+}
+
+int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
+    if (!cfg || !out) return set_err(GM_ERR_INVALID_ARG, "null cfg/out");
+    *out = nullptr;
+    if (!(cfg->fs > 0) || !cfg->n_channels) return set_err(GM_ERR_INVALID_ARG, "fs and n_channels are required");
+    const uint32_t arms = cfg->n_arms ? cfg->n_arms : 3;
+    if (arms != 3 && arms != 5) return set_err(GM_ERR_INVALID_ARG, "n_arms must be 3 or 5");
+    if (cfg->codes && (!cfg->n_codes || !cfg->code_len)) return set_err(GM_ERR_INVALID_ARG, "n_codes/code_len required");
+    if (int rc = ensure_device(g_device)) return rc;
+    gm_trk* t = new gm_trk();
+    t->device = g_device; t->cfg = *cfg; t->C = cfg->n_channels;
+    gm::TrkDevCfg& d = t->dc;
+    d.fs = cfg->fs; d.n_channels = int(cfg->n_channels); d.n_arms = int(arms);
+    d.el_space = cfg->early_late_space > 0 ? cfg->early_late_space : 0.5f;
+    d.vel_space = cfg->very_early_late_space > 0 ? cfg->very_early_late_space : 1.0f;
+    d.code_index_mode = cfg->code_index_mode; d.boc11 = cfg->boc11;
+    d.gps_ca = cfg->codes ? 0 : 1;
+    d.code_len = cfg->codes ? int(cfg->code_len) : 1023;
+    d.code_len_f = float(d.code_len);
+    d.n_codes = cfg->codes ? int(cfg->n_codes) : 32;
+    d.lock_threshold = cfg->lock_threshold > 0 ? cfg->lock_threshold : 15.0f;
+    d.max_lost_epochs = cfg->max_lost_epochs ? cfg->max_lost_epochs : 20u;
+    loop_filter_new(cfg->pll_bw > 0 ? cfg->pll_bw : 25.0f, cfg->pll_zeta > 0 ? cfg->pll_zeta : 0.7f,
+                    cfg->pll_gain > 0 ? cfg->pll_gain : 0.25f, &d.pll_tau1, &d.pll_tau2);
+    loop_filter_new(cfg->dll_bw > 0 ? cfg->dll_bw : 2.0f, cfg->dll_zeta > 0 ? cfg->dll_zeta : 0.7f,
+                    cfg->dll_gain > 0 ? cfg->dll_gain : 1.0f, &d.dll_tau1, &d.dll_tau2);
+    d.pll_dt = cfg->pll_dt > 0 ? cfg->pll_dt : 0.001f;
+    d.dll_dt = cfg->dll_dt > 0 ? cfg->dll_dt : 0.001f;
+    d.nominal_code_rate = cfg->nominal_code_rate > 0 ? cfg->nominal_code_rate : CA_RATE;
+    if (cfg->codes) t->h_codes.assign(cfg->codes, cfg->codes + size_t(cfg->n_codes) * cfg->code_len);
+    else t->h_codes.assign(&ca_table().rows[0][0], &ca_table().rows[0][0] + 32 * 1023);
+
+    // slices per channel: fill the chip (>= ~1000 workgroups) without going under 256 samples each
+    const size_t n_nom = num_samples_per_code(d.nominal_code_rate, d.fs, d.code_len_f);
+    size_t target = (1024 + t->C - 1) / t->C;
+    if (target < 1) target = 1;
+    size_t per = ((n_nom + target - 1) / target + 255) / 256 * 256;
+    if (per < 256) per = 256;
+    size_t s = (n_nom + per - 1) / per;
+    t->slices = int(s < 1 ? 1 : (s > 256 ? 256 : s));
+
+    auto fail = [&](int code) { gm_trk_destroy(t); return code; };
+#define HIPT(expr)                                                     \
+    do {                                                               \
+        hipError_t _e = (expr);                                        \
+        if (_e != hipSuccess) return fail(hip_fail(_e, #expr));        \
+    } while (0)
+    HIPT(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    t->own_stream = true;
+    HIPT(hipMalloc(&t->d_codes, t->h_codes.size()));
+    HIPT(hipMemcpy(t->d_codes, t->h_codes.data(), t->h_codes.size(), hipMemcpyHostToDevice));
+    HIPT(hipMalloc(&t->d_states, sizeof(gm_trk_state) * t->C));
+    std::vector<gm_trk_state> init(t->C);
+    for (auto& st : init) {   // TrackingChannel::new :118-146
+        memset(&st, 0, sizeof(st));
+        st.num_samples_per_code = n_nom;
+        st.code_rate = d.nominal_code_rate;
+    }
+    HIPT(hipMemcpy(t->d_states, init.data(), sizeof(gm_trk_state) * t->C, hipMemcpyHostToDevice));
+    HIPT(hipMalloc(&t->d_partials, sizeof(float) * t->C * size_t(t->slices) * 10));
+    HIPT(hipMalloc(&t->d_ready, t->C));
+    HIPT(hipMemset(t->d_ready, 0, t->C));
+    HIPT(hipEventCreate(&t->ev0));
+    HIPT(hipEventCreate(&t->ev1));
+    if (int rc = trk_reserve_epochs(t, 1)) return fail(rc);
+#undef HIPT
+    *out = t;
+    return GM_OK;
+}
+
+int gm_trk_set_stream(gm_trk* t, void* s) {
+    if (!t) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (t->own_stream && t->stream) { hipStreamSynchronize(t->stream); hipStreamDestroy(t->stream); }
+    t->stream = reinterpret_cast<hipStream_t>(s);
+    t->own_stream = false;
+    return GM_OK;
+}
+
+int gm_trk_get_state(gm_trk* t, uint32_t ch, gm_trk_state* out) {
+    if (!t || !out || ch >= t->C) return set_err(GM_ERR_INVALID_ARG, "bad channel");
+    if (int rc = ensure_device(t->device)) return rc;
+    HIPC(hipStreamSynchronize(t->stream));
+    HIPC(hipMemcpy(out, t->d_states + ch, sizeof(*out), hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+int gm_trk_set_state(gm_trk* t, uint32_t ch, const gm_trk_state* in) {
+    if (!t || !in || ch >= t->C) return set_err(GM_ERR_INVALID_ARG, "bad channel");
+    if (int rc = ensure_device(t->device)) return rc;
+    HIPC(hipStreamSynchronize(t->stream));
+    HIPC(hipMemcpy(t->d_states + ch, in, sizeof(*in), hipMemcpyHostToDevice));
+    return GM_OK;
+}
+
+int gm_trk_start(gm_trk* t, uint32_t ch, const gm_acq_result* r) {   // :148-154
+    if (!t || !r || ch >= t->C) return set_err(GM_ERR_INVALID_ARG, "bad channel");
+    gm_trk_state s;
+    if (int rc = gm_trk_get_state(t, ch, &s)) return rc;
+    s.prn = r->prn;
+    s.carrier_freq = r->carrier_freq;
+    s.code_phase = r->code_phase_chips;
+    s.next_sample_index = r->sample_global_index;
+    s.active = 1;
+    if (t->cfg.code_index_mode == GM_CODE_INDEX_FIXED && s.code_rate == 0.0f)
+        s.code_rate = t->dc.nominal_code_rate;   // FIXED: undo reset()'s code_rate = 0 (reference bug)
+    return gm_trk_set_state(t, ch, &s);
+}
+
+int gm_trk_reset(gm_trk* t, uint32_t ch) {   // :311-327
+    if (!t || ch >= t->C) return set_err(GM_ERR_INVALID_ARG, "bad channel");
+    gm_trk_state s;
+    if (int rc = gm_trk_get_state(t, ch, &s)) return rc;
+    const uint64_t n = s.num_samples_per_code;
+    memset(&s, 0, sizeof(s));
+    s.num_samples_per_code = n;   // reset() leaves num_samples_per_code untouched
+    return gm_trk_set_state(t, ch, &s);
+}
+
+int gm_trk_get_ca_chip(gm_trk* t, uint32_t ch, float phase, float* chip) {   // :274-277
+    if (!t || !chip || ch >= t->C) return set_err(GM_ERR_INVALID_ARG, "bad channel");
+    gm_trk_state s;
+    if (int rc = gm_trk_get_state(t, ch, &s)) return rc;
+    const int len = t->dc.code_len;
+    int row, idx;
+    const float f = floorf(phase);
+    if (t->dc.code_index_mode == GM_CODE_INDEX_FAITHFUL) {
+        row = t->dc.gps_ca ? int(s.prn) : int(s.prn) - 1;
+        if (!(f > 0.0f)) idx = 0;
+        else if (f >= 18446744073709551616.0f) idx = int(18446744073709551615ull % (unsigned long long)len);
+        else idx = int((unsigned long long)f % (unsigned long long)len);
+    } else {
+        row = int(s.prn) - 1;
+        long li = long(f) % len;
+        idx = int(li < 0 ? li + len : li);
+    }
+    if (row < 0 || row >= t->dc.n_codes) return set_err(GM_ERR_OUT_OF_RANGE, "code table row out of bounds (the reference panics)");
+    *chip = float(t->h_codes[size_t(row) * len + idx]);
+    return GM_OK;
+}
+
+static int trk_unit(gm_trk* t, uint32_t ch, const gm_c32* samples, size_t n, int mode, gm_trk_out* out, uint8_t* lost,
+                    uint8_t* lost_prn) {
+    if (!t || !samples || !out || ch >= t->C) return set_err(GM_ERR_INVALID_ARG, "bad argument");
+    if (int rc = ensure_device(t->device)) return rc;
+    gm_trk_state s;
+    if (int rc = gm_trk_get_state(t, ch, &s)) return rc;
+    if (n < s.num_samples_per_code || s.num_samples_per_code == 0)
+        return set_err(GM_ERR_OUT_OF_RANGE, "fewer samples than num_samples_per_code (the reference panics)");
+    const int row = t->dc.gps_ca ? (t->dc.code_index_mode == GM_CODE_INDEX_FAITHFUL ? int(s.prn) : int(s.prn) - 1)
+                                 : int(s.prn) - 1;
+    if (row < 0 || row >= t->dc.n_codes) return set_err(GM_ERR_OUT_OF_RANGE, "code table row out of bounds (the reference panics)");
+    const size_t need = s.num_samples_per_code;
+    if (need > t->scratch_cap) {
+        hipFree(t->d_scratch); t->d_scratch = nullptr; t->scratch_cap = 0;
+        HIPC(hipMalloc(&t->d_scratch, need * 8 * 2));
+        t->scratch_cap = need * 2;
+    }
+    HIPC(hipMemcpyAsync(t->d_scratch, samples, need * 8, hipMemcpyHostToDevice, t->stream));
+    // the unit entries run regardless of ChannelState (the reference's early_late_correlation/do_work do not test it)
+    const uint8_t was_active = s.active;
+    if (!was_active) { s.active = 1; HIPC(hipMemcpyAsync(t->d_states + ch, &s, sizeof(s), hipMemcpyHostToDevice, t->stream)); HIPC(hipStreamSynchronize(t->stream)); }
+    gm::TrkSrc src;
+    src.base = t->d_scratch; src.mask = ~0ull; src.head = 0; src.linear = 1; src.only_channel = int(ch);
+    gm::launch_trk_epoch(t->stream, t->dc, t->d_codes, t->d_states, src, t->slices, t->d_partials, t->d_ready, mode,
+                         t->d_outs, t->d_proc, t->d_lost, t->d_lostprn);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(t->stream));
+    HIPC(hipMemcpy(out, t->d_outs + ch, sizeof(*out), hipMemcpyDeviceToHost));
+    uint8_t l = 0, lp = 0;
+    HIPC(hipMemcpy(&l, t->d_lost + ch, 1, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(&lp, t->d_lostprn + ch, 1, hipMemcpyDeviceToHost));
+    if (lost) *lost = l;
+    if (lost_prn) *lost_prn = lp;
+    if (!was_active && !l) {   // restore the caller's ChannelState
+        gm_trk_state s2;
+        HIPC(hipMemcpy(&s2, t->d_states + ch, sizeof(s2), hipMemcpyDeviceToHost));
+        s2.active = 0;
+        HIPC(hipMemcpy(t->d_states + ch, &s2, sizeof(s2), hipMemcpyHostToDevice));
+    }
+    return GM_OK;
+}
+
+int gm_trk_correlate(gm_trk* t, uint32_t ch, const gm_c32* samples, size_t n, gm_trk_out* out) {
+    return trk_unit(t, ch, samples, n, gm::TRK_MODE_CORRELATE, out, nullptr, nullptr);
+}
+int gm_trk_do_work(gm_trk* t, uint32_t ch, const gm_c32* samples, size_t n, gm_trk_out* out, uint8_t* lost, uint8_t* lost_prn) {
+    return trk_unit(t, ch, samples, n, gm::TRK_MODE_DO_WORK, out, lost, lost_prn);
+}
+
+int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
+    if (!t || !ring || !epochs) return set_err(GM_ERR_INVALID_ARG, "bad argument");
+    if (t->device != ring->device) return set_err(GM_ERR_INVALID_ARG, "ring lives on another device");
+    if (int rc = ensure_device(t->device)) return rc;
+    if (int rc = trk_reserve_epochs(t, epochs)) return rc;
+    gm::TrkSrc src;
+    src.base = ring->d_buf; src.mask = ring->mask; src.head = ring->head; src.linear = 0; src.only_channel = -1;
+    if (t->timing) HIPC(hipEventRecord(t->ev0, t->stream));
+    for (uint32_t e = 0; e < epochs; ++e) {
+        const size_t o = size_t(e) * t->C;
+        gm::launch_trk_epoch(t->stream, t->dc, t->d_codes, t->d_states, src, t->slices, t->d_partials, t->d_ready,
+                             gm::TRK_MODE_DO_WORK, t->d_outs + o, t->d_proc + o, t->d_lost + o, t->d_lostprn + o);
+    }
+    if (t->timing) { HIPC(hipEventRecord(t->ev1, t->stream)); t->timed_launches = epochs; }
+    HIPC(hipGetLastError());
+    return GM_OK;
+}
+
+int gm_trk_update_all(gm_trk* t, gm_ring* ring, uint32_t max_epochs, gm_trk_out* outs, uint8_t* processed, uint8_t* lost,
+                      uint32_t* epochs_done) {
+    if (int rc = gm_trk_update_all_dev(t, ring, max_epochs)) return rc;
+    HIPC(hipStreamSynchronize(t->stream));
+    const size_t n = size_t(max_epochs) * t->C;
+    std::vector<uint8_t> proc(n);
+    HIPC(hipMemcpy(proc.data(), t->d_proc, n, hipMemcpyDeviceToHost));
+    if (outs) HIPC(hipMemcpy(outs, t->d_outs, n * sizeof(gm_trk_out), hipMemcpyDeviceToHost));
+    if (processed) memcpy(processed, proc.data(), n);
+    if (lost) HIPC(hipMemcpy(lost, t->d_lost, n, hipMemcpyDeviceToHost));
+    if (epochs_done) {
+        uint32_t done = 0;
+        for (uint32_t e = 0; e < max_epochs; ++e) {
+            bool any = false;
+            for (uint32_t c = 0; c < t->C; ++c) any |= proc[size_t(e) * t->C + c] != 0;
+            if (any) done = e + 1;
+        }
+        *epochs_done = done;
+    }
+    return GM_OK;
+}
+
+int gm_trk_synchronize(gm_trk* t) {
+    if (!t) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(t->device)) return rc;
+    HIPC(hipStreamSynchronize(t->stream));
+    return GM_OK;
+}
+
+int gm_trk_enable_timing(gm_trk* t, int on) {
+    if (!t) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    t->timing = on != 0;
+    return GM_OK;
+}
+
+int gm_trk_last_timing(gm_trk* t, float* ms_total, uint32_t* launches) {
+    if (!t || !t->timing) return set_err(GM_ERR_INVALID_ARG, "timing not enabled");
+    if (int rc = ensure_device(t->device)) return rc;
+    HIPC(hipStreamSynchronize(t->stream));
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, t->ev0, t->ev1));
+    if (ms_total) *ms_total = ms;
+    if (launches) *launches = t->timed_launches;
+    return GM_OK;
+}
+
+}  // extern "C"

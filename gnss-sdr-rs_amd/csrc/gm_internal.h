@@ -1,0 +1,77 @@
+// gm_internal.h — shared declarations between the kernel translation units and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gnss_mi355x.h"
+#include "fft_core.h"
+
+namespace gm {
+
+// One entry per shipped transform size: launchers for the kernels instantiated on that plan.
+struct PlanOps {
+    int n;             // transform length
+    int threads;       // workgroup size
+    int tw_total;      // base-twiddle table entries (per direction)
+    int lds_bytes;     // static LDS per workgroup of the correlation kernel
+    void (*fill_tw)(cf* tw, bool inverse);
+    // stage F: carrier mix (apply_doppler_shift, doppler_shift.rs:25-58) fused into the forward FFT
+    // (do_acquisition.rs:177-182).  One workgroup per (doppler bin, ms block); shared by all PRNs.
+    void (*mix_fft)(hipStream_t, const void* samples, int fmt, const cf* tables, const cf* tw_fwd,
+                    cf* spectra, int n_bins, int n_int);
+    // stage C: x conj(code spectrum) -> inverse FFT -> |.|^2 accumulated over the integrations ->
+    // {max, first argmax, sum} per (worker, bin)  (do_acquisition.rs:184-202, 229-235)
+    void (*corr)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
+                 uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
+                 int n_int);
+    // AcquisitionWorker::new's replica spectrum (do_acquisition.rs:132-138)
+    void (*code_fft)(hipStream_t, const int8_t* code_samples, const cf* tw_fwd, cf* code_fft, int n_codes);
+    // FFT<T>::execute (fft.rs:21-25) on `batch` contiguous transforms
+    void (*fft_batch)(hipStream_t, cf* data, const cf* tw, int inverse, int batch);
+};
+const PlanOps* find_plan(int n);
+int list_plans(uint32_t* sizes, int cap);
+
+// elementwise apply_doppler_shift (doppler_shift.rs:25-58)
+void launch_apply_doppler(hipStream_t, const cf* s, const cf* t, cf* out, size_t n);
+// |X|^2 (fft.rs:27-29)
+void launch_power(hipStream_t, const cf* x, float* p, size_t n);
+
+// decision replay (do_acquisition.rs:195-225 + 229-238) from per-(worker,bin) metrics
+struct DecideArgs {
+    const float* mmax; const uint32_t* margmax; const float* msum;  // [n_prn][n_bins]
+    const float* table_freq;                                        // [n_bins]
+    const uint8_t* prn_ids;                                         // [n_prn]
+    uint64_t mask_lo;                                               // worker i searched <-> bit i (i < 64), else all
+    int n_prn, n_bins, fft_size;
+    float fs, threshold, code_rate;
+    uint64_t local_tail;
+    gm_acq_result* results; uint8_t* found;                         // [n_prn]
+};
+void launch_decide(hipStream_t, const DecideArgs&);
+
+// ---------------------------------------------------------------- tracking
+struct TrkDevCfg {
+    float fs;
+    int n_channels, n_arms;
+    float el_space, vel_space;
+    int code_index_mode, boc11;
+    int code_len;             // chips per period
+    float code_len_f;
+    int gps_ca;               // 1: built-in C/A table rows (row = prn or prn-1 by mode)
+    int n_codes;
+    float lock_threshold; uint32_t max_lost_epochs;
+    float pll_tau1, pll_tau2, dll_tau1, dll_tau2, pll_dt, dll_dt;
+    float nominal_code_rate;
+};
+enum { TRK_MODE_CORRELATE = 0, TRK_MODE_DO_WORK = 1 };
+// sample source: ring (mask = size-1, absolute index = next_sample_index + i) or linear (mask = ~0, base 0)
+struct TrkSrc {
+    const cf* base; uint64_t mask; uint64_t head; int linear;   // linear: index i directly, no head test
+    int only_channel;                                           // >= 0: run just this channel (unit entries)
+};
+void launch_trk_epoch(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_trk_state* d_states,
+                      const TrkSrc&, int slices, float* d_partials, uint8_t* d_ready, int mode,
+                      gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost, uint8_t* d_lost_prn);
+
+}  // namespace gm

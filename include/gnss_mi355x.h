@@ -1,0 +1,260 @@
+/*
+ * gnss_mi355x.h — C ABI of the MI355X-native acquisition + tracking hot path.
+ *
+ * Drop-in boundary for the acquisition / tracking channel API of kewei/gnss-sdr-rs.  The reference
+ * has no FFI for this path (its API is Rust: SURVEY.md §8b); every entry point below names the
+ * reference item (file:line, relative to the reference checkout) it replaces, and INTEGRATION.md
+ * shows the Rust `extern "C"` binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; no exceptions cross the boundary
+ *   - every function returns a gm_status (0 = GM_OK, < 0 = error); absence (`Option::None`) is
+ *     reported through `found[]` flags, never through the status
+ *   - handles are opaque and thread-compatible: one thread per handle at a time (the reference
+ *     hands one `&mut` worker/channel to each rayon task)
+ *   - host pointers unless the name ends in `_dev`; `_dev` pointers are HIP device pointers on the
+ *     handle's device and the call is asynchronous on the handle's stream
+ *   - arithmetic type: f32 everywhere, as in the reference (num_complex::Complex32 = {f32 re, im})
+ *   - the compute path is HIP on gfx950 only; there is NO CPU fallback — without a usable device
+ *     every compute entry returns GM_ERR_NO_DEVICE
+ */
+#ifndef GNSS_MI355X_H
+#define GNSS_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_ABI_VERSION 1
+
+typedef enum {
+    GM_OK = 0,
+    GM_ERR_INVALID_ARG = -1,   /* null pointer, bad size, prn out of range ... (the reference panics) */
+    GM_ERR_UNSUPPORTED_N = -2, /* no in-LDS FFT plan for this fft_size (see gm_fft_supported_sizes) */
+    GM_ERR_NO_DEVICE = -3,     /* no HIP device / gm_init not called */
+    GM_ERR_HIP = -4,           /* a HIP runtime call failed; gm_last_error() has the text */
+    GM_ERR_OUT_OF_RANGE = -5,  /* slice/index out of range (the reference panics: index out of bounds) */
+    GM_ERR_ALIGNMENT = -6,     /* fft_size % 8 != 0: the reference's SIMD tails (doppler_shift.rs:26,
+                                  do_acquisition.rs:230-234) would leave stale / uncounted elements */
+    GM_ERR_NOMEM = -7
+} gm_status;
+
+/* num_complex::Complex32 */
+typedef struct { float re, im; } gm_c32;
+
+/* ------------------------------------------------------------------ library / device */
+int gm_abi_version(void);
+/* Select the HIP device for subsequently created handles (one process per GPU). */
+int gm_init(int device);
+int gm_device_count(int *count);
+const char *gm_last_error(void);
+const char *gm_status_string(int status);
+
+/* ------------------------------------------------------------------ constants / code table
+ * GPS_CA_CODE_32_PRN (src/constants/gps_ca_constants.rs:1-1346): row r <-> PRN r+1, chips +-1. */
+int gm_ca_code_row(int row, int8_t out_chips[1023]);
+/* generate_ca_code_samples(prn, code_rate, f_sampling) (src/utilities/ca_code.rs:12-27).
+ * *n_out = round(fs/(code_rate/1023)); writes min(n, cap) samples.  GM_ERR_OUT_OF_RANGE where the
+ * reference would panic (prn not in 1..=32, chip index reaching 1023). */
+int gm_generate_ca_code_samples(uint8_t prn, float code_rate, float f_sampling, int8_t *out, size_t cap,
+                                size_t *n_out);
+
+/* ------------------------------------------------------------------ Doppler wipe-off
+ * DopplerShiftTable::new(f_if, doppler_freq_hz, fs, num_samples) (src/acquisition/doppler_shift.rs:10-22).
+ * Host-side (glibc cosf/sinf, exactly the reference's arithmetic); *doppler_freq_hz_out receives the
+ * stored field (= f_if + doppler, :20). */
+int gm_doppler_table_new(float f_if, float doppler_freq_hz, float fs, size_t num_samples,
+                         float *doppler_freq_hz_out, gm_c32 *table_out);
+/* apply_doppler_shift(samples, table, output) (doppler_shift.rs:25-58) on the GPU.
+ * Writes only the first 4*floor(n/4) outputs, like the reference. */
+int gm_apply_doppler_shift(const gm_c32 *samples, const gm_c32 *table, gm_c32 *output, size_t n);
+
+/* ------------------------------------------------------------------ FFT<T> / RealFFT<T> (src/fft.rs:5-56)
+ * Unnormalised complex FFT, in place, `batch` contiguous transforms of length n.
+ * dir: 0 forward (FFT::execute), 1 inverse. */
+int gm_fft_c2c_f32(size_t n, int dir, gm_c32 *inout, size_t batch);
+/* FFT::power_spectrum (src/fft.rs:27-29): transforms `inout` in place and writes |X|^2. */
+int gm_fft_power_spectrum_f32(size_t n, gm_c32 *inout, float *power);
+/* RealFFT::execute (src/fft.rs:45-49): n real inputs -> n/2+1 bins. */
+int gm_rfft_f32(size_t n, const float *in, gm_c32 *out);
+/* Sizes with an in-LDS plan; returns how many were written (<= cap). */
+int gm_fft_supported_sizes(uint32_t *sizes, int cap);
+
+/* ------------------------------------------------------------------ Acquisition
+ * AcquisitionResult (src/acquisition/do_acquisition.rs:93-116) + the winning table index. */
+typedef struct {
+    uint8_t prn;
+    uint64_t code_phase_samples;
+    float code_phase_chips;
+    float carrier_freq;        /* DopplerShiftTable.doppler_freq_hz of the winning bin = IF + Doppler */
+    float fs;
+    float mag_relative;        /* raw accumulated peak power (do_acquisition.rs:219) */
+    uint64_t sample_global_index;
+    int32_t doppler_bin;       /* extra: index into the table list */
+} gm_acq_result;
+
+typedef enum { GM_FMT_C32 = 0, GM_FMT_I8_IQ = 1, GM_FMT_I8_REAL = 2 } gm_sample_format;
+
+typedef struct {
+    float fs;                  /* freq_sampling_hz */
+    float f_if;                /* used only when `tables` is NULL */
+    uint32_t fft_size;         /* samples per code period (do_acquisition.rs:249-251) */
+    uint32_t n_integrations;   /* LONG_SAMPLES_LENGTH = 10 (:23) */
+    uint32_t n_bins;           /* Doppler bins; reference: 14000/500+1 = 29 (:248) */
+    const float *doppler_hz;   /* [n_bins] offsets from f_if, ascending as the reference iterates */
+    const gm_c32 *tables;      /* optional [n_bins][fft_size] caller-built DopplerShiftTable.table */
+    const float *table_freq;   /* optional [n_bins] DopplerShiftTable.doppler_freq_hz (with `tables`) */
+    uint32_t n_prn;            /* workers; reference: PRN_SEARCH_ACQUISITION_TOTAL = 32 (:22) */
+    const uint8_t *prn_ids;    /* [n_prn] PRN of each worker (1..=32 when `codes` is NULL) */
+    const int8_t *codes;       /* optional [n_prn][code_len] +-1 chips for non-GPS code families */
+    uint32_t code_len;         /* chips per period of `codes` (ignored when NULL: 1023) */
+    float code_rate;           /* chips/s of `codes` (ignored when NULL: 1.023e6) */
+    float threshold;           /* is_good_satellite ratio, 7.0 (:237); 0 -> 7.0 */
+} gm_acq_cfg;
+
+typedef struct gm_acq gm_acq;
+
+/* = building the Doppler tables (:252-262) + AcquisitionWorker::new for every PRN (:268-271):
+ * code replicas resampled, their forward FFTs computed on the GPU, plans/twiddles uploaded. */
+int gm_acq_create(const gm_acq_cfg *cfg, gm_acq **out);
+int gm_acq_destroy(gm_acq *a);
+
+/* The batched equivalent of `workers.par_iter_mut()...search_satellite(...)` (:302-313, :158-226).
+ *   samples  : n_integrations*fft_size samples in `fmt`
+ *   prn_mask : bit i set <-> worker i searched (the (mask >> (prn-1)) & 1 test for the default list)
+ *   results[i], found[i] for every worker i (found = 0 <-> None).
+ * Identical outcome to the reference loop: ascending-Doppler running best, first bin passing
+ * is_good_satellite wins (early exit), argmax = first strict maximum. */
+int gm_acq_search(gm_acq *a, const void *samples, size_t n_samples, int fmt, uint64_t local_tail,
+                  uint64_t prn_mask, gm_acq_result *results, uint8_t *found);
+int gm_acq_search_c32(gm_acq *a, const gm_c32 *samples, size_t n_samples, uint64_t local_tail,
+                      uint64_t prn_mask, gm_acq_result *results, uint8_t *found);
+int gm_acq_search_i8(gm_acq *a, const int8_t *iq_interleaved, size_t n_samples, uint64_t local_tail,
+                     uint64_t prn_mask, gm_acq_result *results, uint8_t *found);
+
+/* Device-resident form: samples already in HBM; kernels are enqueued on the handle's stream and the
+ * call returns without synchronising.  d_metrics (optional, may be NULL -> internal buffer) receives
+ * 3*n_prn*n_bins 32-bit words: max f32 [P][D], argmax u32 [P][D], sum f32 [P][D]. */
+int gm_acq_search_dev(gm_acq *a, const void *d_samples, int fmt, void *d_metrics);
+/* Which workers the device-resident form searches (bit i <-> worker i); default: all. */
+int gm_acq_set_prn_mask(gm_acq *a, uint64_t prn_mask);
+/* Replay the reference's decision (running best + ratio test + early exit) on the GPU from a metrics
+ * block laid out as above for `n_prn` workers (e.g. an all-gathered one).  prn_ids: host [n_prn].
+ * Asynchronous; results land in an internal device buffer read back by gm_acq_fetch_results. */
+int gm_acq_decide_dev(gm_acq *a, const void *d_metrics, uint32_t n_prn, const uint8_t *prn_ids,
+                      uint64_t local_tail);
+int gm_acq_fetch_results(gm_acq *a, uint32_t n_prn, gm_acq_result *results, uint8_t *found); /* syncs */
+int gm_acq_synchronize(gm_acq *a);
+/* Use an existing HIP stream (e.g. torch's current stream) instead of the handle's own. */
+int gm_acq_set_stream(gm_acq *a, void *hip_stream);
+
+/* Per-(worker, bin) planes of the last search: max, first-argmax, sum of the accumulated power
+ * plane ([n_prn][n_bins] each; any pointer may be NULL).  For parity tests and the all-gather. */
+int gm_acq_metrics(gm_acq *a, float *max, uint32_t *argmax, float *sum);
+/* ca_code_samples_fft of worker i (AcquisitionWorker field, :126): fft_size bins. */
+int gm_acq_code_fft(gm_acq *a, uint32_t worker, gm_c32 *out);
+/* The table list in use: [n_bins][fft_size] and [n_bins] (either may be NULL). */
+int gm_acq_tables(gm_acq *a, gm_c32 *tables, float *table_freq);
+/* Kernel timing of the last gm_acq_search*_dev call, measured with HIP events on the handle's
+ * stream: ms_mix_fft (stage F), ms_corr (stage C, the dominant kernel), ms_decide.  Enable first. */
+int gm_acq_enable_timing(gm_acq *a, int on);
+int gm_acq_last_timing(gm_acq *a, float *ms_mix_fft, float *ms_corr, float *ms_decide);
+
+/* AcquisitionManager (do_acquisition.rs:39-74): mode 0 ColdStart / 1 WarmStart / 2 SteadyState. */
+int gm_acq_manager_mode_for(size_t tracked_count);
+int gm_acq_manager_pacing_and_list(int mode, uint32_t active_prn_mask, uint64_t *interval_ms, uint32_t *mask);
+
+/* ------------------------------------------------------------------ MulticastRingBuffer device mirror
+ * (src/utilities/multicast_ring_buffer.rs:36-130): power-of-two ring of Complex32 addressed by the
+ * absolute sample index `head`; the mirror keeps the same bytes in HBM for the tracking kernels. */
+typedef struct gm_ring gm_ring;
+int gm_ring_create(size_t buf_size, gm_ring **out);                      /* ::new :46-61 */
+int gm_ring_destroy(gm_ring *r);
+int gm_ring_write_samples(gm_ring *r, const gm_c32 *samples, size_t n);  /* :66-101 */
+int gm_ring_get_head(gm_ring *r, uint64_t *head);                        /* :103-105 */
+int gm_ring_copy_to_slice(gm_ring *r, uint64_t start, gm_c32 *dest, size_t n); /* :107-129 */
+
+/* ------------------------------------------------------------------ Tracking
+ * The evolving fields of TrackingChannel (src/tracking/do_tracking.rs:88-116). */
+typedef struct {
+    uint8_t prn;
+    uint8_t active;            /* state == ChannelState::Tracking(prn) */
+    uint8_t reserved[2];
+    uint32_t lost_counter;
+    uint64_t next_sample_index;
+    uint64_t num_samples_per_code;
+    float carrier_freq, carrier_phase, carrier_error, carrier_nco;
+    float code_phase, code_error, code_nco, code_rate;
+    float i_prompt, q_prompt;
+} gm_trk_state;
+
+/* Correlator outputs of one epoch: (i_p,q_p,i_e,q_e,i_l,q_l) = early_late_correlation() :231-272,
+ * plus very-early / very-late for 5-arm configurations. */
+typedef struct {
+    float ip, qp, ie, qe, il, ql, ive, qve, ivl, qvl;
+} gm_trk_out;
+
+typedef enum { GM_CODE_INDEX_FAITHFUL = 0, GM_CODE_INDEX_FIXED = 1 } gm_code_index_mode;
+
+typedef struct {
+    float fs;
+    uint32_t n_channels;       /* NUM_OF_CHANNELS = 15 (:18) */
+    uint32_t n_arms;           /* 3 (E/P/L, reference) or 5 (VE/E/P/L/VL) */
+    float early_late_space;    /* EARLY_LATE_SPACE = 0.5 chips (:28); 0 -> 0.5 */
+    float very_early_late_space; /* 5-arm only; 0 -> 1.0 */
+    int32_t code_index_mode;   /* FAITHFUL: get_ca_chip indexes row `prn` and saturates negative phases to
+                                  chip 0 exactly like :274-277; FIXED: row prn-1, wrapping */
+    int32_t boc11;             /* 1: multiply the chip by the BOC(1,1) sub-carrier sign (no reference code) */
+    const int8_t *codes;       /* optional [n_codes][code_len] custom +-1 chips (NULL: GPS C/A table) */
+    uint32_t n_codes, code_len;
+    float nominal_code_rate;   /* 0 -> 1.023e6 */
+    /* loop constants (:16-27); 0 -> reference value */
+    float pll_bw, pll_zeta, pll_gain, dll_bw, dll_zeta, dll_gain, pll_dt, dll_dt;
+    float lock_threshold;      /* LOCK_THRESHOLD = 15 (:16) */
+    uint32_t max_lost_epochs;  /* MAX_LOST_EPOCHS = 20 (:17) */
+} gm_trk_cfg;
+
+typedef struct gm_trk gm_trk;
+
+int gm_trk_create(const gm_trk_cfg *cfg, gm_trk **out);   /* TrackingManager::new :336-348 + Channel::new :118-146 */
+int gm_trk_destroy(gm_trk *t);
+int gm_trk_start(gm_trk *t, uint32_t ch, const gm_acq_result *r);      /* TrackingChannel::start :148-154 */
+int gm_trk_reset(gm_trk *t, uint32_t ch);                              /* ::reset :311-327 */
+int gm_trk_get_state(gm_trk *t, uint32_t ch, gm_trk_state *out);
+int gm_trk_set_state(gm_trk *t, uint32_t ch, const gm_trk_state *in);
+/* get_ca_chip(phase) :274-277 for channel ch (host-side table look-up with the configured mode). */
+int gm_trk_get_ca_chip(gm_trk *t, uint32_t ch, float phase, float *chip);
+/* LoopFilter::new / ::update (:52-71), host-side scalars. */
+int gm_loop_filter_new(float noise_bw, float damping, float gain, float *tau1, float *tau2);
+float gm_loop_filter_update(float tau1, float tau2, float d_err, float err, float dt);
+
+/* early_late_correlation() :231-272 for one channel on caller-supplied samples
+ * (n must equal the channel's num_samples_per_code): advances carrier_phase / code_phase and sets
+ * i_prompt/q_prompt exactly like the reference; no loop filters, no lock logic. */
+int gm_trk_correlate(gm_trk *t, uint32_t ch, const gm_c32 *samples, size_t n, gm_trk_out *out);
+/* do_work() :183-210 on caller-supplied samples (the reference's real-data test path, :734-739).
+ * *lost = 1 <-> Some(TrackingMessage::SatelliteLost); *lost_prn = the prn the reference puts in the
+ * message (0, because reset() runs first, :199-201). */
+int gm_trk_do_work(gm_trk *t, uint32_t ch, const gm_c32 *samples, size_t n, gm_trk_out *out, uint8_t *lost,
+                   uint8_t *lost_prn);
+/* The batched equivalent of TrackingManager::process_channels' par_iter over active channels
+ * (:364-371) repeated while data is available: up to `max_epochs` passes; in each pass every active
+ * channel with head >= next_sample_index + num_samples_per_code runs update() :160-180 against the
+ * device ring.  outs: [max_epochs][n_channels] (may be NULL); processed/lost: [max_epochs][n_channels]
+ * flags (may be NULL).  *epochs_done = passes in which at least one channel ran. */
+int gm_trk_update_all(gm_trk *t, gm_ring *ring, uint32_t max_epochs, gm_trk_out *outs, uint8_t *processed,
+                      uint8_t *lost, uint32_t *epochs_done);
+/* Asynchronous device-resident form for benchmarking: enqueues `epochs` passes, no host readback. */
+int gm_trk_update_all_dev(gm_trk *t, gm_ring *ring, uint32_t epochs);
+int gm_trk_synchronize(gm_trk *t);
+int gm_trk_set_stream(gm_trk *t, void *hip_stream);
+int gm_trk_enable_timing(gm_trk *t, int on);
+int gm_trk_last_timing(gm_trk *t, float *ms_correlate_total, uint32_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNSS_MI355X_H */

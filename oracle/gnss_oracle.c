@@ -1,0 +1,718 @@
+/*
+ * gnss_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  See gnss_oracle.h.
+ *
+ * Restates, in plain C with f32 arithmetic in the reference's operation order:
+ *   src/utilities/ca_code.rs:12-27, src/constants/gps_ca_constants.rs (regenerated),
+ *   src/acquisition/doppler_shift.rs:10-58, src/acquisition/do_acquisition.rs:39-74,130-238,302-313,
+ *   src/tracking/do_tracking.rs:52-71,118-327, src/utilities/multicast_ring_buffer.rs:46-129,
+ *   src/fft.rs:5-56.
+ * Compile with -ffp-contract=off: rustc never fuses a*b+c.
+ * libm calls (cosf/sinf/atanf/sqrtf/fmodf/roundf/floorf) are glibc's, which is what Rust's
+ * f32::{cos,sin,atan,sqrt,%,round,floor} lower to on x86_64-unknown-linux-gnu.
+ */
+#include "gnss_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PI_F 3.14159265358979323846f /* std::f32::consts::PI */
+
+/* ------------------------------------------------------------------------------------------
+ * C/A code: IS-GPS-200 G1/G2 generator.  Reproduces GPS_CA_CODE_32_PRN
+ * (src/constants/gps_ca_constants.rs:1-1346): row r <-> PRN r+1, chip bit 1 -> +1, 0 -> -1.
+ * ------------------------------------------------------------------------------------------ */
+static const uint16_t G2_DELAY[32] = { /* IS-GPS-200 Table 3-Ia, code delay chips */
+    5,   6,   7,   8,   17,  18,  139, 140, 141, 251, 252, 254, 255, 256, 257, 258,
+    469, 470, 471, 472, 473, 474, 509, 512, 513, 514, 515, 516, 859, 860, 861, 862};
+
+static void lfsr1023(const int *taps, int ntaps, uint8_t out[1023]) {
+    uint8_t reg[10];
+    for (int i = 0; i < 10; i++) reg[i] = 1;
+    for (int i = 0; i < 1023; i++) {
+        out[i] = reg[9];
+        uint8_t fb = 0;
+        for (int t = 0; t < ntaps; t++) fb ^= reg[taps[t] - 1];
+        for (int j = 9; j > 0; j--) reg[j] = reg[j - 1];
+        reg[0] = fb;
+    }
+}
+
+int orc_ca_code_row(int row, int8_t out[1023]) {
+    if (row < 0 || row > 31) return -1;
+    static const int g1_taps[] = {3, 10};
+    static const int g2_taps[] = {2, 3, 6, 8, 9, 10};
+    uint8_t g1[1023], g2[1023];
+    lfsr1023(g1_taps, 2, g1);
+    lfsr1023(g2_taps, 6, g2);
+    int delay = G2_DELAY[row];
+    for (int i = 0; i < 1023; i++) {
+        uint8_t bit = g1[i] ^ g2[(i + 1023 - delay) % 1023];
+        out[i] = bit ? 1 : -1;
+    }
+    return 0;
+}
+
+/* src/utilities/ca_code.rs:13-16 */
+size_t orc_num_samples_per_code(float code_rate, float fs) {
+    float v = roundf(fs / (code_rate / ORC_GPS_L1_CA_CODE_LENGTH_CHIPS));
+    if (!(v > 0.0f)) return 0; /* `as usize` saturates negatives/NaN to 0 */
+    return (size_t)v;
+}
+
+/* src/utilities/ca_code.rs:12-27 */
+long orc_generate_ca_code_samples(int prn, float code_rate, float fs, int8_t *out, size_t cap) {
+    if (prn < 1 || prn > 32) return -1; /* `prn as usize - 1` underflow / table OOB -> panic */
+    int8_t code[1023];
+    orc_ca_code_row(prn - 1, code);
+    size_t n = orc_num_samples_per_code(code_rate, fs);
+    for (size_t i = 0; i < n; i++) {
+        float f = floorf(((float)i * code_rate) / fs); /* :19  x as f32 * code_rate / f_sampling */
+        size_t ind = (f > 0.0f) ? (size_t)f : 0;
+        if (ind >= 1023) return -1; /* ca_code[ind] out of bounds -> panic */
+        if (i < cap) out[i] = code[ind];
+    }
+    return (long)n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Doppler wipe-off table and multiply (src/acquisition/doppler_shift.rs)
+ * ------------------------------------------------------------------------------------------ */
+float orc_doppler_table_new(float f_if, float doppler_hz, float fs, size_t n, orc_c32 *table) {
+    float carr_freq = f_if + doppler_hz;               /* :13 */
+    float phase_step = 2.0f * PI_F * carr_freq / fs;   /* :14  ((2*PI)*carr)/fs */
+    for (size_t i = 0; i < n; i++) {
+        float phase = (float)i * phase_step;           /* :17 */
+        table[i].re = cosf(phase);                     /* :18 */
+        table[i].im = -sinf(phase);
+    }
+    return carr_freq;                                   /* :20 stores IF + Doppler */
+}
+
+void orc_apply_doppler_shift(const orc_c32 *s, const orc_c32 *t, orc_c32 *out, size_t n) {
+    size_t chunks = n / 4;                              /* :26 — the tail n%4 is left untouched */
+    for (size_t i = 0; i < chunks * 4; i++) {
+        float a = s[i].re, b = s[i].im, c = t[i].re, d = t[i].im;
+        /* multiply_simd_block :43-58: first = [a*c, a*d]; second = [b*d*(-1), b*c*(+1)] */
+        float re1 = a * c, im1 = a * d;
+        float re2 = (b * d) * -1.0f, im2 = (b * c) * 1.0f;
+        out[i].re = re1 + re2;
+        out[i].im = im1 + im2;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FFT: f32 mixed-radix Stockham autosort, unnormalised, any n (prime factors handled by an
+ * O(r^2) butterfly).  Restates the DFT that rustfft 6.1.0 computes at do_acquisition.rs:137,182,188
+ * (forward = sum x[n] e^{-j2pi kn/N}; inverse = e^{+...}; no 1/N).  Not bit-identical to rustfft.
+ * ------------------------------------------------------------------------------------------ */
+#define ORC_MAX_PASS 40
+struct orc_fft_plan {
+    size_t n;
+    int inverse;
+    int npass;
+    int radix[ORC_MAX_PASS];
+    orc_c32 *tw[ORC_MAX_PASS];    /* per pass: p*(R-1) twiddles, tw[k*(R-1)+r-1] = w_{pR}^{r k} */
+    orc_c32 *roots[ORC_MAX_PASS]; /* per pass: R roots w_R^j (generic radix) */
+    orc_c32 *scratch;
+};
+
+static inline orc_c32 cmul(orc_c32 a, orc_c32 b) {
+    orc_c32 r = {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+    return r;
+}
+static inline orc_c32 cadd(orc_c32 a, orc_c32 b) { orc_c32 r = {a.re + b.re, a.im + b.im}; return r; }
+static inline orc_c32 csub(orc_c32 a, orc_c32 b) { orc_c32 r = {a.re - b.re, a.im - b.im}; return r; }
+/* multiply by -j (forward) or +j (inverse) */
+static inline orc_c32 cmulj(orc_c32 a, int inverse) {
+    orc_c32 r;
+    if (!inverse) { r.re = a.im; r.im = -a.re; } else { r.re = -a.im; r.im = a.re; }
+    return r;
+}
+
+orc_fft_plan *orc_fft_plan_create(size_t n, int inverse) {
+    if (n == 0) return NULL;
+    orc_fft_plan *pl = (orc_fft_plan *)calloc(1, sizeof(*pl));
+    pl->n = n;
+    pl->inverse = inverse ? 1 : 0;
+    size_t m = n;
+    int np = 0, e2 = 0;
+    while ((m & 1) == 0) { m >>= 1; e2++; }
+    /* odd radices first (ascending primes), then 4s, then a final 2 */
+    for (size_t f = 3; f * f <= m; f += 2)
+        while (m % f == 0) { pl->radix[np++] = (int)f; m /= f; }
+    if (m > 1) pl->radix[np++] = (int)m;
+    for (int i = 0; i < e2 / 2; i++) pl->radix[np++] = 4;
+    if (e2 & 1) pl->radix[np++] = 2;
+    if (np == 0) pl->radix[np++] = 1; /* n == 1 */
+    pl->npass = np;
+    const double sign = inverse ? 1.0 : -1.0;
+    size_t p = 1;
+    for (int s = 0; s < np; s++) {
+        int R = pl->radix[s];
+        pl->tw[s] = (orc_c32 *)malloc(sizeof(orc_c32) * p * (size_t)(R - 1) + 8);
+        for (size_t k = 0; k < p; k++)
+            for (int r = 1; r < R; r++) {
+                double ang = sign * 2.0 * M_PI * (double)((size_t)r * k) / (double)(p * (size_t)R);
+                pl->tw[s][k * (size_t)(R - 1) + (size_t)(r - 1)].re = (float)cos(ang);
+                pl->tw[s][k * (size_t)(R - 1) + (size_t)(r - 1)].im = (float)sin(ang);
+            }
+        pl->roots[s] = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)R);
+        for (int j = 0; j < R; j++) {
+            double ang = sign * 2.0 * M_PI * (double)j / (double)R;
+            pl->roots[s][j].re = (float)cos(ang);
+            pl->roots[s][j].im = (float)sin(ang);
+        }
+        p *= (size_t)R;
+    }
+    pl->scratch = (orc_c32 *)malloc(sizeof(orc_c32) * n);
+    return pl;
+}
+
+void orc_fft_plan_destroy(orc_fft_plan *p) {
+    if (!p) return;
+    for (int s = 0; s < p->npass; s++) { free(p->tw[s]); free(p->roots[s]); }
+    free(p->scratch);
+    free(p);
+}
+
+static void butterfly(int R, orc_c32 *u, const orc_c32 *roots, int inverse) {
+    switch (R) {
+    case 2: {
+        orc_c32 a = u[0], b = u[1];
+        u[0] = cadd(a, b); u[1] = csub(a, b);
+        return;
+    }
+    case 3: {
+        const float s3 = 0.86602540378443864676f;
+        orc_c32 t1 = cadd(u[1], u[2]);
+        orc_c32 m = {u[0].re - 0.5f * t1.re, u[0].im - 0.5f * t1.im};
+        orc_c32 d = csub(u[1], u[2]);
+        orc_c32 sd = {s3 * d.re, s3 * d.im};
+        orc_c32 js = cmulj(sd, inverse);
+        u[0] = cadd(u[0], t1); u[1] = cadd(m, js); u[2] = csub(m, js);
+        return;
+    }
+    case 4: {
+        orc_c32 t0 = cadd(u[0], u[2]), t1 = csub(u[0], u[2]);
+        orc_c32 t2 = cadd(u[1], u[3]), t3 = cmulj(csub(u[1], u[3]), inverse);
+        u[0] = cadd(t0, t2); u[1] = cadd(t1, t3); u[2] = csub(t0, t2); u[3] = csub(t1, t3);
+        return;
+    }
+    case 5: {
+        const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+        const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+        orc_c32 t1 = cadd(u[1], u[4]), t2 = cadd(u[2], u[3]);
+        orc_c32 t3 = csub(u[1], u[4]), t4 = csub(u[2], u[3]);
+        orc_c32 a1 = {u[0].re + c1 * t1.re + c2 * t2.re, u[0].im + c1 * t1.im + c2 * t2.im};
+        orc_c32 a2 = {u[0].re + c2 * t1.re + c1 * t2.re, u[0].im + c2 * t1.im + c1 * t2.im};
+        orc_c32 b1 = {s1 * t3.re + s2 * t4.re, s1 * t3.im + s2 * t4.im};
+        orc_c32 b2 = {s2 * t3.re - s1 * t4.re, s2 * t3.im - s1 * t4.im};
+        orc_c32 jb1 = cmulj(b1, inverse), jb2 = cmulj(b2, inverse);
+        orc_c32 y0 = {u[0].re + t1.re + t2.re, u[0].im + t1.im + t2.im};
+        u[0] = y0; u[1] = cadd(a1, jb1); u[4] = csub(a1, jb1); u[2] = cadd(a2, jb2); u[3] = csub(a2, jb2);
+        return;
+    }
+    default: {
+        orc_c32 y[64];
+        orc_c32 *yy = y, *heap = NULL;
+        if (R > 64) yy = heap = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)R);
+        for (int q = 0; q < R; q++) {
+            orc_c32 acc = u[0];
+            for (int r = 1; r < R; r++) acc = cadd(acc, cmul(u[r], roots[(int)(((long)r * q) % R)]));
+            yy[q] = acc;
+        }
+        memcpy(u, yy, sizeof(orc_c32) * (size_t)R);
+        free(heap);
+        return;
+    }
+    }
+}
+
+void orc_fft_exec(orc_fft_plan *pl, orc_c32 *data) {
+    const size_t n = pl->n;
+    orc_c32 *x = data, *y = pl->scratch;
+    size_t p = 1;
+    orc_c32 ubuf[64];
+    for (int s = 0; s < pl->npass; s++) {
+        const int R = pl->radix[s];
+        const size_t t = n / (size_t)R;
+        const orc_c32 *tw = pl->tw[s];
+        orc_c32 *u = ubuf, *heap = NULL;
+        if (R > 64) u = heap = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)R);
+        for (size_t blk = 0; blk < t / p; blk++) {
+            for (size_t k = 0; k < p; k++) {
+                const size_t i = blk * p + k;
+                u[0] = x[i];
+                if (k == 0) {
+                    for (int r = 1; r < R; r++) u[r] = x[i + (size_t)r * t];
+                } else {
+                    const orc_c32 *twk = tw + k * (size_t)(R - 1);
+                    for (int r = 1; r < R; r++) u[r] = cmul(x[i + (size_t)r * t], twk[r - 1]);
+                }
+                butterfly(R, u, pl->roots[s], pl->inverse);
+                const size_t j = blk * p * (size_t)R + k;
+                for (int r = 0; r < R; r++) y[j + (size_t)r * p] = u[r];
+            }
+        }
+        free(heap);
+        orc_c32 *tmp = x; x = y; y = tmp;
+        p *= (size_t)R;
+    }
+    if (x != data) memcpy(data, x, sizeof(orc_c32) * n);
+}
+
+int orc_fft_forward(orc_c32 *data, size_t n) { /* src/fft.rs:21-25 */
+    orc_fft_plan *p = orc_fft_plan_create(n, 0);
+    if (!p) return -1;
+    orc_fft_exec(p, data);
+    orc_fft_plan_destroy(p);
+    return 0;
+}
+
+int orc_fft_power_spectrum(orc_c32 *data, size_t n, float *power) { /* src/fft.rs:27-29 */
+    if (orc_fft_forward(data, n)) return -1;
+    for (size_t i = 0; i < n; i++) power[i] = data[i].re * data[i].re + data[i].im * data[i].im;
+    return 0;
+}
+
+int orc_rfft_forward(const float *in, size_t n, orc_c32 *out) { /* src/fft.rs:45-49 (realfft 3.3.0) */
+    orc_c32 *buf = (orc_c32 *)malloc(sizeof(orc_c32) * n);
+    if (!buf) return -1;
+    for (size_t i = 0; i < n; i++) { buf[i].re = in[i]; buf[i].im = 0.0f; }
+    int rc = orc_fft_forward(buf, n);
+    if (!rc) memcpy(out, buf, sizeof(orc_c32) * (n / 2 + 1));
+    free(buf);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Acquisition (src/acquisition/do_acquisition.rs)
+ * ------------------------------------------------------------------------------------------ */
+struct orc_acq_worker {
+    uint8_t prn;
+    size_t fft_size;
+    float fs;
+    orc_fft_plan *fft, *ifft;
+    orc_c32 *code_fft;    /* ca_code_samples_fft :126 */
+    orc_c32 *result_buf;  /* :127 */
+    float *best_power, *acc_power;
+};
+
+static orc_acq_worker *worker_alloc(uint8_t prn, size_t fft_size, float fs) {
+    orc_acq_worker *w = (orc_acq_worker *)calloc(1, sizeof(*w));
+    w->prn = prn; w->fft_size = fft_size; w->fs = fs;
+    w->fft = orc_fft_plan_create(fft_size, 0);
+    w->ifft = orc_fft_plan_create(fft_size, 1);
+    w->code_fft = (orc_c32 *)calloc(fft_size, sizeof(orc_c32));
+    w->result_buf = (orc_c32 *)calloc(fft_size, sizeof(orc_c32)); /* vec![0; fft_size] :154 */
+    w->best_power = (float *)calloc(fft_size, sizeof(float));
+    w->acc_power = (float *)calloc(fft_size, sizeof(float));
+    return w;
+}
+
+orc_acq_worker *orc_acq_worker_new(uint8_t prn, size_t fft_size, float fs) { /* :130-156 */
+    int8_t *code = (int8_t *)malloc(fft_size + 16);
+    long n = orc_generate_ca_code_samples(prn, ORC_GPS_L1_CA_CODE_RATE_CHIPS_PER_S, fs, code, fft_size);
+    /* rustfft's process() panics unless buffer length is a multiple of fft_size (:135-137) */
+    if (n < 0 || (size_t)n != fft_size) { free(code); return NULL; }
+    orc_acq_worker *w = worker_alloc(prn, fft_size, fs);
+    for (size_t i = 0; i < fft_size; i++) { w->code_fft[i].re = (float)code[i]; w->code_fft[i].im = 0.0f; }
+    orc_fft_exec(w->fft, w->code_fft);
+    free(code);
+    return w;
+}
+
+orc_acq_worker *orc_acq_worker_new_custom(uint8_t prn, size_t fft_size, float fs, const int8_t *code,
+                                          size_t code_len, float code_rate) {
+    /* generalisation of ca_code.rs:12-27 to an arbitrary +-1 chip sequence (no reference code) */
+    orc_acq_worker *w = worker_alloc(prn, fft_size, fs);
+    for (size_t i = 0; i < fft_size; i++) {
+        float f = floorf(((float)i * code_rate) / fs);
+        size_t ind = (f > 0.0f) ? (size_t)f : 0;
+        w->code_fft[i].re = (float)code[ind % code_len];
+        w->code_fft[i].im = 0.0f;
+    }
+    orc_fft_exec(w->fft, w->code_fft);
+    return w;
+}
+
+void orc_acq_worker_free(orc_acq_worker *w) {
+    if (!w) return;
+    orc_fft_plan_destroy(w->fft); orc_fft_plan_destroy(w->ifft);
+    free(w->code_fft); free(w->result_buf); free(w->best_power); free(w->acc_power);
+    free(w);
+}
+
+const orc_c32 *orc_acq_worker_code_fft(const orc_acq_worker *w) { return w->code_fft; }
+
+int orc_is_good_satellite(const float *power, size_t n, float max_val, float *sum_out) { /* :229-238 */
+    float lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};       /* fold(f32x8::splat(0.0), |acc,x| acc + x) */
+    size_t chunks = n / 8;                           /* chunks_exact(8) drops the tail */
+    for (size_t c = 0; c < chunks; c++)
+        for (int l = 0; l < 8; l++) lane[l] = lane[l] + power[c * 8 + (size_t)l];
+    float sum = -0.0f;                               /* reduce_sum = simd_reduce_add_ordered(v, -0.0) */
+    for (int l = 0; l < 8; l++) sum = sum + lane[l];
+    if (sum_out) *sum_out = sum;
+    float avg = (sum - max_val) / (float)(n - 1);    /* (self.fft_size - 1) as f32 */
+    return (max_val / avg) > 7.0f;
+}
+
+int orc_search_satellite(orc_acq_worker *w, const orc_c32 *samples, size_t n_samples,
+                         const orc_c32 *const *tables, const float *table_freq, size_t n_tables,
+                         uint64_t local_tail, size_t num_integrations, orc_acq_result *out,
+                         float *bin_max, uint32_t *bin_argmax, float *bin_sum, uint32_t *bins_done,
+                         int no_early_exit) {
+    const size_t N = w->fft_size;
+    if (n_samples < N * num_integrations) return -1; /* slice index panic :176 */
+    float global_max_val = 0.0f, best_doppler_freq = 0.0f;   /* :165-167 */
+    size_t best_code_phase = 0;
+    int32_t best_bin = -1;
+    memset(w->best_power, 0, sizeof(float) * N);             /* :168 */
+    int found = 0;
+    uint32_t done = 0;
+    for (size_t d = 0; d < n_tables; d++) {                  /* :171 */
+        memset(w->acc_power, 0, sizeof(float) * N);          /* :172 */
+        for (size_t c = 0; c < num_integrations; c++) {      /* :174 */
+            const orc_c32 *chunk = samples + c * N;
+            orc_apply_doppler_shift(chunk, tables[d], w->result_buf, N);  /* :177-181 */
+            orc_fft_exec(w->fft, w->result_buf);                          /* :182 */
+            for (size_t i = 0; i < N; i++) {                              /* :184-186  *= conj() */
+                orc_c32 a = w->result_buf[i];
+                orc_c32 b = {w->code_fft[i].re, -w->code_fft[i].im};
+                w->result_buf[i] = cmul(a, b);
+            }
+            orc_fft_exec(w->ifft, w->result_buf);                         /* :188 */
+            for (size_t i = 0; i < N; i++) {                              /* :190-192 norm_sqr */
+                orc_c32 v = w->result_buf[i];
+                w->acc_power[i] += v.re * v.re + v.im * v.im;
+            }
+        }
+        float local_max = 0.0f;                              /* :195-202 first strict maximum */
+        size_t local_best_phase = 0;
+        for (size_t i = 0; i < N; i++)
+            if (w->acc_power[i] > local_max) { local_max = w->acc_power[i]; local_best_phase = i; }
+        if (bin_max) bin_max[d] = local_max;
+        if (bin_argmax) bin_argmax[d] = (uint32_t)local_best_phase;
+        if (bin_sum) orc_is_good_satellite(w->acc_power, N, local_max, &bin_sum[d]);
+        done++;
+        if (!found) {
+            if (local_max > global_max_val) {                /* :204-209 */
+                global_max_val = local_max;
+                best_doppler_freq = table_freq[d];
+                best_code_phase = local_best_phase;
+                best_bin = (int32_t)d;
+                memcpy(w->best_power, w->acc_power, sizeof(float) * N);
+            }
+            if (orc_is_good_satellite(w->best_power, N, global_max_val, NULL)) {  /* :211-222 */
+                out->prn = w->prn;
+                out->code_phase_samples = best_code_phase;
+                out->code_phase_chips =
+                    (float)best_code_phase * ORC_GPS_L1_CA_CODE_RATE_CHIPS_PER_S / w->fs;
+                out->carrier_freq = best_doppler_freq;
+                out->fs = w->fs;
+                out->mag_relative = global_max_val;
+                out->sample_global_index = local_tail + best_code_phase;
+                out->doppler_bin = best_bin;
+                found = 1;
+                if (!no_early_exit) break;
+            }
+        }
+    }
+    if (bins_done) *bins_done = done;
+    return found;                                            /* :225 None */
+}
+
+int orc_decide_from_metrics(const float *bin_max, const uint32_t *bin_argmax, const float *bin_sum,
+                            const float *table_freq, size_t n_tables, size_t fft_size, uint8_t prn,
+                            float fs, uint64_t local_tail, float threshold, orc_acq_result *out) {
+    float global_max_val = 0.0f, best_freq = 0.0f, best_sum = 0.0f; /* best plane starts all-zero */
+    size_t best_phase = 0;
+    int32_t best_bin = -1;
+    for (size_t d = 0; d < n_tables; d++) {
+        if (bin_max[d] > global_max_val) {
+            global_max_val = bin_max[d]; best_freq = table_freq[d];
+            best_phase = bin_argmax[d]; best_sum = bin_sum[d]; best_bin = (int32_t)d;
+        }
+        float avg = (best_sum - global_max_val) / (float)(fft_size - 1);
+        if (global_max_val / avg > threshold) {
+            out->prn = prn; out->code_phase_samples = best_phase;
+            out->code_phase_chips = (float)best_phase * ORC_GPS_L1_CA_CODE_RATE_CHIPS_PER_S / fs;
+            out->carrier_freq = best_freq; out->fs = fs; out->mag_relative = global_max_val;
+            out->sample_global_index = local_tail + best_phase; out->doppler_bin = best_bin;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+int orc_acq_search_all(orc_acq_worker *const *workers, size_t n_workers, uint64_t mask,
+                       const orc_c32 *samples, size_t n_samples, const orc_c32 *const *tables,
+                       const float *table_freq, size_t n_tables, uint64_t local_tail,
+                       size_t num_integrations, int n_threads, int no_early_exit,
+                       orc_acq_result *results, uint8_t *found, uint64_t *cells_out) {
+    uint64_t cells = 0;
+    int err = 0;
+    if (n_threads < 1) n_threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : cells) reduction(| : err)
+#endif
+    for (long i = 0; i < (long)n_workers; i++) {     /* workers.par_iter_mut().enumerate() :302-313 */
+        found[i] = 0;
+        if (!((mask >> i) & 1)) continue;            /* (mask >> (prn - 1)) & 1 == 1 */
+        uint32_t done = 0;
+        int rc = orc_search_satellite(workers[i], samples, n_samples, tables, table_freq, n_tables,
+                                      local_tail, num_integrations, &results[i], NULL, NULL, NULL,
+                                      &done, no_early_exit);
+        if (rc < 0) { err |= 1; continue; }
+        found[i] = (uint8_t)rc;
+        cells += (uint64_t)done * workers[i]->fft_size;
+    }
+    if (cells_out) *cells_out = cells;
+    return err ? -1 : 0;
+}
+
+int orc_acq_mode_for(size_t n) { return n == 0 ? 0 : (n <= 4 ? 1 : 2); }  /* update_mode :50-56 */
+
+void orc_acq_pacing_and_list(int mode, uint32_t active_mask, uint64_t *interval_ms, uint32_t *mask) {
+    uint64_t interval; uint32_t search_size;                   /* get_pacing_and_list :58-73 */
+    switch (mode) {
+    case 0: interval = 500; search_size = ORC_PRN_SEARCH_ACQUISITION_TOTAL; break;
+    case 1: interval = 1000; search_size = 8; break;
+    default: interval = 2000; search_size = 5; break;
+    }
+    uint32_t m = 0, taken = 0;
+    for (uint32_t prn = 1; prn <= ORC_PRN_SEARCH_ACQUISITION_TOTAL && taken < search_size; prn++)
+        if (!((active_mask >> (prn - 1)) & 1)) { m |= (1u << (prn - 1)); taken++; }
+    *interval_ms = interval; *mask = m;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Tracking (src/tracking/do_tracking.rs)
+ * ------------------------------------------------------------------------------------------ */
+#define LOCK_THRESHOLD 15.0f          /* :16 */
+#define MAX_LOST_EPOCHS 20u           /* :17 */
+#define DLL_DUMPING_RATIO 0.7f        /* :19 */
+#define PLL_DUMPING_RATIO 0.7f
+#define PLL_GAIN 0.25f
+#define DLL_NOISE_BANDWIDTH 2.0f
+#define PLL_NOISE_BANDWIDTH 25.0f
+#define DLL_GAIN 1.0f
+#define PLL_SUM_CARR 0.001f
+#define DLL_SUM_CODE 0.001f
+#define EARLY_LATE_SPACE 0.5f         /* :28 */
+
+orc_loop_filter orc_loop_filter_new(float noise_bw, float zeta, float gain) { /* :59-65 */
+    float w = noise_bw * 8.0f * zeta / (4.0f * (zeta * zeta) + 1.0f); /* powf(2.0) == x*x */
+    orc_loop_filter f;
+    f.tau1 = gain / (w * w);
+    f.tau2 = (2.0f * zeta) / w;
+    return f;
+}
+
+float orc_loop_filter_update(const orc_loop_filter *f, float d_err, float err, float dt) { /* :68-70 */
+    return d_err * (dt / f->tau1) + (d_err - err) * (f->tau2 / f->tau1);
+}
+
+void orc_trk_new(orc_trk_channel *c, uint8_t id, float fs) { /* :118-146 */
+    memset(c, 0, sizeof(*c));
+    c->id = id;
+    c->state = ORC_STATE_IDLE;
+    c->fs = fs;
+    c->num_samples_per_code =
+        orc_num_samples_per_code(ORC_GPS_L1_CA_CODE_RATE_CHIPS_PER_S, fs);
+    c->code_rate = ORC_GPS_L1_CA_CODE_RATE_CHIPS_PER_S;
+    c->pll_filter = orc_loop_filter_new(PLL_NOISE_BANDWIDTH, PLL_DUMPING_RATIO, PLL_GAIN);
+    c->dll_filter = orc_loop_filter_new(DLL_NOISE_BANDWIDTH, DLL_DUMPING_RATIO, DLL_GAIN);
+    c->code_index_mode = ORC_CODE_INDEX_FAITHFUL;
+}
+
+void orc_trk_start(orc_trk_channel *c, const orc_acq_result *r) { /* :148-154 */
+    c->prn = r->prn;
+    c->carrier_freq = r->carrier_freq;
+    c->code_phase = r->code_phase_chips;
+    c->next_sample_index = r->sample_global_index;
+    c->state = ORC_STATE_TRACKING;
+    c->state_prn = r->prn;
+}
+
+int orc_trk_is_active(const orc_trk_channel *c) { /* :156-158 */
+    return c->state == ORC_STATE_TRACKING && c->state_prn == c->prn;
+}
+
+void orc_trk_reset(orc_trk_channel *c) { /* :311-327 */
+    c->prn = 0;
+    c->state = ORC_STATE_IDLE;
+    c->lost_counter = 0;
+    c->next_sample_index = 0;
+    c->carrier_freq = 0.0f; c->carrier_phase = 0.0f; c->carrier_error = 0.0f; c->carrier_nco = 0.0f;
+    c->code_phase = 0.0f; c->code_error = 0.0f; c->code_nco = 0.0f;
+    c->code_rate = 0.0f;   /* reference bug kept in the oracle: a restarted channel has code_rate 0 */
+    c->i_prompt = 0.0f; c->q_prompt = 0.0f;
+}
+
+/* `x.floor() as usize` (saturating cast) then `% 1023` */
+static inline size_t floor_as_usize_mod1023(float phase) {
+    float f = floorf(phase);
+    if (!(f > 0.0f)) return 0;                       /* negative, -0, NaN -> 0 */
+    if (f >= 18446744073709551616.0f) return (size_t)(18446744073709551615ull % 1023ull);
+    return (size_t)((uint64_t)f % 1023ull);
+}
+
+static const int8_t *ca_row_cached(int row) {
+    static int8_t table[32][1023];
+    static int ready = 0;
+    if (!ready) {
+#ifdef _OPENMP
+#pragma omp critical(orc_ca_table)
+#endif
+        {
+            if (!ready) { for (int r = 0; r < 32; r++) orc_ca_code_row(r, table[r]); ready = 1; }
+        }
+    }
+    return table[row];
+}
+
+int orc_trk_get_ca_chip(const orc_trk_channel *c, float phase, float *chip) { /* :274-277 */
+    int row;
+    size_t idx;
+    if (c->code_index_mode == ORC_CODE_INDEX_FAITHFUL) {
+        row = (int)c->prn;                           /* GPS_CA_CODE_32_PRN[self.prn as usize] */
+        idx = floor_as_usize_mod1023(phase);
+    } else {
+        row = (int)c->prn - 1;                       /* fixed: the PRN's own code, wrapping late arm */
+        float f = floorf(phase);
+        long li = (long)f % 1023;
+        if (li < 0) li += 1023;
+        idx = (size_t)li;
+    }
+    if (row < 0 || row > 31) return -1;
+    *chip = (float)ca_row_cached(row)[idx];
+    return 0;
+}
+
+int orc_trk_early_late_correlation(orc_trk_channel *c, orc_c32 *data, float out6[6], double acc64[6]) {
+    const size_t n = (size_t)c->num_samples_per_code;
+    for (size_t i = 0; i < n; i++) {                 /* :232-238 */
+        float phase = c->carrier_phase + (2.0f * PI_F * c->carrier_freq * (float)i / c->fs);
+        float cos_p = cosf(phase);
+        float sin_p = -sinf(phase);
+        orc_c32 w = {cos_p, sin_p};
+        data[i] = cmul(data[i], w);
+    }
+    c->carrier_phase = fmodf(c->carrier_phase +
+                                 2.0f * PI_F * c->carrier_freq * ((float)n / c->fs),
+                             2.0f * PI_F);           /* :240-242 */
+    float i_p = 0.0f, q_p = 0.0f, i_e = 0.0f, q_e = 0.0f, i_l = 0.0f, q_l = 0.0f;
+    double a64[6] = {0, 0, 0, 0, 0, 0};
+    int rc = 0;
+    for (size_t i = 0; i < n; i++) {                 /* :251-263 */
+        float chip_idx = fmodf(c->code_phase + ((float)i * (c->code_rate / c->fs)), 1023.0f);
+        float p_chip, e_chip, l_chip;
+        if (orc_trk_get_ca_chip(c, chip_idx, &p_chip) ||
+            orc_trk_get_ca_chip(c, chip_idx + EARLY_LATE_SPACE, &e_chip) ||
+            orc_trk_get_ca_chip(c, chip_idx - EARLY_LATE_SPACE, &l_chip)) { rc = -1; break; }
+        i_p += data[i].re * p_chip; q_p += data[i].im * p_chip;
+        i_e += data[i].re * e_chip; q_e += data[i].im * e_chip;
+        i_l += data[i].re * l_chip; q_l += data[i].im * l_chip;
+        if (acc64) {
+            a64[0] += (double)(data[i].re * p_chip); a64[1] += (double)(data[i].im * p_chip);
+            a64[2] += (double)(data[i].re * e_chip); a64[3] += (double)(data[i].im * e_chip);
+            a64[4] += (double)(data[i].re * l_chip); a64[5] += (double)(data[i].im * l_chip);
+        }
+    }
+    if (rc) return rc;
+    c->code_phase = fmodf(c->code_phase + (c->code_rate / c->fs) * (float)n, 1023.0f); /* :265-267 */
+    c->i_prompt = i_p; c->q_prompt = q_p;            /* :269-270 */
+    out6[0] = i_p; out6[1] = q_p; out6[2] = i_e; out6[3] = q_e; out6[4] = i_l; out6[5] = q_l;
+    if (acc64) memcpy(acc64, a64, sizeof(a64));
+    return 0;
+}
+
+void orc_trk_run_loop_filters(orc_trk_channel *c, float i_p, float q_p, float i_e, float q_e,
+                              float i_l, float q_l) { /* :279-302 */
+    float pll_err = atanf(q_p / i_p) / (2.0f * PI_F);
+    c->carrier_nco = orc_loop_filter_update(&c->pll_filter, pll_err, c->carrier_error, PLL_SUM_CARR);
+    c->carrier_error = pll_err;
+    c->carrier_freq += c->carrier_nco;
+    float pow_e = sqrtf(i_e * i_e + q_e * q_e);      /* powi(2) == x*x */
+    float pow_l = sqrtf(i_l * i_l + q_l * q_l);
+    float dll_err = ((pow_e + pow_l) != 0.0f) ? (pow_e - pow_l) / (pow_e + pow_l) : 0.0f;
+    c->code_nco = orc_loop_filter_update(&c->dll_filter, dll_err, c->code_error, DLL_SUM_CODE);
+    c->code_error = dll_err;
+    c->code_rate += c->code_nco;
+}
+
+int orc_trk_do_work(orc_trk_channel *c, orc_c32 *data, float out6[6], uint8_t *msg_prn) { /* :183-210 */
+    if (orc_trk_early_late_correlation(c, data, out6, NULL)) return -1;
+    float i_p = out6[0], q_p = out6[1];
+    float power = i_p * i_p + q_p * q_p;
+    if (power > LOCK_THRESHOLD) {
+        c->lost_counter = 0;
+        orc_trk_run_loop_filters(c, out6[0], out6[1], out6[2], out6[3], out6[4], out6[5]);
+        c->next_sample_index += c->num_samples_per_code;
+        c->num_samples_per_code = orc_num_samples_per_code(c->code_rate, c->fs);
+        return 0;
+    }
+    c->lost_counter += 1;
+    if (c->lost_counter >= MAX_LOST_EPOCHS) {
+        orc_trk_reset(c);
+        if (msg_prn) *msg_prn = c->prn;              /* built AFTER reset -> carries 0 (:199-201) */
+        return 1;
+    }
+    c->next_sample_index += c->num_samples_per_code;
+    c->num_samples_per_code = orc_num_samples_per_code(c->code_rate, c->fs);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * MulticastRingBuffer (src/utilities/multicast_ring_buffer.rs)
+ * ------------------------------------------------------------------------------------------ */
+int orc_ring_new(orc_ring *r, size_t buf_size) { /* :46-61 */
+    if (buf_size == 0 || (buf_size & (buf_size - 1))) return -1; /* assert power of two */
+    r->buffer = (orc_c32 *)calloc(buf_size, sizeof(orc_c32));
+    r->buf_size = buf_size; r->mask = buf_size - 1; r->head = 0;
+    return r->buffer ? 0 : -1;
+}
+void orc_ring_free(orc_ring *r) { free(r->buffer); r->buffer = NULL; }
+
+void orc_ring_write_samples(orc_ring *r, const orc_c32 *s, size_t n) { /* :66-101 */
+    size_t start = (size_t)(r->head & r->mask);
+    if (start + n <= r->buf_size) {
+        memcpy(r->buffer + start, s, n * sizeof(orc_c32));
+    } else {
+        size_t first = r->buf_size - start;
+        memcpy(r->buffer + start, s, first * sizeof(orc_c32));
+        memcpy(r->buffer, s + first, (n - first) * sizeof(orc_c32));
+    }
+    r->head += n;
+}
+uint64_t orc_ring_get_head(const orc_ring *r) { return r->head; }
+
+void orc_ring_copy_to_slice(const orc_ring *r, uint64_t start, orc_c32 *dest, size_t n) { /* :107-129 */
+    size_t ps = (size_t)(start & r->mask);
+    if (ps + n <= r->buf_size) {
+        memcpy(dest, r->buffer + ps, n * sizeof(orc_c32));
+    } else {
+        size_t first = r->buf_size - ps;
+        memcpy(dest, r->buffer + ps, first * sizeof(orc_c32));
+        memcpy(dest + first, r->buffer, (n - first) * sizeof(orc_c32));
+    }
+}
+
+int orc_trk_update(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float out6[6],
+                   uint8_t *msg_prn) { /* :160-180 */
+    if (!orc_trk_is_active(c)) return 0;
+    /* generate_ca_code_samples(...).len() :165-166 — only the length is used */
+    if (c->prn < 1 || c->prn > 32) return -1;
+    c->num_samples_per_code = orc_num_samples_per_code(c->code_rate, c->fs);
+    uint64_t head = orc_ring_get_head(ring);
+    if ((int64_t)(head - (c->next_sample_index + c->num_samples_per_code)) < 0) return 0;
+    orc_ring_copy_to_slice(ring, c->next_sample_index, scratch, (size_t)c->num_samples_per_code);
+    int rc = orc_trk_do_work(c, scratch, out6, msg_prn);
+    if (rc < 0) return -1;
+    return rc == 1 ? 2 : 1;
+}

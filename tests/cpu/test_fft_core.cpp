@@ -1,0 +1,86 @@
+// CPU emulation of the in-LDS FFT (gnss-sdr-rs_amd/csrc/fft_core.h): the T "threads" of a
+// workgroup are run phase by phase, a phase boundary standing for a workgroup barrier.
+// Checks every shipped plan, forward and inverse, against a float64 O(N^2) DFT.
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fft_core.h"
+#include "fft_plans.h"
+
+using namespace gm;
+
+template <class PL, bool INV, int S> struct Middle {
+    static void run(std::vector<cf>& lds, const std::vector<cf>& tw) {
+        if constexpr (S <= PL::NP - 2) {
+            constexpr int IT = PL::IT(S), R = PL::R[S];
+            std::vector<cf> regs(size_t(PL::T) * IT * R);
+            for (int tid = 0; tid < PL::T; ++tid) {   // phase: gather
+                auto& u = *reinterpret_cast<cf(*)[IT][R]>(&regs[size_t(tid) * IT * R]);
+                Fft<PL, INV>::template gather<S>(u, lds.data(), tw.data(), tid);
+            }
+            for (int tid = 0; tid < PL::T; ++tid) {   // barrier; phase: scatter
+                auto& u = *reinterpret_cast<cf(*)[IT][R]>(&regs[size_t(tid) * IT * R]);
+                Fft<PL, INV>::template scatter<S>(u, lds.data(), tid);
+            }
+            Middle<PL, INV, S + 1>::run(lds, tw);
+        }
+    }
+};
+
+template <class PL, bool INV> static double run_plan(const char* name) {
+    constexpr int N = PL::N, T = PL::T;
+    std::vector<cf> x(N), y(N), lds(PL::LDS_ELEMS), tw(PL::TW_TOTAL + 1);
+    fill_twiddles<PL>(tw.data(), INV, [](double a) { return std::cos(a); }, [](double a) { return std::sin(a); });
+    unsigned s = 12345u + N;
+    for (int i = 0; i < N; ++i) {
+        s = s * 1664525u + 1013904223u; float a = float(int(s >> 8) % 2001 - 1000) / 100.f;
+        s = s * 1664525u + 1013904223u; float b = float(int(s >> 8) % 2001 - 1000) / 100.f;
+        x[i] = cf_make(a, b);
+    }
+    // pass 0
+    for (int tid = 0; tid < T; ++tid) {
+        cf in[PL::IT0][PL::R0];
+        for (int it = 0; it < PL::IT0; ++it)
+            for (int r = 0; r < PL::R0; ++r) {
+                int b = tid + it * T;
+                in[it][r] = (b < PL::NB(0)) ? x[b + r * PL::NB(0)] : cf_make(0, 0);
+            }
+        Fft<PL, INV>::scatter0(in, lds.data(), tid);
+    }
+    Middle<PL, INV, 1>::run(lds, tw);
+    for (int tid = 0; tid < T; ++tid) {
+        cf out[PL::ITL][PL::RL];
+        Fft<PL, INV>::gather_last(out, lds.data(), tw.data(), tid);
+        for (int it = 0; it < PL::ITL; ++it) {
+            int b = tid + it * T;
+            if (b < PL::NB(PL::NP - 1))
+                for (int r = 0; r < PL::RL; ++r) y[b + r * PL::NB(PL::NP - 1)] = out[it][r];
+        }
+    }
+    // reference: float64 DFT
+    std::vector<std::complex<double>> w(N);
+    for (int i = 0; i < N; ++i) w[i] = std::polar(1.0, (INV ? 2.0 : -2.0) * M_PI * i / N);
+    double num = 0, den = 0;
+    for (int k = 0; k < N; ++k) {
+        std::complex<double> acc = 0;
+        size_t idx = 0;
+        for (int n = 0; n < N; ++n) { acc += std::complex<double>(x[n].x, x[n].y) * w[idx]; idx += k; if (idx >= size_t(N)) idx -= N; }
+        std::complex<double> d = acc - std::complex<double>(y[k].x, y[k].y);
+        num += std::norm(d); den += std::norm(acc);
+    }
+    double err = std::sqrt(num / den);
+    std::printf("%-28s N=%6d T=%4d %s rel_l2_err=%.3e lds_elems=%d tw=%d\n", name, N, T, INV ? "inv" : "fwd", err,
+                PL::LDS_ELEMS, PL::TW_TOTAL);
+    return err;
+}
+
+int main() {
+    double worst = 0;
+#define RUN(PL) worst = std::fmax(worst, run_plan<PL, false>(#PL)); worst = std::fmax(worst, run_plan<PL, true>(#PL));
+    GM_FOR_EACH_PLAN(RUN)
+    std::printf("worst %.3e\n", worst);
+    return worst < 5e-7 ? 0 : 1;
+}

@@ -1,0 +1,143 @@
+"""CPU: pin the oracle (oracle/) against every known answer the reference's own tests and constants hold
+(SURVEY.md §8c-4).  These run without a GPU."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+def test_ca_code_prn1_known_answer(oracle):
+    # src/bk/gps_ca_prn.rs:72-124 (test_prn_code)
+    g = golden("ca_code_known_answers.json")
+    assert (oracle.ca_code_row(0) == np.array(g["prn1_chips"], np.int8)).all()
+
+
+def test_ca_code_table_digest_and_first10(oracle):
+    # src/constants/gps_ca_constants.rs:1-1346 — all 32 rows, by digest, packed bits and IS-GPS-200 octals
+    g = golden("ca_code_known_answers.json")
+    t = oracle.ca_code_table()
+    assert t.shape == (32, 1023) and set(np.unique(t)) == {-1, 1}
+    assert hashlib.sha256(t.tobytes()).hexdigest() == g["table_sha256"]
+    bits = np.unpackbits(np.frombuffer(bytes.fromhex(g["table_bits_hex"]), np.uint8).reshape(32, 128), axis=1)[:, :1023]
+    assert ((t > 0).astype(np.uint8) == bits).all()
+    for r in range(32):
+        v = 0
+        for b in (t[r, :10] > 0):
+            v = (v << 1) | int(b)
+        assert oct(v)[2:] == g["first10_octal"][r]
+    assert g["first10_octal"][0] == "1440" and g["first10_octal"][31] == "1712"   # IS-GPS-200 Table 3-Ia
+
+
+def test_ca_code_row_out_of_range(oracle):
+    with pytest.raises(IndexError):
+        oracle.ca_code_row(32)      # GPS_CA_CODE_32_PRN[32] panics in the reference
+
+
+def test_generate_ca_code_samples(oracle):
+    # ca_code.rs:12-27: n = round(fs/(rate/1023)), idx = floor(i*rate/fs)
+    for fs, n in [(16_367_600.0, 16368), (8.0e6, 8000), (4_096_000.0, 4096), (2.048e6, 2048), (25.0e6, 25000)]:
+        s = oracle.generate_ca_code_samples(3, 1.023e6, fs)
+        assert s.size == n
+        i = np.arange(n, dtype=np.float32)
+        idx = np.floor((i * np.float32(1.023e6)) / np.float32(fs)).astype(np.int64)
+        assert (s == oracle.ca_code_row(2)[idx]).all()
+    with pytest.raises(IndexError):
+        oracle.generate_ca_code_samples(0, 1.023e6, 8e6)     # prn as usize - 1 underflows
+    with pytest.raises(IndexError):
+        oracle.generate_ca_code_samples(33, 1.023e6, 8e6)
+
+
+def test_acquisition_manager_known_answers(oracle):
+    # do_acquisition.rs:339-395
+    g = golden("manager_known_answers.json")
+    m = oracle.AcquisitionManager()
+    assert m.mode == m.COLD
+    names = {"ColdStart": m.COLD, "WarmStart": m.WARM, "SteadyState": m.STEADY}
+    for n in ("3", "5", "0"):
+        m.update_mode(int(n))
+        assert m.mode == names[g["mode_for_tracked"][n]]
+    m = oracle.AcquisitionManager()
+    assert m.get_pacing_and_list(set(g["cold_start"]["active"])) == (g["cold_start"]["interval_ms"], g["cold_start"]["mask"])
+    m.update_mode(g["warm_start"]["update_mode"])
+    assert m.get_pacing_and_list(set(g["warm_start"]["active"])) == (g["warm_start"]["interval_ms"], g["warm_start"]["mask"])
+    m.update_mode(7)   # steady: 2000 ms, first 5 inactive
+    assert m.get_pacing_and_list({1, 3}) == (2000, 0b1111010)
+
+
+def test_ring_buffer_vectors(oracle):
+    # multicast_ring_buffer.rs:147-209
+    g = golden("ring_buffer_vectors.json")
+    rb = oracle.MulticastRingBuffer(g["buf_size"])
+    rng = lambda a: np.arange(a[0], a[1]).astype(np.complex64)
+    for st in g["steps"]:
+        rb.write_samples(rng(st["write"]))
+        assert rb.get_head() == st["head"]
+        raw = rb.raw()
+        for key, sl in (("buffer_1020_1024", slice(1020, 1024)), ("buffer_0_6", slice(0, 6)), ("buffer_6_16", slice(6, 16))):
+            if key in st:
+                assert (raw[sl] == rng(st[key])).all()
+        if "copy_to_slice" in st:
+            c = st["copy_to_slice"]
+            assert (rb.copy_to_slice(c["start"], c["n"]) == rng(c["expect"])).all()
+    with pytest.raises(AssertionError):
+        oracle.MulticastRingBuffer(1000)   # "Buffer size must be a power of two"
+
+
+def test_loop_filter_constants(oracle):
+    # do_tracking.rs:16-28, 60-64
+    g = golden("loop_filter_constants.json")
+    for k in ("pll", "dll"):
+        f = oracle.loop_filter_new(g[k]["bw"], g[k]["zeta"], g[k]["gain"])
+        assert f.tau1 == pytest.approx(g[k]["tau1"], rel=0, abs=0) and f.tau2 == pytest.approx(g[k]["tau2"], rel=0, abs=0)
+    assert g["pll"]["tau1"] == pytest.approx(1.117551e-4, rel=1e-6) and g["dll"]["tau1"] == pytest.approx(0.06984694, rel=1e-6)
+
+
+def test_oracle_fft_against_float64(oracle):
+    # rustfft semantics: forward e^{-j..}, inverse e^{+j..}, unnormalised (do_acquisition.rs:137,182,188)
+    rng = np.random.default_rng(1)
+    for n in (8, 100, 1023, 2048, 4096, 8000, 16368):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        ref = np.fft.fft(x.astype(np.complex128))
+        assert np.linalg.norm(oracle.fft(x) - ref) / np.linalg.norm(ref) < 4e-7
+        refi = np.fft.ifft(x.astype(np.complex128)) * n
+        assert np.linalg.norm(oracle.fft(x, inverse=True) - refi) / np.linalg.norm(refi) < 4e-7
+    r = rng.standard_normal(64).astype(np.float32)
+    assert np.allclose(oracle.rfft(r), np.fft.rfft(r.astype(np.float64)), atol=1e-4)
+
+
+def test_doppler_table_and_apply(oracle):
+    # doppler_shift.rs:10-58 against a float32 numpy restatement of the same formulas
+    f = np.float32
+    t = oracle.DopplerShiftTable(4_130_400.0, -7000.0, 16_367_600.0, 16368)
+    assert t.doppler_freq_hz == float(f(4_130_400.0) + f(-7000.0))          # stores IF + Doppler (:20)
+    step = f(f(f(2.0) * f(np.pi)) * f(t.doppler_freq_hz)) / f(16_367_600.0)
+    ph = np.arange(16368, dtype=np.float32) * step
+    # glibc cosf/sinf vs numpy's float32 kernels can differ in the last bit
+    assert np.max(np.abs(t.table.real - np.cos(ph))) < 2e-7 and np.max(np.abs(t.table.imag + np.sin(ph))) < 2e-7
+    rng = np.random.default_rng(2)
+    s = (rng.integers(-127, 128, 1003) + 1j * rng.integers(-127, 128, 1003)).astype(np.complex64)
+    out = np.full(1003, 99 + 99j, np.complex64)
+    oracle.apply_doppler_shift(s, t.table[:1003], out)
+    a, b, c, d = s.real, s.imag, t.table[:1003].real, t.table[:1003].imag
+    re = (a * c).astype(f) + (-(b * d).astype(f))
+    im = (a * d).astype(f) + (b * c).astype(f)
+    assert (out[:1000].real == re[:1000]).all() and (out[:1000].imag == im[:1000]).all()
+    assert (out[1000:] == 99 + 99j).all()      # only 4*floor(n/4) elements are written (:26)
+
+
+def test_is_good_satellite_lane_order(oracle):
+    # do_acquisition.rs:229-238: 8 lane sums over chunks_exact(8), then an ordered reduce
+    rng = np.random.default_rng(3)
+    p = (rng.random(8003) * 1e6).astype(np.float32)
+    lanes = np.zeros(8, np.float32)
+    for c in range(8003 // 8):
+        lanes = (lanes + p[c * 8:c * 8 + 8]).astype(np.float32)
+    s = np.float32(-0.0)
+    for l in lanes:
+        s = np.float32(s + l)
+    ok, got = oracle.is_good_satellite(p, float(p.max()))
+    assert got == float(s)
+    avg = np.float32(np.float32(s - p.max()) / np.float32(8002))
+    assert ok == bool(np.float32(p.max() / avg) > 7.0)
