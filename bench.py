@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path of BASELINE.json on N GPUs of one node (one process per GPU).
+
+Workload at N = 1: BASELINE.json configs[1] — GPS L1 C/A, 32 PRN x 41 Doppler bins (+-5 kHz / 250 Hz),
+8 Msps complex int8, 10 x 1 ms non-coherent (the reference's LONG_SAMPLES_LENGTH).  A "step" is one
+acquisition dwell: stage F (carrier mix + forward FFT, shared by all PRNs) + stage C (x conj(code
+spectrum), inverse FFT, |.|^2 accumulated over the 10 ms, {max, argmax, sum} per (PRN, bin)) + the
+reference's decision replay, with the IF samples already resident in HBM.  `value` = (PRN, Doppler,
+code-phase) cells decided per second over all ranks.
+
+N > 1 (weak scaling, the shape of configs[3]): every rank searches its own 32-code block of a 32*N-code
+grid on the same IF snapshot, then ONE all-gather (RCCL, torch.distributed) of the per-(code, bin)
+{max, argmax, sum} metrics, and every rank replays the decision on the gathered grid.
+
+Also reported (not part of `value`): the tracking leg of configs[2] (32 channels, 25 Msps, E/P/L + DLL/PLL),
+the roofline of the dominant kernel (acq_corr_kernel) from HIP events recorded inside the timed region on
+the stream the kernels run on, and the CPU oracle ("port" of the reference) timed on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def gold_codes(delays):
+    """Gold codes of the GPS C/A family for arbitrary G2 delays (the extra code blocks of ranks > 0)."""
+    def lfsr(taps):
+        reg = [1] * 10
+        out = np.zeros(1023, np.uint8)
+        for i in range(1023):
+            out[i] = reg[9]
+            fb = 0
+            for t in taps:
+                fb ^= reg[t - 1]
+            reg = [fb] + reg[:9]
+        return out
+    g1, g2 = lfsr([3, 10]), lfsr([2, 3, 6, 8, 9, 10])
+    return np.stack([np.where(g1 ^ np.roll(g2, d), 1, -1).astype(np.int8) for d in delays])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tracking", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from gnss_sdr_rs_amd import _lib, acquisition as A, synth, tracking as T
+    _lib.init(local_rank)                      # raises if the HIP library is missing: no fallback
+
+    # ------------------------------------------------------------------ acquisition workload (configs[1])
+    ca = A.ca_code_table()
+    sc = synth.cfg2_scene(ca)
+    P, D, N, M = 32, int(sc["doppler_hz"].size), sc["N"], sc["M"]
+    xi8 = synth.to_i8_iq(sc["x"])
+    if rank == 0:
+        eng = A.AcquisitionEngine(sc["fs"], sc["f_if"], N, doppler_hz=sc["doppler_hz"], n_integrations=M)
+        prn_ids_local = np.arange(1, 33, dtype=np.uint8)
+    else:   # further code blocks of the grid: other members of the same Gold family
+        gps = {5, 6, 7, 8, 17, 18, 139, 140, 141, 251, 252, 254, 255, 256, 257, 258, 469, 470, 471, 472, 473, 474, 509,
+               512, 513, 514, 515, 516, 859, 860, 861, 862}
+        free = [d for d in range(1, 1023) if d not in gps]
+        delays = free[(rank - 1) * 32:(rank - 1) * 32 + 32]
+        prn_ids_local = np.arange(1, 33, dtype=np.uint8)
+        eng = A.AcquisitionEngine(sc["fs"], sc["f_if"], N, doppler_hz=sc["doppler_hz"], n_integrations=M,
+                                  prn_ids=prn_ids_local, codes=gold_codes(delays))
+    stream = torch.cuda.current_stream().cuda_stream
+    eng.set_stream(stream)
+    d_samples = torch.from_numpy(xi8).to(dev)                       # IF snapshot resident in HBM
+    d_metrics = torch.zeros(3 * P * D, dtype=torch.int32, device=dev)
+    if world > 1:
+        d_gather = torch.zeros(world * 3 * P * D, dtype=torch.int32, device=dev)
+        ids_all = np.tile(np.arange(1, 33, dtype=np.uint8), world)
+
+    def step():
+        eng.search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, d_metrics.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(d_gather, d_metrics)        # the path's one exchange step
+            g = d_gather.view(world, 3, P * D).permute(1, 0, 2).contiguous()   # -> [3][world*P][D]
+            eng.decide_dev(g.data_ptr(), n_prn=world * P, prn_ids=ids_all)
+            return g
+        eng.decide_dev(d_metrics.data_ptr())
+        return None
+
+    keep = None
+    for _ in range(args.warmup):
+        keep = step()
+    torch.cuda.synchronize()
+    eng.enable_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keep = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tsum = eng.timing_summary()
+    eng.enable_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # detections must be the simulated satellites (rank 0's block), every step's result identical by construction
+    res = eng.fetch_results(world * P if world > 1 else P)
+    truth = {s["prn"]: s["code_start"] for s in sc["sats"]}
+    got = {r["prn"]: r["code_phase_samples"] for r in res[:P] if r}
+    detections_ok = (got == truth) and all(r is None for r in res[P:])
+
+    cells_per_step = world * P * D * N
+    value = cells_per_step * args.steps / elapsed
+    # roofline of the dominant kernel: algorithmic bytes per launch (SURVEY §8d stage C): P*D*M*N*16
+    corr_bytes = P * D * M * N * 16
+    mix_bytes = D * M * N * (2 + 8)
+    corr_s = tsum["avg_corr_ms"] * 1e-3
+    achieved = corr_bytes / corr_s / 1e9 if corr_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("acq_corr_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "acq PRN×Doppler cells/s + tracking ch×Msps at 1/2/4/8 GPU; % HBM roofline",
+        "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "GPS L1 C/A 32-PRN x +-5 kHz/250 Hz (41 bins) acquisition, 8 Msps complex int8, "
+                               "N=8000, 10 x 1 ms non-coherent, per GPU" + ("; all-gather of {max,argmax,sum}[P][D]" if world > 1 else ""),
+                   "prns_per_gpu": P, "doppler_bins": D, "fft_size": N, "integrations": M,
+                   "cells_per_step": cells_per_step, "cell_integrations_per_s": value * M,
+                   "parallelism": f"prn-shard x{world}", "detections_ok": bool(detections_ok)},
+        "roofline": {"bound": "hbm", "kernel": "acq_corr_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": corr_bytes, "avg_launch_ms": tsum["avg_corr_ms"],
+                     "launches_timed": tsum["launches"],
+                     "stage_F": {"kernel": "acq_mix_fft_kernel", "algorithmic_bytes_per_launch": mix_bytes,
+                                 "avg_launch_ms": tsum["avg_mix_fft_ms"]},
+                     "whole_step_algorithmic_GBs": (corr_bytes + mix_bytes) * args.steps / elapsed / 1e9},
+    }
+    del keep
+
+    # ------------------------------------------------------------------ tracking leg (configs[2]), rank-local
+    if not args.no_tracking:
+        try:
+            out["tracking"] = tracking_leg(torch, dev, stream, ca, T, synth, world, dist)
+        except Exception as e:   # the headline number stands on its own
+            out["tracking"] = {"error": repr(e)}
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sc, args.cpu_seconds)
+
+    eng.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def tracking_leg(torch, dev, stream, ca, T, synth, world, dist):
+    """32 channels x 25 Msps, 1 ms E/P/L correlators + DLL/PLL on-device, FIXED code indexing
+    (FAITHFUL cannot run PRN 32: the reference indexes GPS_CA_CODE_32_PRN[32])."""
+    fs, C, epochs, reps = 25.0e6, 32, 40, 5
+    n = 25000
+    prns = list(range(1, 33))
+    sc = synth.tracking_scene(ca, fs, 0.0, prns, epochs + 2, config_id=3, cn0=47.0)
+    ring = T.MulticastRingBuffer(1 << 21)
+    ring.write_samples(synth.to_c32(sc["x"]))
+    mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED)
+    mgr.set_stream(stream)
+
+    def restart():
+        for i, s in enumerate(sc["sats"]):
+            mgr.channels[i].start(dict(prn=s["prn"], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=s["doppler_hz"] + 20.0,
+                                       fs=fs, mag_relative=1.0, sample_global_index=s["code_start"], doppler_bin=0))
+            mgr.channels[i].set_state(code_rate=1.023e6, num_samples_per_code=n, carrier_phase=0.0, code_error=0.0,
+                                      carrier_error=0.0, lost_counter=0)
+    restart()
+    mgr.update_all_dev(ring, epochs)
+    mgr.synchronize()
+    locked = sum(1 for c in mgr.channels if c.is_active() and abs(c.carrier_freq - sc["sats"][c.id]["doppler_hz"]) < 25.0)
+    times = []
+    for _ in range(reps):
+        restart()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mgr.update_all_dev(ring, epochs)
+        mgr.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    ch_msps = C * fs / 1e6 * (epochs * 1e-3 / dt)
+    bytes_per_epoch = C * n * 8
+    gbs = bytes_per_epoch * epochs / dt / 1e9
+    mgr.close()
+    ring.close()
+    return {"metric": "tracking ch×Msps", "value": ch_msps * world, "unit": "ch*Msps", "channels_per_gpu": C,
+            "fs_msps": 25.0, "epochs": epochs, "ms_per_epoch": dt / epochs * 1e3, "channels_locked": locked,
+            "roofline": {"bound": "hbm", "kernel": "trk_correlate_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_epoch": bytes_per_epoch}}
+
+
+def cpu_baseline(sc, budget_s):
+    """The oracle (CPU restatement of the reference: one worker per PRN redoing mix + FFT + IFFT, early exit,
+    do_acquisition.rs:302-313) on this host's cores, threads = min(32, nproc) like rayon.  Bounded sample:
+    whole dwells of the same scene until ~budget_s seconds."""
+    from oracle import oracle as O
+    from gnss_sdr_rs_amd import synth
+    O.build(native=True)
+    nthreads = min(32, os.cpu_count() or 1)
+    x = synth.to_c32(sc["x"])
+    tables = [O.DopplerShiftTable(sc["f_if"], float(d), sc["fs"], sc["N"]) for d in sc["doppler_hz"]]
+    workers = [O.AcquisitionWorker(p, sc["N"], sc["fs"], native=True) for p in range(1, 33)]
+    O.search_all(workers, 0xFFFFFFFF, x, tables, 0, sc["M"], n_threads=nthreads, native=True)     # warm-up dwell
+    rates, dwell_s, t_start = [], [], time.perf_counter()
+    while len(rates) < 3 or (time.perf_counter() - t_start < budget_s and len(rates) < 25):
+        t0 = time.perf_counter()
+        _, cells = O.search_all(workers, 0xFFFFFFFF, x, tables, 0, sc["M"], n_threads=nthreads, native=True)
+        dt = time.perf_counter() - t0
+        rates.append(cells / dt)
+        dwell_s.append(dt)
+    # single-thread rate on a bounded slice (4 PRNs) for reference
+    t0 = time.perf_counter()
+    _, cells1 = O.search_all(workers[:4], 0xF, x, tables, 0, sc["M"], n_threads=1, native=True)
+    r1 = cells1 / (time.perf_counter() - t0)
+    return {"value": float(np.median(rates)), "unit": "cells/s", "cores": nthreads, "kind": "port",
+            "sample": f"{len(rates)} dwells of the bench scene (32 PRN x 41 bins x 8000 phases, 10 ms, early exit as in "
+                      f"the reference; cells = bins visited x 8000), median dwell {np.median(dwell_s):.3f} s",
+            "single_thread_cells_per_s": float(r1),
+            "note": "oracle's own f32 mixed-radix FFT, not rustfft 6.1.0 (AVX); reported baseline, not the target"}
+
+
+if __name__ == "__main__":
+    main()

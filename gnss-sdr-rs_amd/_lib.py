@@ -82,6 +82,7 @@ SIGNATURES = {
     "gm_acq_set_prn_mask": (_i, [_vp, _u64]),
     "gm_acq_decide_dev": (_i, [_vp, _vp, _u32, _vp, _u64]),
     "gm_acq_fetch_results": (_i, [_vp, _u32, _vp, _vp]),
+    "gm_acq_decide_host": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _f, _f, _f, _u64, _vp, _vp]),
     "gm_acq_synchronize": (_i, [_vp]),
     "gm_acq_set_stream": (_i, [_vp, _vp]),
     "gm_acq_metrics": (_i, [_vp, _vp, _vp, _vp]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "gm_acq_tables": (_i, [_vp, _vp, _vp]),
     "gm_acq_enable_timing": (_i, [_vp, _i]),
     "gm_acq_last_timing": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f)]),
+    "gm_acq_timing_summary": (_i, [_vp, C.POINTER(_u32), C.POINTER(_f), C.POINTER(_f)]),
     "gm_acq_manager_mode_for": (_i, [_sz]),
     "gm_acq_manager_pacing_and_list": (_i, [_i, _u32, C.POINTER(_u64), C.POINTER(_u32)]),
     "gm_ring_create": (_i, [_sz, C.POINTER(_vp)]),

@@ -179,6 +179,12 @@ class AcquisitionEngine:
         return {"mix_fft_ms": a.value, "corr_ms": b.value, "decide_ms": c.value}
 
 
+    def timing_summary(self):
+        n, a, b = C.c_uint32(0), C.c_float(0), C.c_float(0)
+        check(lib().gm_acq_timing_summary(self._h, C.byref(n), C.byref(a), C.byref(b)), "gm_acq_timing_summary")
+        return {"launches": n.value, "avg_mix_fft_ms": a.value, "avg_corr_ms": b.value}
+
+
 class AcquisitionWorker:
     """AcquisitionWorker::new(prn, fft_size, freq_sampling_hz) + search_satellite(...)
     (do_acquisition.rs:130-226), one PRN per handle like the reference; the Doppler tables arrive

@@ -95,9 +95,14 @@ void loop_filter_new(float bw, float zeta, float gain, float* tau1, float* tau2)
     *tau2 = (2.0f * zeta) / w;
 }
 
+// HIP-event timing of the acquisition kernels on the handle's stream: a pool of event triples, one per
+// gm_acq_search_dev call since timing was (re-)enabled, averaged by gm_acq_timing_summary.
 struct Timing {
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool on = false, valid = false;
+    static constexpr int CAP = 512;
+    std::vector<hipEvent_t> ev;   // CAP * 4 events, created on first enable
+    bool on = false;
+    int count = 0;                // calls recorded since enable (only the last CAP are kept)
+    bool decide_valid = false;
 };
 
 }  // namespace
@@ -393,7 +398,6 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     HIPA(hipMemcpy(a->d_tw_fwd, twf.data(), twf.size() * 8, hipMemcpyHostToDevice));
     HIPA(hipMemcpy(a->d_tw_inv, twi.data(), twi.size() * 8, hipMemcpyHostToDevice));
     HIPA(hipMemcpy(a->d_code_samples, code_samples.data(), P * N, hipMemcpyHostToDevice));
-    for (auto& e : a->tm.ev) HIPA(hipEventCreate(&e));
     if ((rc = acq_reserve_results(a, uint32_t(P)))) return fail(rc);
     HIPA(hipMemcpy(a->d_prn_ids, a->prn_ids.data(), P, hipMemcpyHostToDevice));
     // replica spectra: forward FFT of the resampled code (:136-138)
@@ -429,15 +433,15 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     uint32_t* met = d_metrics ? static_cast<uint32_t*>(d_metrics) : a->d_metrics;
     const size_t PD = size_t(a->P) * a->D;
     const bool t = a->tm.on;
-    if (t) HIPC(hipEventRecord(a->tm.ev[0], a->stream));
+    hipEvent_t* ev = t ? &a->tm.ev[size_t(a->tm.count % Timing::CAP) * 4] : nullptr;
+    if (t) HIPC(hipEventRecord(ev[0], a->stream));
     a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_fwd, a->d_spectra, int(a->D), int(a->M));
-    if (t) HIPC(hipEventRecord(a->tm.ev[1], a->stream));
+    if (t) HIPC(hipEventRecord(ev[1], a->stream));
     a->plan->corr(a->stream, a->d_spectra, a->d_code_fft, a->d_tw_inv, reinterpret_cast<float*>(met), met + PD,
                   reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M));
-    if (t) HIPC(hipEventRecord(a->tm.ev[2], a->stream));
+    if (t) { HIPC(hipEventRecord(ev[2], a->stream)); a->tm.count++; a->tm.decide_valid = false; }
     HIPC(hipGetLastError());
     a->last_metrics = met;
-    a->tm.valid = false;
     return GM_OK;
 }
 
@@ -462,7 +466,10 @@ int gm_acq_decide_dev(gm_acq* a, const void* d_metrics, uint32_t n_prn, const ui
     da.local_tail = local_tail;
     da.results = a->d_results; da.found = a->d_found;
     gm::launch_decide(a->stream, da);
-    if (a->tm.on) { HIPC(hipEventRecord(a->tm.ev[3], a->stream)); a->tm.valid = true; }
+    if (a->tm.on && a->tm.count > 0) {
+        HIPC(hipEventRecord(a->tm.ev[size_t((a->tm.count - 1) % Timing::CAP) * 4 + 3], a->stream));
+        a->tm.decide_valid = true;
+    }
     HIPC(hipGetLastError());
     return GM_OK;
 }
@@ -535,21 +542,82 @@ int gm_acq_tables(gm_acq* a, gm_c32* tables, float* freq) {
 
 int gm_acq_enable_timing(gm_acq* a, int on) {
     if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(a->device)) return rc;
+    if (on && a->tm.ev.empty()) {
+        a->tm.ev.assign(size_t(Timing::CAP) * 4, nullptr);
+        for (auto& e : a->tm.ev) HIPC(hipEventCreate(&e));
+    }
     a->tm.on = on != 0;
-    a->tm.valid = false;
+    a->tm.count = 0;
+    a->tm.decide_valid = false;
     return GM_OK;
 }
 
 int gm_acq_last_timing(gm_acq* a, float* ms_mix, float* ms_corr, float* ms_decide) {
+    if (!a || !a->tm.on || a->tm.count == 0) return set_err(GM_ERR_INVALID_ARG, "timing not enabled / nothing recorded");
+    if (int rc = ensure_device(a->device)) return rc;
+    HIPC(hipStreamSynchronize(a->stream));
+    hipEvent_t* ev = &a->tm.ev[size_t((a->tm.count - 1) % Timing::CAP) * 4];
+    float t = 0;
+    if (ms_mix) { HIPC(hipEventElapsedTime(&t, ev[0], ev[1])); *ms_mix = t; }
+    if (ms_corr) { HIPC(hipEventElapsedTime(&t, ev[1], ev[2])); *ms_corr = t; }
+    if (ms_decide) {
+        *ms_decide = 0;
+        if (a->tm.decide_valid) { HIPC(hipEventElapsedTime(&t, ev[2], ev[3])); *ms_decide = t; }
+    }
+    return GM_OK;
+}
+
+int gm_acq_timing_summary(gm_acq* a, uint32_t* launches, float* avg_ms_mix, float* avg_ms_corr) {
     if (!a || !a->tm.on) return set_err(GM_ERR_INVALID_ARG, "timing not enabled");
     if (int rc = ensure_device(a->device)) return rc;
     HIPC(hipStreamSynchronize(a->stream));
-    float t = 0;
-    if (ms_mix) { HIPC(hipEventElapsedTime(&t, a->tm.ev[0], a->tm.ev[1])); *ms_mix = t; }
-    if (ms_corr) { HIPC(hipEventElapsedTime(&t, a->tm.ev[1], a->tm.ev[2])); *ms_corr = t; }
-    if (ms_decide) {
-        *ms_decide = 0;
-        if (a->tm.valid) { HIPC(hipEventElapsedTime(&t, a->tm.ev[2], a->tm.ev[3])); *ms_decide = t; }
+    const int n = a->tm.count < Timing::CAP ? a->tm.count : Timing::CAP;
+    double sm = 0, sc = 0;
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t* ev = &a->tm.ev[size_t(i) * 4];
+        float t = 0;
+        HIPC(hipEventElapsedTime(&t, ev[0], ev[1])); sm += t;
+        HIPC(hipEventElapsedTime(&t, ev[1], ev[2])); sc += t;
+    }
+    if (launches) *launches = uint32_t(n);
+    if (avg_ms_mix) *avg_ms_mix = n ? float(sm / n) : 0.f;
+    if (avg_ms_corr) *avg_ms_corr = n ? float(sc / n) : 0.f;
+    return GM_OK;
+}
+
+// Host replay of the decision (same arithmetic as decide_kernel) for callers that hold the metrics on the
+// host, e.g. after a gloo/MPI all-gather.  No device needed.
+int gm_acq_decide_host(const float* mmax, const uint32_t* margmax, const float* msum, const float* table_freq,
+                       uint32_t n_prn, uint32_t n_bins, const uint8_t* prn_ids, uint32_t fft_size, float fs,
+                       float code_rate, float threshold, uint64_t local_tail, gm_acq_result* results, uint8_t* found) {
+    if (!mmax || !margmax || !msum || !table_freq || !prn_ids || !results || !found || fft_size < 2)
+        return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (threshold == 0.0f) threshold = 7.0f;
+    if (!(code_rate > 0.0f)) code_rate = CA_RATE;
+    const float nm1 = float(fft_size - 1);
+    for (uint32_t p = 0; p < n_prn; ++p) {
+        gm_acq_result r;
+        memset(&r, 0, sizeof(r));
+        r.prn = prn_ids[p]; r.doppler_bin = -1;
+        found[p] = 0;
+        float gmax = 0.0f, bfreq = 0.0f, bsum = 0.0f;
+        uint32_t bphase = 0;
+        int bbin = -1;
+        for (uint32_t d = 0; d < n_bins; ++d) {
+            const size_t o = size_t(p) * n_bins + d;
+            if (mmax[o] > gmax) { gmax = mmax[o]; bfreq = table_freq[d]; bphase = margmax[o]; bsum = msum[o]; bbin = int(d); }
+            const float avg = (bsum - gmax) / nm1;
+            if (gmax / avg > threshold) {
+                r.code_phase_samples = bphase;
+                r.code_phase_chips = float(bphase) * code_rate / fs;
+                r.carrier_freq = bfreq; r.fs = fs; r.mag_relative = gmax;
+                r.sample_global_index = local_tail + bphase; r.doppler_bin = bbin;
+                found[p] = 1;
+                break;
+            }
+        }
+        results[p] = r;
     }
     return GM_OK;
 }

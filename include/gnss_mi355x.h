@@ -147,6 +147,11 @@ int gm_acq_set_prn_mask(gm_acq *a, uint64_t prn_mask);
 int gm_acq_decide_dev(gm_acq *a, const void *d_metrics, uint32_t n_prn, const uint8_t *prn_ids,
                       uint64_t local_tail);
 int gm_acq_fetch_results(gm_acq *a, uint32_t n_prn, gm_acq_result *results, uint8_t *found); /* syncs */
+/* The same decision replay on host-resident metrics ([n_prn][n_bins] planes), no device involved. */
+int gm_acq_decide_host(const float *max, const uint32_t *argmax, const float *sum, const float *table_freq,
+                       uint32_t n_prn, uint32_t n_bins, const uint8_t *prn_ids, uint32_t fft_size, float fs,
+                       float code_rate, float threshold, uint64_t local_tail, gm_acq_result *results,
+                       uint8_t *found);
 int gm_acq_synchronize(gm_acq *a);
 /* Use an existing HIP stream (e.g. torch's current stream) instead of the handle's own. */
 int gm_acq_set_stream(gm_acq *a, void *hip_stream);
@@ -162,6 +167,8 @@ int gm_acq_tables(gm_acq *a, gm_c32 *tables, float *table_freq);
  * stream: ms_mix_fft (stage F), ms_corr (stage C, the dominant kernel), ms_decide.  Enable first. */
 int gm_acq_enable_timing(gm_acq *a, int on);
 int gm_acq_last_timing(gm_acq *a, float *ms_mix_fft, float *ms_corr, float *ms_decide);
+/* Averages over every gm_acq_search_dev call since timing was enabled (the last 512 at most). */
+int gm_acq_timing_summary(gm_acq *a, uint32_t *launches, float *avg_ms_mix_fft, float *avg_ms_corr);
 
 /* AcquisitionManager (do_acquisition.rs:39-74): mode 0 ColdStart / 1 WarmStart / 2 SteadyState. */
 int gm_acq_manager_mode_for(size_t tracked_count);

@@ -1,0 +1,117 @@
+"""CPU: the C-ABI library loads, exports every symbol the header declares, and its host-side (no-GPU) entry
+points agree with the golden fixtures and the oracle.  No compute entry is called here."""
+import ctypes as C
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+
+def test_header_symbols_all_exported(gm):
+    hdr = open(os.path.join(ROOT, "include", "gnss_mi355x.h")).read()
+    declared = set(re.findall(r"\b(gm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"gm_status", "gm_c32"}
+    from gnss_sdr_rs_amd import _lib
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    nm = subprocess.run(["nm", "-D", "--defined-only", gm.library_path()], stdout=subprocess.PIPE, text=True).stdout
+    exported = set(re.findall(r" T (gm_[a-z0-9_]+)", nm))
+    assert declared <= exported, declared - exported
+    assert not [s for s in re.findall(r" [TDB] (\S+)", nm) if not s.startswith("gm_")]   # nothing else leaks
+    assert gm.lib().gm_abi_version() == 1
+
+
+def test_library_links_no_oracle_and_no_torch(gm):
+    out = subprocess.run(["ldd", gm.library_path()], stdout=subprocess.PIPE, text=True).stdout
+    assert "liboracle" not in out and "torch" not in out and "libamdhip64" in out
+
+
+def test_compute_entry_fails_loudly_without_device(gm):
+    """No CPU fallback: on a box without a GPU the compute entries return GM_ERR_NO_DEVICE."""
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, ctypes as C; import gnss_sdr_rs_amd as g; L = g.lib();"
+            "n = C.c_int(0); L.gm_device_count(C.byref(n));"
+            "x = np.zeros(1024, np.complex64);"
+            "rc = L.gm_fft_c2c_f32(1024, 0, x.ctypes.data_as(C.c_void_p), 1);"
+            "print(n.value, rc)") % ROOT
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    ndev, rc = out.stdout.split()[-2:]
+    if int(ndev) == 0:
+        assert int(rc) == -3, out.stdout + out.stderr
+
+
+def test_ca_table_and_resampler_host(gm, oracle):
+    from gnss_sdr_rs_amd import acquisition as A
+    g = golden("ca_code_known_answers.json")
+    t = A.ca_code_table()
+    assert hashlib.sha256(t.tobytes()).hexdigest() == g["table_sha256"]
+    assert (t[0] == np.array(g["prn1_chips"], np.int8)).all()
+    for fs in (16_367_600.0, 8.0e6, 4_096_000.0):
+        assert (A.generate_ca_code_samples(19, 1.023e6, fs) == oracle.generate_ca_code_samples(19, 1.023e6, fs)).all()
+    from gnss_sdr_rs_amd import GmError
+    with pytest.raises(GmError):
+        A.generate_ca_code_samples(0, 1.023e6, 8e6)
+
+
+def test_doppler_table_host_bit_exact_with_oracle(gm, oracle):
+    from gnss_sdr_rs_amd import acquisition as A
+    for f_if, dop, fs, n in ((4_130_400.0, -7000.0, 16_367_600.0, 16368), (0.0, 250.0, 8.0e6, 8000)):
+        a, b = A.DopplerShiftTable(f_if, dop, fs, n), oracle.DopplerShiftTable(f_if, dop, fs, n)
+        assert a.doppler_freq_hz == b.doppler_freq_hz
+        assert (a.table.view(np.uint32) == b.table.view(np.uint32)).all()
+    assert (A.doppler_grid() == np.array(golden("capture_config.json")["doppler_hz"], np.float32)).all()
+
+
+def test_manager_and_loop_filter_host(gm):
+    from gnss_sdr_rs_amd import acquisition as A, tracking as T
+    g = golden("manager_known_answers.json")
+    m = A.AcquisitionManager()
+    assert m.mode == A.SearchMode.ColdStart
+    assert m.get_pacing_and_list(set()) == (500, 0xFFFFFFFF)
+    m.update_mode(3)
+    assert m.mode == A.SearchMode.WarmStart and m.get_pacing_and_list({1, 2, 3}) == (1000, g["warm_start"]["mask"])
+    m.update_mode(5)
+    assert m.mode == A.SearchMode.SteadyState
+    m.update_mode(0)
+    assert m.mode == A.SearchMode.ColdStart
+    lf = golden("loop_filter_constants.json")
+    for k in ("pll", "dll"):
+        f = T.LoopFilter(lf[k]["bw"], lf[k]["zeta"], lf[k]["gain"])
+        assert f.tau1 == lf[k]["tau1"] and f.tau2 == lf[k]["tau2"]
+    f = T.LoopFilter(25.0, 0.7, 0.25)
+    d, e, dt = np.float32(0.01), np.float32(0.004), np.float32(0.001)
+    exp = np.float32(d * np.float32(dt / np.float32(f.tau1))) + np.float32(np.float32(d - e) * np.float32(np.float32(f.tau2) / np.float32(f.tau1)))
+    assert f.update(float(d), float(e), float(dt)) == float(np.float32(exp))
+
+
+def test_decide_host_equals_oracle_decision(gm, oracle):
+    from gnss_sdr_rs_amd import distributed as Dm
+    rng = np.random.default_rng(4)
+    P, D, N = 6, 9, 4096
+    mx = (rng.random((P, D)) * 1e6 + 1e6).astype(np.float32)
+    sm = (mx * rng.uniform(300, 900, (P, D))).astype(np.float32)     # ratio max/avg ~ 4.5 .. 13.6
+    am = rng.integers(0, N, (P, D)).astype(np.uint32)
+    tf = np.linspace(-2000, 2000, D).astype(np.float32)
+    prns = [3, 4, 9, 12, 20, 31]
+    got = Dm.decide_host(Dm.pack_metrics(mx, am, sm), prns, tf, N, 4.096e6, local_tail=77)
+    n_found = 0
+    for i, p in enumerate(prns):
+        exp = oracle.decide_from_metrics(mx[i], am[i], sm[i], tf, N, p, 4.096e6, 77)
+        assert got[i] == exp
+        n_found += exp is not None
+    assert 0 < n_found < P
+
+
+def test_synth_scene_is_deterministic(gm):
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    t = A.ca_code_table()
+    a, b = synth.cfg2_scene(t), synth.cfg2_scene(t)
+    assert (a["x"] == b["x"]).all() and a["sats"] == b["sats"]
+    i8 = synth.to_i8_iq(a["x"])
+    assert i8.shape == (80000, 2) and np.abs(i8).max() <= 127
+    assert hashlib.sha256(i8.tobytes()).hexdigest() == hashlib.sha256(synth.to_i8_iq(b["x"]).tobytes()).hexdigest()

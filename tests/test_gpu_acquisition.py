@@ -165,7 +165,9 @@ def test_cfg1_geometry_real_int8(gpu, oracle):
     for r, prn in zip(res, prns):
         if prn in (2, 3, 6):
             row = [s for s in cap["signals"] if s["prn"] == prn][0]
-            assert r["code_phase_samples"] == row["code_phase_samples"]       # config.txt:6-15
+            # config.txt:6-15; +-1 sample: 16 samples/chip and floor() resampling put the correlation peak on
+            # either side of the simulated code start
+            assert abs(r["code_phase_samples"] - row["code_phase_samples"]) <= 1
     eng.close()
 
 
