@@ -26,18 +26,48 @@ namespace gm {
 template <class PL, bool INV, int S> struct MiddlePasses {
     static __device__ __forceinline__ void run(cf* lds, const cf* tw, int tid) {
         if constexpr (S <= PL::NP - 2) {
-            cf u[PL::IT(S)][PL::R[S]];
-            Fft<PL, INV>::template gather<S>(u, lds, tw, tid);
-            __syncthreads();
-            Fft<PL, INV>::template scatter<S>(u, lds, tid);
+            cf v[PL::IT(S)][PL::R[S]];
+            Fft<PL, INV>::template mid_stage1<S>(v, lds, tw, tid);
+            __syncthreads();   // every lane has read its inputs: the image may be overwritten
+            Fft<PL, INV>::template mid_stage2<S>(v, lds, tid);
             __syncthreads();
             MiddlePasses<PL, INV, S + 1>::run(lds, tw, tid);
         }
     }
 };
 
+// One length-N transform by the whole workgroup: in(it, r) feeds pass 0, out(it, r, value) receives
+// the natural-order outputs.  Safe to call back to back (the first barrier orders the scatter after
+// the previous transform's last LDS reads and after the twiddle-table load).
+template <class PL, bool INV, class In, class Out>
+__device__ __forceinline__ void lds_transform(In&& in, Out&& out, cf* lds, const cf* tw, int tid) {
+    {
+        cf v0[PL::IT0][PL::R0];
+        Fft<PL, INV>::pass0_stage1(v0, in, tid);
+        __syncthreads();
+        Fft<PL, INV>::pass0_stage2(v0, lds, tid);
+    }
+    __syncthreads();
+    MiddlePasses<PL, INV, 1>::run(lds, tw, tid);
+    cf vl[PL::ITL][PL::RL];
+    Fft<PL, INV>::last_stage1(vl, lds, tw, tid);
+    Fft<PL, INV>::last_stage2(vl, out, tid);
+}
+
 template <class PL> __device__ __forceinline__ void load_twiddles(cf* tw_lds, const cf* tw_g, int tid) {
     for (int i = tid; i < PL::TW_TOTAL; i += PL::T) tw_lds[i] = tw_g[i];
+}
+
+// Buffer-descriptor loads: the 128-bit resource sits in SGPRs, the per-lane byte offset is ONE VGPR
+// shared by every element of the butterfly, the per-element stride goes into the scalar offset.
+// (Flat addressing made hipcc keep one 64-bit VGPR address per element live across the m loop.)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, int(bytes), 0x00020000);
+}
+__device__ __forceinline__ cf buf_load_cf(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_bytes, soff_bytes, 0);
+    return cf_make(__uint_as_float(v.x), __uint_as_float(v.y));
 }
 
 __device__ __forceinline__ cf load_sample(const void* samples, int fmt, size_t idx) {
@@ -60,38 +90,19 @@ __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restri
     const int tid = threadIdx.x;
     const int d = blockIdx.x / n_int, m = blockIdx.x % n_int;
     load_twiddles<PL>(tw, tw_fwd, tid);
-
-    cf in[PL::IT0][PL::R0];
-    const size_t sbase = size_t(m) * PL::N, tbase = size_t(d) * PL::N;
-#pragma unroll
-    for (int it = 0; it < PL::IT0; ++it) {
-        const int b = tid + it * PL::T;
-        if (b < PL::NB(0)) {
-#pragma unroll
-            for (int r = 0; r < PL::R0; ++r) {
-                const int idx = b + r * PL::NB(0);
-                const cf s = load_sample(samples, fmt, sbase + idx);
-                const cf t = tables[tbase + idx];
-                // multiply_simd_block (doppler_shift.rs:43-58): a*c + (b*d*(-1)), a*d + (b*c*(+1))
-                in[it][r] = cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);
-            }
-        }
-    }
-    Fft<PL, false>::scatter0(in, lds, tid);
-    __syncthreads();
-    MiddlePasses<PL, false, 1>::run(lds, tw, tid);
-    cf out[PL::ITL][PL::RL];
-    Fft<PL, false>::gather_last(out, lds, tw, tid);
+    const size_t sbase = size_t(m) * PL::N;
+    const cf* tab = tables + size_t(d) * PL::N;
     cf* dst = spectra + size_t(blockIdx.x) * PL::N;   // [d][m][k]
-    constexpr int NBL = PL::NB(PL::NP - 1);
-#pragma unroll
-    for (int it = 0; it < PL::ITL; ++it) {
-        const int b = tid + it * PL::T;
-        if (b < NBL) {
-#pragma unroll
-            for (int r = 0; r < PL::RL; ++r) dst[b + r * NBL] = out[it][r];
-        }
-    }
+    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    lds_transform<PL, false>(
+        [&](int it, int r) {
+            const int idx = (tid + it * PL::T) + r * NB0;
+            const cf s = load_sample(samples, fmt, sbase + idx);
+            const cf t = tab[idx];
+            // multiply_simd_block (doppler_shift.rs:43-58): a*c + (b*d*(-1)), a*d + (b*c*(+1))
+            return cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);
+        },
+        [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
 }
 
 // ------------------------------------------------------------------------------------ stage C
@@ -101,13 +112,10 @@ __device__ __forceinline__ void take_better(float& bv, uint32_t& bi, float v, ui
 }
 
 template <class PL, bool KEEP_CODE>
-__global__ __launch_bounds__(PL::T) void acq_corr_kernel(const cf* __restrict__ spectra,
-                                                         const cf* __restrict__ code_fft,
-                                                         const cf* __restrict__ tw_inv,
-                                                         float* __restrict__ mmax, uint32_t* __restrict__ margmax,
-                                                         float* __restrict__ msum,
-                                                         const uint32_t* __restrict__ worker_list, int n_workers,
-                                                         int n_bins, int n_int) {
+__global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
+    const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ tw_inv,
+    float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
+    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int) {
     // XCD-aware tile map: blocks b and b+8 share an XCD (round-robin dispatch, speed only).  All
     // workers of one Doppler bin go to one XCD so that bin's M spectra (M*8N bytes) stay in its L2.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -119,19 +127,22 @@ __global__ __launch_bounds__(PL::T) void acq_corr_kernel(const cf* __restrict__ 
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
     load_twiddles<PL>(tw, tw_inv, tid);
+    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
 
-    // conj(code spectrum) for this thread's pass-0 elements: resident in registers across the m
-    // loop when the register budget allows (KEEP_CODE), else re-read from L2 next to the spectrum
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(spectra + size_t(d) * n_int * PL::N, unsigned(n_int) * PL::N * 8u);
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(code_fft + size_t(p) * PL::N, PL::N * 8u);
+
+    // conj(code spectrum) for this lane's pass-0 elements: resident in registers across the m loop
+    // when the register budget allows (KEEP_CODE), else re-read from L2 next to the spectrum
     cf cc[KEEP_CODE ? PL::IT0 : 1][KEEP_CODE ? PL::R0 : 1];
-    const cf* cptr = code_fft + size_t(p) * PL::N;
     if constexpr (KEEP_CODE) {
 #pragma unroll
         for (int it = 0; it < PL::IT0; ++it) {
             const int b = tid + it * PL::T;
-            if (b < PL::NB(0)) {
+            if (b < NB0) {
 #pragma unroll
                 for (int r = 0; r < PL::R0; ++r) {
-                    const cf c = cptr[b + r * PL::NB(0)];
+                    const cf c = buf_load_cf(crs, b * 8, r * NB0 * 8);
                     cc[it][r] = cf_make(c.x, -c.y);
                 }
             }
@@ -143,41 +154,22 @@ __global__ __launch_bounds__(PL::T) void acq_corr_kernel(const cf* __restrict__ 
 #pragma unroll
         for (int r = 0; r < PL::RL; ++r) acc[it][r] = 0.0f;
 
-    constexpr int NBL = PL::NB(PL::NP - 1);
-    const cf* xptr = spectra + size_t(d) * n_int * PL::N;
-    for (int m = 0; m < n_int; ++m, xptr += PL::N) {
-        cf in[PL::IT0][PL::R0];
-#pragma unroll
-        for (int it = 0; it < PL::IT0; ++it) {
-            const int b = tid + it * PL::T;
-            if (b < PL::NB(0)) {
-#pragma unroll
-                for (int r = 0; r < PL::R0; ++r) {
-                    const cf a = xptr[b + r * PL::NB(0)];
-                    cf c;
-                    if constexpr (KEEP_CODE) c = cc[it][r];
-                    else { const cf g = cptr[b + r * PL::NB(0)]; c = cf_make(g.x, -g.y); }
-                    // result_buf[i] *= conj(code[i])  (:184-186), num-complex Mul, no FMA
-                    in[it][r] = cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
-                }
-            }
-        }
-        __syncthreads();   // previous transform's last gather (and the twiddle load) is complete
-        Fft<PL, true>::scatter0(in, lds, tid);
-        __syncthreads();
-        MiddlePasses<PL, true, 1>::run(lds, tw, tid);
-        cf out[PL::ITL][PL::RL];
-        Fft<PL, true>::gather_last(out, lds, tw, tid);
-#pragma unroll
-        for (int it = 0; it < PL::ITL; ++it)
-#pragma unroll
-            for (int r = 0; r < PL::RL; ++r) {
-                const cf v = out[it][r];
-                acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y);   // += norm_sqr() (:190-192)
-            }
+    for (int m = 0; m < n_int; ++m) {
+        lds_transform<PL, true>(
+            [&](int it, int r) {
+                const int voff = (tid + it * PL::T) * 8;
+                const cf a = buf_load_cf(xrs, voff, (m * PL::N + r * NB0) * 8);
+                cf c;
+                if constexpr (KEEP_CODE) c = cc[it][r];
+                else { const cf g = buf_load_cf(crs, voff, r * NB0 * 8); c = cf_make(g.x, -g.y); }
+                // result_buf[i] *= conj(code[i])  (:184-186), num-complex Mul, no FMA
+                return cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
+            },
+            [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y); },   // += norm_sqr() (:190-192)
+            lds, tw, tid);
     }
 
-    // per-thread: first strict maximum + partial sum
+    // per-lane: first strict maximum + partial sum
     float bv = 0.0f, sum = 0.0f;
     uint32_t bi = 0xffffffffu;
 #pragma unroll
@@ -228,30 +220,10 @@ __global__ __launch_bounds__(PL::T) void acq_code_fft_kernel(const int8_t* __res
     const int tid = threadIdx.x;
     load_twiddles<PL>(tw, tw_fwd, tid);
     const int8_t* src = code_samples + size_t(blockIdx.x) * PL::N;
-    cf in[PL::IT0][PL::R0];
-#pragma unroll
-    for (int it = 0; it < PL::IT0; ++it) {
-        const int b = tid + it * PL::T;
-        if (b < PL::NB(0)) {
-#pragma unroll
-            for (int r = 0; r < PL::R0; ++r) in[it][r] = cf_make(float(src[b + r * PL::NB(0)]), 0.0f);
-        }
-    }
-    Fft<PL, false>::scatter0(in, lds, tid);
-    __syncthreads();
-    MiddlePasses<PL, false, 1>::run(lds, tw, tid);
-    cf out[PL::ITL][PL::RL];
-    Fft<PL, false>::gather_last(out, lds, tw, tid);
     cf* dst = code_fft + size_t(blockIdx.x) * PL::N;
-    constexpr int NBL = PL::NB(PL::NP - 1);
-#pragma unroll
-    for (int it = 0; it < PL::ITL; ++it) {
-        const int b = tid + it * PL::T;
-        if (b < NBL) {
-#pragma unroll
-            for (int r = 0; r < PL::RL; ++r) dst[b + r * NBL] = out[it][r];
-        }
-    }
+    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    lds_transform<PL, false>([&](int it, int r) { return cf_make(float(src[(tid + it * PL::T) + r * NB0]), 0.0f); },
+                             [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
 }
 
 // ------------------------------------------------------------------------------------ plain batched FFT
@@ -262,29 +234,11 @@ __global__ __launch_bounds__(PL::T) void fft_batch_kernel(cf* __restrict__ data,
     const int tid = threadIdx.x;
     load_twiddles<PL>(tw, tw_g, tid);
     cf* x = data + size_t(blockIdx.x) * PL::N;
-    cf in[PL::IT0][PL::R0];
-#pragma unroll
-    for (int it = 0; it < PL::IT0; ++it) {
-        const int b = tid + it * PL::T;
-        if (b < PL::NB(0)) {
-#pragma unroll
-            for (int r = 0; r < PL::R0; ++r) in[it][r] = x[b + r * PL::NB(0)];
-        }
-    }
-    Fft<PL, INV>::scatter0(in, lds, tid);
-    __syncthreads();
-    MiddlePasses<PL, INV, 1>::run(lds, tw, tid);
-    cf out[PL::ITL][PL::RL];
-    Fft<PL, INV>::gather_last(out, lds, tw, tid);
-    constexpr int NBL = PL::NB(PL::NP - 1);
-#pragma unroll
-    for (int it = 0; it < PL::ITL; ++it) {
-        const int b = tid + it * PL::T;
-        if (b < NBL) {
-#pragma unroll
-            for (int r = 0; r < PL::RL; ++r) x[b + r * NBL] = out[it][r];
-        }
-    }
+    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    // in place: every input is in registers (pass-0 stage 1) before the first barrier, outputs are
+    // written after the last pass
+    lds_transform<PL, INV>([&](int it, int r) { return x[(tid + it * PL::T) + r * NB0]; },
+                           [&](int it, int r, cf val) { x[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
 }
 
 // ------------------------------------------------------------------------------------ launchers

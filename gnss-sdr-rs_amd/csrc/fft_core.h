@@ -268,6 +268,97 @@ template <bool INV> struct Dft<25, INV> { static GM_HD void run(cf (&u)[25]) { D
 template <bool INV> struct Dft<32, INV> { static GM_HD void run(cf (&u)[32]) { DftCT<4, 8, INV>::run(u); } };
 template <bool INV> struct Dft<33, INV> { static GM_HD void run(cf (&u)[33]) { DftPFA<3, 11, INV>::run(u); } };
 
+// ------------------------------------------------------------------ two-stage (streaming) butterflies
+// A radix-R butterfly is split at its Cooley-Tukey / Good-Thomas seam so that the caller can put the
+// in-place barrier BETWEEN the stages and so that inputs are consumed as they are loaded and outputs
+// stored as they are produced: peak live state is the R intermediate values, not inputs + outputs.
+//   stage1(in, v)  : in(r) yields input r (already twiddled); B sub-DFTs of size A -> v[R]
+//   stage2(v, out) : A sub-DFTs of size B; out(k, value) receives output k
+// KIND 0 = leaf (whole DFT in stage 1), 1 = Cooley-Tukey, 2 = Good-Thomas.
+template <int R> struct Fac { static constexpr int A = R, B = 1, KIND = 0; };
+template <> struct Fac<8> { static constexpr int A = 2, B = 4, KIND = 1; };
+template <> struct Fac<10> { static constexpr int A = 2, B = 5, KIND = 2; };
+template <> struct Fac<16> { static constexpr int A = 4, B = 4, KIND = 1; };
+template <> struct Fac<20> { static constexpr int A = 4, B = 5, KIND = 2; };
+template <> struct Fac<25> { static constexpr int A = 5, B = 5, KIND = 1; };
+template <> struct Fac<32> { static constexpr int A = 4, B = 8, KIND = 1; };
+template <> struct Fac<33> { static constexpr int A = 3, B = 11, KIND = 2; };
+
+template <int R, bool INV> struct Bfly {
+    static constexpr int A = Fac<R>::A, B = Fac<R>::B, KIND = Fac<R>::KIND;
+    static constexpr int EA = KIND == 2 ? int(B * ct::modinv(B, A)) : 0;
+    static constexpr int EB = KIND == 2 ? int(A * ct::modinv(A, B)) : 0;
+
+    template <int N2, int K1> static GM_HD void inner_tw(cf (&t)[A]) {
+        if constexpr (K1 < A) {
+            t[K1] = mul_wconst<INV, long(N2) * K1, long(R)>(t[K1]);
+            inner_tw<N2, K1 + 1>(t);
+        }
+    }
+    template <int N2, class In> static GM_HD void s1(In& in, cf (&v)[R]) {
+        if constexpr (N2 < B) {
+            cf t[A];
+#pragma unroll
+            for (int n1 = 0; n1 < A; ++n1) {
+                if constexpr (KIND == 2) t[n1] = in((B * n1 + A * N2) % R);
+                else t[n1] = in(N2 + B * n1);
+            }
+            Dft<A, INV>::run(t);
+            if constexpr (KIND == 1) inner_tw<N2, 1>(t);
+#pragma unroll
+            for (int k1 = 0; k1 < A; ++k1) v[N2 * A + k1] = t[k1];
+            s1<N2 + 1>(in, v);
+        }
+    }
+    template <class In> static GM_HD void stage1(In&& in, cf (&v)[R]) { s1<0>(in, v); }
+
+    template <class Out> static GM_HD void stage2(const cf (&v)[R], Out&& out) {
+        if constexpr (KIND == 0) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) out(k, v[k]);
+        } else {
+#pragma unroll
+            for (int k1 = 0; k1 < A; ++k1) {
+                cf t[B];
+#pragma unroll
+                for (int n2 = 0; n2 < B; ++n2) t[n2] = v[n2 * A + k1];
+                Dft<B, INV>::run(t);
+#pragma unroll
+                for (int k2 = 0; k2 < B; ++k2) {
+                    if constexpr (KIND == 2) out((k1 * EA + k2 * EB) % R, t[k2]);
+                    else out(k1 + A * k2, t[k2]);
+                }
+            }
+        }
+    }
+};
+
+// w^r for r = 0..R-1 from the table value w^1: w^r = G[r / BS] * B[r % BS] (baby-step / giant-step).
+// Only BS-1 + ceil(R/BS)-1 powers stay live (7 complex registers at R = 20), every power is at most
+// ~4 rounded products away from w^1, and they are multiplied on the fly as inputs arrive.
+template <int R> struct TwPow {
+    static constexpr int BS = R <= 4 ? R : (R <= 9 ? 3 : (R <= 16 ? 4 : (R <= 25 ? 5 : 6)));
+    static constexpr int NG = (R + BS - 1) / BS;
+    cf Bp[BS], G[NG];
+    GM_HD void init(cf w1) {
+        Bp[1 % BS] = w1;
+#pragma unroll
+        for (int b = 2; b < BS; ++b) Bp[b] = cf_mul(Bp[b / 2], Bp[b - b / 2]);
+        if constexpr (NG > 1) {
+            G[1] = cf_mul(Bp[BS / 2], Bp[BS - BS / 2]);
+#pragma unroll
+            for (int g = 2; g < NG; ++g) G[g] = cf_mul(G[g / 2], G[g - g / 2]);
+        }
+    }
+    GM_HD cf apply(cf u, int r) const {   // r is a compile-time constant after unrolling
+        const int g = r / BS, b = r % BS;
+        if (r == 0) return u;
+        if (g == 0) return cf_mul(u, Bp[b]);
+        if (b == 0) return cf_mul(u, G[g]);
+        return cf_mul(u, cf_mul(G[g], Bp[b]));
+    }
+};
+
 // ------------------------------------------------------------------ the plan
 template <int N_, int T_, int... Rs> struct Plan {
     static constexpr int N = N_, T = T_, NP = int(sizeof...(Rs));
@@ -277,7 +368,7 @@ template <int N_, int T_, int... Rs> struct Plan {
     static constexpr int IT(int s) { return (NB(s) + T - 1) / T; }
     static constexpr int TWOFF(int s) { int o = 0; for (int i = 1; i < s; ++i) o += P(i); return o; }
     static constexpr int TW_TOTAL = TWOFF(NP);
-    // pad the pass0 -> pass1 image by one element per R0 when R0 is even (stride-R0 scatter would
+    // pad the pass0 -> pass1 image by one element per R0 when R0 is even (a stride-R0 scatter would
     // otherwise land 16 lanes on few banks); later scatters are runs of P >= R0 contiguous elements
     static constexpr int PAD_Q = (R[0] % 2 == 0) ? R[0] : 0;
     static constexpr int LDS_ELEMS = N + (PAD_Q ? N / PAD_Q : 0);
@@ -285,6 +376,10 @@ template <int N_, int T_, int... Rs> struct Plan {
     // correlation kernel: keep conj(code spectrum) in registers across the integrations loop
     // (IT0*R0 complex VGPR pairs) only when it does not push the kernel past its VGPR budget
     static constexpr bool KEEP_CODE = (IT0 * R0 + ITL * RL) <= 24;
+    // workgroups per CU the LDS footprint admits (160 KB per CU), and the waves per SIMD that needs
+    static constexpr int LDS_BYTES = 8 * (LDS_ELEMS + TW_TOTAL);
+    static constexpr int WG_PER_CU = (2 * LDS_BYTES <= 160 * 1024 && T <= 512) ? 2 : 1;
+    static constexpr int WAVES_PER_EU = (WG_PER_CU * T / 64 + 3) / 4;
     static constexpr bool check() { int p = 1; for (int i = 0; i < NP; ++i) p *= R[i]; return p == N && NP >= 2; }
     static_assert(check(), "radices must multiply to N and there must be >= 2 passes");
 };
@@ -301,10 +396,13 @@ template <class PL> inline void fill_twiddles(cf* tw, bool inverse, double (*cos
     }
 }
 
-// ------------------------------------------------------------------ per-thread phases
-// A transform is run by every thread calling, in order, with a workgroup barrier at each '|':
-//   scatter0 | gather<1> scatter<1> (barrier between them) | ... | gather_last
-// The split into phases is what lets the CPU emulation interleave "threads".
+// ------------------------------------------------------------------ per-thread phases of one transform
+// Every thread of the workgroup calls, in order ('|' = workgroup barrier):
+//   pass0_stage1  | pass0_stage2 | mid_stage1<1> | mid_stage2<1> | ... | last_stage1  last_stage2
+//   (the barrier before pass0_stage2 only orders it after the PREVIOUS transform's last_stage1 reads)
+// Element (it, r) of pass S belongs to butterfly b = tid + it*T and is input index b + r*NB(S);
+// outputs of the last pass are output index b + r*NB(last).  The split into phases is also what lets
+// the CPU emulation (tests/cpu) interleave "threads".
 template <class PL, bool INV> struct Fft {
     static constexpr int NP = PL::NP;
 
@@ -312,80 +410,67 @@ template <class PL, bool INV> struct Fft {
         if constexpr (PL::PAD_Q != 0) return e + e / PL::PAD_Q;
         else return e;
     }
+    // LDS index of input element e of pass S (only the pass0 -> pass1 image is padded)
+    template <int S> static GM_HD int rd(int e) { return S == 1 ? map01(e) : e; }
 
-    // powers w^1..w^(R-1) by a balanced product tree (<= ~log2(R)+1 roundings each)
-    template <int R> static GM_HD void twiddle(cf (&u)[R], cf w1) {
-        cf w[R];
-        w[1] = w1;
-#pragma unroll
-        for (int r = 2; r < R; ++r) w[r] = cf_mul(w[r / 2], w[r - r / 2]);
-#pragma unroll
-        for (int r = 1; r < R; ++r) u[r] = cf_mul(u[r], w[r]);
-    }
-
-    // pass 0: butterfly the caller's registers (element (it, r) is input index (tid + it*T) + r*NB(0))
-    // and scatter to LDS.  Call after the barrier that ends the previous transform's last gather.
-    static GM_HD void scatter0(cf (&in)[PL::IT0][PL::R0], cf* lds, int tid) {
-        constexpr int R = PL::R0, NB = PL::NB(0);
+    // pass 0: in(it, r) yields the caller's input element (fused global load / mix / x conj(code))
+    template <class In> static GM_HD void pass0_stage1(cf (&v)[PL::IT0][PL::R0], In&& in, int tid) {
 #pragma unroll
         for (int it = 0; it < PL::IT0; ++it) {
             const int b = tid + it * PL::T;
-            if (b < NB) {
-                Dft<R, INV>::run(in[it]);
+            if (b < PL::NB(0)) Bfly<PL::R0, INV>::stage1([&](int r) { return in(it, r); }, v[it]);
+        }
+    }
+    static GM_HD void pass0_stage2(const cf (&v)[PL::IT0][PL::R0], cf* lds, int tid) {
+        constexpr int R = PL::R0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) lds[map01(b * R + r)] = in[it][r];
+        for (int it = 0; it < PL::IT0; ++it) {
+            const int b = tid + it * PL::T;
+            if (b < PL::NB(0)) {
+                // map01(b*R + k) == b*(R + pad) + k : one base register, constant offsets
+                cf* dst = lds + b * (R + (PL::PAD_Q ? 1 : 0));
+                Bfly<R, INV>::stage2(v[it], [&](int k, cf val) { dst[k] = val; });
             }
         }
     }
 
-    // middle pass S (1 <= S <= NP-2): gather + twiddle + butterfly into registers
-    template <int S> static GM_HD void gather(cf (&u)[PL::IT(S)][PL::R[S]], const cf* lds, const cf* tw, int tid) {
+    template <int S> static GM_HD void gather_stage1(cf (&v)[PL::IT(S)][PL::R[S]], const cf* lds, const cf* tw, int tid) {
         constexpr int R = PL::R[S], NB = PL::NB(S), P = PL::P(S);
 #pragma unroll
         for (int it = 0; it < PL::IT(S); ++it) {
             const int b = tid + it * PL::T;
             if (b < NB) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int e = b + r * NB;
-                    u[it][r] = lds[S == 1 ? map01(e) : e];
-                }
-                const int k = b % P;
-                twiddle<R>(u[it], tw[PL::TWOFF(S) + k]);
-                Dft<R, INV>::run(u[it]);
+                TwPow<R> w;
+                w.init(tw[PL::TWOFF(S) + (b % P)]);
+                Bfly<R, INV>::stage1([&](int r) { return w.apply(lds[rd<S>(b + r * NB)], r); }, v[it]);
             }
         }
     }
-    template <int S> static GM_HD void scatter(const cf (&u)[PL::IT(S)][PL::R[S]], cf* lds, int tid) {
+    template <int S> static GM_HD void mid_stage1(cf (&v)[PL::IT(S)][PL::R[S]], const cf* lds, const cf* tw, int tid) {
+        gather_stage1<S>(v, lds, tw, tid);
+    }
+    template <int S> static GM_HD void mid_stage2(const cf (&v)[PL::IT(S)][PL::R[S]], cf* lds, int tid) {
         constexpr int R = PL::R[S], NB = PL::NB(S), P = PL::P(S);
 #pragma unroll
         for (int it = 0; it < PL::IT(S); ++it) {
             const int b = tid + it * PL::T;
             if (b < NB) {
                 const int k = b % P;
-                const int j = (b - k) * R + k;
-#pragma unroll
-                for (int r = 0; r < R; ++r) lds[j + r * P] = u[it][r];
+                cf* dst = lds + (b - k) * R + k;
+                Bfly<R, INV>::stage2(v[it], [&](int q, cf val) { dst[q * P] = val; });
             }
         }
     }
-    // last pass: outputs in registers, element (it, r) is output index (tid + it*T) + r*NB(last)
-    static GM_HD void gather_last(cf (&out)[PL::ITL][PL::RL], const cf* lds, const cf* tw, int tid) {
-        constexpr int S = NP - 1;
-        constexpr int R = PL::RL, NB = PL::NB(S), P = PL::P(S);
-        static_assert(P == NB, "last pass has P == N/R");
+    static GM_HD void last_stage1(cf (&v)[PL::ITL][PL::RL], const cf* lds, const cf* tw, int tid) {
+        static_assert(PL::P(NP - 1) == PL::NB(NP - 1), "last pass has P == N/R");
+        gather_stage1<NP - 1>(v, lds, tw, tid);
+    }
+    // out(it, r, value): output index (tid + it*T) + r*NB(last)
+    template <class Out> static GM_HD void last_stage2(const cf (&v)[PL::ITL][PL::RL], Out&& out, int tid) {
 #pragma unroll
         for (int it = 0; it < PL::ITL; ++it) {
             const int b = tid + it * PL::T;
-            if (b < NB) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int e = b + r * NB;
-                    out[it][r] = lds[S == 1 ? map01(e) : e];
-                }
-                twiddle<R>(out[it], tw[PL::TWOFF(S) + b]);
-                Dft<R, INV>::run(out[it]);
-            }
+            if (b < PL::NB(NP - 1)) Bfly<PL::RL, INV>::stage2(v[it], [&](int q, cf val) { out(it, q, val); });
         }
     }
 };

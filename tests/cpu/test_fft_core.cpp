@@ -17,13 +17,13 @@ template <class PL, bool INV, int S> struct Middle {
         if constexpr (S <= PL::NP - 2) {
             constexpr int IT = PL::IT(S), R = PL::R[S];
             std::vector<cf> regs(size_t(PL::T) * IT * R);
-            for (int tid = 0; tid < PL::T; ++tid) {   // phase: gather
-                auto& u = *reinterpret_cast<cf(*)[IT][R]>(&regs[size_t(tid) * IT * R]);
-                Fft<PL, INV>::template gather<S>(u, lds.data(), tw.data(), tid);
+            for (int tid = 0; tid < PL::T; ++tid) {   // phase: gather + first half of the butterfly
+                auto& v = *reinterpret_cast<cf(*)[IT][R]>(&regs[size_t(tid) * IT * R]);
+                Fft<PL, INV>::template mid_stage1<S>(v, lds.data(), tw.data(), tid);
             }
-            for (int tid = 0; tid < PL::T; ++tid) {   // barrier; phase: scatter
-                auto& u = *reinterpret_cast<cf(*)[IT][R]>(&regs[size_t(tid) * IT * R]);
-                Fft<PL, INV>::template scatter<S>(u, lds.data(), tid);
+            for (int tid = 0; tid < PL::T; ++tid) {   // barrier; phase: second half + scatter
+                auto& v = *reinterpret_cast<cf(*)[IT][R]>(&regs[size_t(tid) * IT * R]);
+                Fft<PL, INV>::template mid_stage2<S>(v, lds.data(), tid);
             }
             Middle<PL, INV, S + 1>::run(lds, tw);
         }
@@ -40,25 +40,22 @@ template <class PL, bool INV> static double run_plan(const char* name) {
         s = s * 1664525u + 1013904223u; float b = float(int(s >> 8) % 2001 - 1000) / 100.f;
         x[i] = cf_make(a, b);
     }
-    // pass 0
-    for (int tid = 0; tid < T; ++tid) {
-        cf in[PL::IT0][PL::R0];
-        for (int it = 0; it < PL::IT0; ++it)
-            for (int r = 0; r < PL::R0; ++r) {
-                int b = tid + it * T;
-                in[it][r] = (b < PL::NB(0)) ? x[b + r * PL::NB(0)] : cf_make(0, 0);
-            }
-        Fft<PL, INV>::scatter0(in, lds.data(), tid);
+    {   // pass 0: stage 1 for every thread, (barrier), stage 2 for every thread
+        std::vector<cf> regs(size_t(T) * PL::IT0 * PL::R0);
+        for (int tid = 0; tid < T; ++tid) {
+            auto& v = *reinterpret_cast<cf(*)[PL::IT0][PL::R0]>(&regs[size_t(tid) * PL::IT0 * PL::R0]);
+            Fft<PL, INV>::pass0_stage1(v, [&](int it, int r) { return x[(tid + it * T) + r * PL::NB(0)]; }, tid);
+        }
+        for (int tid = 0; tid < T; ++tid) {
+            auto& v = *reinterpret_cast<cf(*)[PL::IT0][PL::R0]>(&regs[size_t(tid) * PL::IT0 * PL::R0]);
+            Fft<PL, INV>::pass0_stage2(v, lds.data(), tid);
+        }
     }
     Middle<PL, INV, 1>::run(lds, tw);
     for (int tid = 0; tid < T; ++tid) {
-        cf out[PL::ITL][PL::RL];
-        Fft<PL, INV>::gather_last(out, lds.data(), tw.data(), tid);
-        for (int it = 0; it < PL::ITL; ++it) {
-            int b = tid + it * T;
-            if (b < PL::NB(PL::NP - 1))
-                for (int r = 0; r < PL::RL; ++r) y[b + r * PL::NB(PL::NP - 1)] = out[it][r];
-        }
+        cf v[PL::ITL][PL::RL];
+        Fft<PL, INV>::last_stage1(v, lds.data(), tw.data(), tid);
+        Fft<PL, INV>::last_stage2(v, [&](int it, int r, cf val) { y[(tid + it * T) + r * PL::NB(PL::NP - 1)] = val; }, tid);
     }
     // reference: float64 DFT
     std::vector<std::complex<double>> w(N);
