@@ -317,28 +317,38 @@ void launch_power(hipStream_t st, const cf* x, float* p, size_t n) {
 }
 
 // ------------------------------------------------------------------------------------ decision replay
-__global__ void decide_kernel(DecideArgs a) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.n_prn) return;
+__global__ __launch_bounds__(64) void decide_kernel(DecideArgs a) {
+    // one wavefront per worker: the D metric triples are staged to LDS with coalesced loads, then lane 0
+    // replays the reference's sequential scan out of LDS (no dependent global-memory round trips)
+    extern __shared__ float dsm[];
+    const int p = blockIdx.x, lane = threadIdx.x, D = a.n_bins;
+    float* smax = dsm;
+    float* ssum = dsm + D;
+    uint32_t* sarg = reinterpret_cast<uint32_t*>(dsm + 2 * D);
+    for (int d = lane; d < D; d += 64) {
+        const size_t o = size_t(p) * D + d;
+        smax[d] = a.mmax[o]; ssum[d] = a.msum[o]; sarg[d] = a.margmax[o];
+    }
+    __syncthreads();
+    if (lane != 0) return;
     gm_acq_result r;
     r.prn = a.prn_ids[p]; r.code_phase_samples = 0; r.code_phase_chips = 0.f; r.carrier_freq = 0.f;
     r.fs = 0.f; r.mag_relative = 0.f; r.sample_global_index = 0; r.doppler_bin = -1;   // AcquisitionResult::new
     uint8_t found = 0;
     const bool searched = (p >= 64) || ((a.mask_lo >> p) & 1ull);
     if (searched) {
-        float gmax = 0.0f, bfreq = 0.0f, bsum = 0.0f;      // best plane starts all-zero (:168)
+        float gmax = 0.0f, bsum = 0.0f;                    // best plane starts all-zero (:168)
         uint32_t bphase = 0;
         int bbin = -1;
         const float nm1 = float(a.fft_size - 1);
-        for (int d = 0; d < a.n_bins; ++d) {               // ascending Doppler (:171)
-            const size_t o = size_t(p) * a.n_bins + d;
-            const float lm = a.mmax[o];
-            if (lm > gmax) { gmax = lm; bfreq = a.table_freq[d]; bphase = a.margmax[o]; bsum = a.msum[o]; bbin = d; }
+        for (int d = 0; d < D; ++d) {                      // ascending Doppler (:171)
+            const float lm = smax[d];
+            if (lm > gmax) { gmax = lm; bphase = sarg[d]; bsum = ssum[d]; bbin = d; }
             const float avg = __fdiv_rn(bsum - gmax, nm1);  // (sum - max) / (N-1)  (:236)
             if (__fdiv_rn(gmax, avg) > a.threshold) {       // max/avg > 7.0       (:237)
                 r.code_phase_samples = bphase;
                 r.code_phase_chips = __fdiv_rn(float(bphase) * a.code_rate, a.fs);   // (:215-216)
-                r.carrier_freq = bfreq; r.fs = a.fs; r.mag_relative = gmax;
+                r.carrier_freq = a.table_freq[bbin]; r.fs = a.fs; r.mag_relative = gmax;
                 r.sample_global_index = a.local_tail + bphase; r.doppler_bin = bbin;
                 found = 1;
                 break;                                       // early exit (:211-222)
@@ -350,7 +360,7 @@ __global__ void decide_kernel(DecideArgs a) {
 }
 void launch_decide(hipStream_t st, const DecideArgs& a) {
     if (a.n_prn <= 0) return;
-    hipLaunchKernelGGL(decide_kernel, dim3((a.n_prn + 63) / 64), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(decide_kernel, dim3(a.n_prn), dim3(64), size_t(a.n_bins) * 12, st, a);
 }
 
 }  // namespace gm

@@ -117,7 +117,7 @@ struct gm_acq {
     uint32_t N = 0, D = 0, M = 0, P = 0;
     float code_rate = CA_RATE;
     std::vector<float> table_freq;
-    std::vector<uint8_t> prn_ids;
+    std::vector<uint8_t> prn_ids, dev_prn_ids;
     cf *d_tables = nullptr, *d_tw_fwd = nullptr, *d_tw_inv = nullptr, *d_code_fft = nullptr, *d_spectra = nullptr;
     float* d_table_freq = nullptr;
     int8_t* d_code_samples = nullptr;
@@ -154,6 +154,7 @@ static int acq_set_mask(gm_acq* a, uint64_t mask) {
 static int acq_reserve_results(gm_acq* a, uint32_t n) {
     if (n <= a->results_cap) return GM_OK;
     if (a->d_results) { hipFree(a->d_results); hipFree(a->d_found); hipFree(a->d_prn_ids); }
+    a->dev_prn_ids.clear();
     HIPC(hipMalloc(&a->d_results, sizeof(gm_acq_result) * n));
     HIPC(hipMalloc(&a->d_found, n));
     HIPC(hipMalloc(&a->d_prn_ids, n));
@@ -400,6 +401,7 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     HIPA(hipMemcpy(a->d_code_samples, code_samples.data(), P * N, hipMemcpyHostToDevice));
     if ((rc = acq_reserve_results(a, uint32_t(P)))) return fail(rc);
     HIPA(hipMemcpy(a->d_prn_ids, a->prn_ids.data(), P, hipMemcpyHostToDevice));
+    a->dev_prn_ids = a->prn_ids;
     // replica spectra: forward FFT of the resampled code (:136-138)
     pl->code_fft(a->stream, a->d_code_samples, a->d_tw_fwd, a->d_code_fft, int(P));
     HIPA(hipGetLastError());
@@ -450,9 +452,13 @@ int gm_acq_decide_dev(gm_acq* a, const void* d_metrics, uint32_t n_prn, const ui
     if (int rc = ensure_device(a->device)) return rc;
     if (int rc = acq_reserve_results(a, n_prn)) return rc;
     const uint32_t* met = d_metrics ? static_cast<const uint32_t*>(d_metrics) : a->d_metrics;
-    if (prn_ids) HIPC(hipMemcpyAsync(a->d_prn_ids, prn_ids, n_prn, hipMemcpyHostToDevice, a->stream));
-    else if (n_prn == a->P) HIPC(hipMemcpyAsync(a->d_prn_ids, a->prn_ids.data(), n_prn, hipMemcpyHostToDevice, a->stream));
-    else return set_err(GM_ERR_INVALID_ARG, "prn_ids required when n_prn differs from the handle's");
+    const uint8_t* ids = prn_ids ? prn_ids : (n_prn == a->P ? a->prn_ids.data() : nullptr);
+    if (!ids) return set_err(GM_ERR_INVALID_ARG, "prn_ids required when n_prn differs from the handle's");
+    if (a->dev_prn_ids.size() != n_prn || memcmp(a->dev_prn_ids.data(), ids, n_prn) != 0) {   // upload only on change
+        a->dev_prn_ids.assign(ids, ids + n_prn);
+        HIPC(hipMemcpyAsync(a->d_prn_ids, a->dev_prn_ids.data(), n_prn, hipMemcpyHostToDevice, a->stream));
+        HIPC(hipStreamSynchronize(a->stream));
+    }
     const size_t PD = size_t(n_prn) * a->D;
     gm::DecideArgs da;
     da.mmax = reinterpret_cast<const float*>(met);
