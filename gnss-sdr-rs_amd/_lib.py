@@ -113,6 +113,7 @@ SIGNATURES = {
     "gm_trk_update_all_dev": (_i, [_vp, _vp, _u32]),
     "gm_trk_synchronize": (_i, [_vp]),
     "gm_trk_set_stream": (_i, [_vp, _vp]),
+    "gm_trk_debug_stamps": (_i, [_vp, _u32, _vp]),
     "gm_trk_enable_timing": (_i, [_vp, _i]),
     "gm_trk_last_timing": (_i, [_vp, C.POINTER(_f), C.POINTER(_u32)]),
 }

@@ -738,8 +738,15 @@ struct gm_trk {
     uint32_t epochs_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false; uint32_t timed_launches = 0;
+    // persistent multi-epoch kernel: G workgroups per channel, granule exchange buffer, launch counter
+    int G = 1;
+    unsigned long long* d_xchg = nullptr;
+    int* d_error = nullptr;
+    uint32_t launch_seq = 0;
+    long long* d_stamps = nullptr; uint32_t stamps_cap = 0;   // diagnostic phase stamps (gm_trk_debug_stamps)
 };
 
+static int trk_check_error(gm_trk* t);
 static int trk_reserve_epochs(gm_trk* t, uint32_t e) {
     if (e <= t->epochs_cap) return GM_OK;
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
@@ -766,6 +773,7 @@ int gm_trk_destroy(gm_trk* t) {
     if (t->device >= 0) hipSetDevice(t->device);
     hipFree(t->d_codes); hipFree(t->d_states); hipFree(t->d_partials); hipFree(t->d_ready); hipFree(t->d_scratch);
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
+    hipFree(t->d_xchg); hipFree(t->d_error); hipFree(t->d_stamps);
     if (t->ev0) hipEventDestroy(t->ev0);
     if (t->ev1) hipEventDestroy(t->ev1);
     if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
@@ -780,6 +788,12 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
     const uint32_t arms = cfg->n_arms ? cfg->n_arms : 3;
     if (arms != 3 && arms != 5) return set_err(GM_ERR_INVALID_ARG, "n_arms must be 3 or 5");
     if (cfg->codes && (!cfg->n_codes || !cfg->code_len)) return set_err(GM_ERR_INVALID_ARG, "n_codes/code_len required");
+    {   // the kernels replace `% code_len` by one conditional subtraction: arm spacings must stay below a code period
+        const float len = cfg->codes ? float(cfg->code_len) : 1023.0f;
+        if (cfg->early_late_space >= len || cfg->very_early_late_space >= len || cfg->early_late_space < 0 ||
+            cfg->very_early_late_space < 0)
+            return set_err(GM_ERR_INVALID_ARG, "arm spacing must be in [0, code_len)");
+    }
     if (int rc = ensure_device(g_device)) return rc;
     gm_trk* t = new gm_trk();
     t->device = g_device; t->cfg = *cfg; t->C = cfg->n_channels;
@@ -836,6 +850,20 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
     HIPT(hipMemset(t->d_ready, 0, t->C));
     HIPT(hipEventCreate(&t->ev0));
     HIPT(hipEventCreate(&t->ev1));
+    {   // workgroups per channel for the persistent kernel: all n_channels*G must be co-resident (one per CU)
+        hipDeviceProp_t prop;
+        HIPT(hipGetDeviceProperties(&prop, t->device));
+        const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+        const int nv = 2 * d.n_arms;
+        int g = 1;
+        while (g * 2 <= 16 && size_t(g) * 2 * t->C <= size_t(cus) && g * 2 * nv <= 256) g *= 2;
+        t->G = g;
+        const size_t xb = size_t(2) * t->C * g * nv * sizeof(unsigned long long);
+        HIPT(hipMalloc(&t->d_xchg, xb));
+        HIPT(hipMemset(t->d_xchg, 0, xb));
+        HIPT(hipMalloc(&t->d_error, sizeof(int)));
+        HIPT(hipMemset(t->d_error, 0, sizeof(int)));
+    }
     if (int rc = trk_reserve_epochs(t, 1)) return fail(rc);
 #undef HIPT
     *out = t;
@@ -966,13 +994,16 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
     if (t->device != ring->device) return set_err(GM_ERR_INVALID_ARG, "ring lives on another device");
     if (int rc = ensure_device(t->device)) return rc;
     if (int rc = trk_reserve_epochs(t, epochs)) return rc;
-    gm::TrkSrc src;
-    src.base = ring->d_buf; src.mask = ring->mask; src.head = ring->head; src.linear = 0; src.only_channel = -1;
     if (t->timing) HIPC(hipEventRecord(t->ev0, t->stream));
-    for (uint32_t e = 0; e < epochs; ++e) {
-        const size_t o = size_t(e) * t->C;
-        gm::launch_trk_epoch(t->stream, t->dc, t->d_codes, t->d_states, src, t->slices, t->d_partials, t->d_ready,
-                             gm::TRK_MODE_DO_WORK, t->d_outs + o, t->d_proc + o, t->d_lost + o, t->d_lostprn + o);
+    // one persistent launch per <= 4095 epochs (the epoch index lives in the low 12 bits of the granule tag)
+    for (uint32_t e0 = 0; e0 < epochs; e0 += 4095) {
+        const uint32_t ne = epochs - e0 < 4095 ? epochs - e0 : 4095;
+        const size_t o = size_t(e0) * t->C;
+        t->launch_seq = (t->launch_seq + 1) & 0xfffffu;
+        if (t->launch_seq == 0) t->launch_seq = 1;
+        gm::launch_trk_persistent(t->stream, t->dc, t->d_codes, t->d_states, ring->d_buf, ring->mask, ring->head, t->G,
+                                  int(ne), t->launch_seq << 12, t->d_xchg, t->d_outs + o, t->d_proc + o, t->d_lost + o,
+                                  t->d_lostprn + o, t->d_error, (t->d_stamps && e0 == 0 && ne <= t->stamps_cap) ? t->d_stamps : nullptr);
     }
     if (t->timing) { HIPC(hipEventRecord(t->ev1, t->stream)); t->timed_launches = epochs; }
     HIPC(hipGetLastError());
@@ -983,6 +1014,7 @@ int gm_trk_update_all(gm_trk* t, gm_ring* ring, uint32_t max_epochs, gm_trk_out*
                       uint32_t* epochs_done) {
     if (int rc = gm_trk_update_all_dev(t, ring, max_epochs)) return rc;
     HIPC(hipStreamSynchronize(t->stream));
+    if (int rc = trk_check_error(t)) return rc;
     const size_t n = size_t(max_epochs) * t->C;
     std::vector<uint8_t> proc(n);
     HIPC(hipMemcpy(proc.data(), t->d_proc, n, hipMemcpyDeviceToHost));
@@ -1001,10 +1033,36 @@ int gm_trk_update_all(gm_trk* t, gm_ring* ring, uint32_t max_epochs, gm_trk_out*
     return GM_OK;
 }
 
+static int trk_check_error(gm_trk* t) {
+    int err = 0;
+    HIPC(hipMemcpy(&err, t->d_error, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) {
+        HIPC(hipMemset(t->d_error, 0, sizeof(int)));
+        return set_err(GM_ERR_HIP, "tracking: inter-workgroup exchange timed out (workgroups of a channel not co-resident?)");
+    }
+    return GM_OK;
+}
+
 int gm_trk_synchronize(gm_trk* t) {
     if (!t) return set_err(GM_ERR_INVALID_ARG, "null handle");
     if (int rc = ensure_device(t->device)) return rc;
     HIPC(hipStreamSynchronize(t->stream));
+    return trk_check_error(t);
+}
+
+// Diagnostic: s_memtime stamps of workgroup 0 at 8 phase boundaries of each epoch of the next launches
+// (epochs <= cap).  out = [cap][8] after gm_trk_synchronize.  Not part of the reference API.
+int gm_trk_debug_stamps(gm_trk* t, uint32_t cap, long long* out) {
+    if (!t) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(t->device)) return rc;
+    if (!out) {   // arm
+        hipFree(t->d_stamps); t->d_stamps = nullptr; t->stamps_cap = 0;
+        if (cap) { HIPC(hipMalloc(&t->d_stamps, size_t(cap) * 8 * sizeof(long long))); HIPC(hipMemset(t->d_stamps, 0, size_t(cap) * 64)); t->stamps_cap = cap; }
+        return GM_OK;
+    }
+    if (!t->d_stamps || cap > t->stamps_cap) return set_err(GM_ERR_INVALID_ARG, "stamps not armed");
+    HIPC(hipStreamSynchronize(t->stream));
+    HIPC(hipMemcpy(out, t->d_stamps, size_t(cap) * 64, hipMemcpyDeviceToHost));
     return GM_OK;
 }
 

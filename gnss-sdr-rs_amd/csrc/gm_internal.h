@@ -74,4 +74,10 @@ void launch_trk_epoch(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_t
                       const TrkSrc&, int slices, float* d_partials, uint8_t* d_ready, int mode,
                       gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost, uint8_t* d_lost_prn);
 
+// persistent multi-epoch tracking (one launch = `epochs` passes over all channels); G workgroups per channel
+void launch_trk_persistent(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_trk_state* d_states,
+                           const cf* ring, uint64_t mask, uint64_t head, int G, int epochs, uint32_t tag_base,
+                           unsigned long long* d_xchg, gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost,
+                           uint8_t* d_lost_prn, int* d_error, long long* d_stamps);
+
 }  // namespace gm

@@ -28,56 +28,137 @@ namespace gm {
 
 #define GM_PI_F 3.14159265358979323846f
 
-// sin/cos of an f32 argument, evaluated in f64, rounded once to f32
+// sin/cos of an f32 argument up to ~1e5 rad in magnitude: the f32 value is reduced EXACTLY in f64
+// (r = x - k*pi/2 with a two-term pi/2, |r| <= pi/4, error < 1e-11), then evaluated with f32 minimax
+// polynomials (Cephes sinf/cosf cores, < 1 ulp).  glibc's cosf/sinf, which the reference calls, are
+// likewise < 1 ulp; the two agree to the last bit for almost every sample and to 1 ulp otherwise.
 __device__ __forceinline__ void sincos_f32_via_f64(float x, float& s, float& c) {
     const double xd = double(x);
     const double kd = __builtin_rint(xd * 0.63661977236758134308);   // 2/pi
-    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
-    double r = __builtin_fma(-kd, PIO2_HI, xd);
-    r = __builtin_fma(-kd, PIO2_LO, r);
-    const double r2 = r * r;
-    // minimax-quality Taylor cores on |r| <= pi/4 (truncation < 1e-13)
-    double sp = -7.6471637318198164759e-13;                  // -1/15!
-    sp = __builtin_fma(sp, r2, 1.6059043836821614599e-10);   //  1/13!
-    sp = __builtin_fma(sp, r2, -2.5052108385441718775e-08);  // -1/11!
-    sp = __builtin_fma(sp, r2, 2.7557319223985890653e-06);   //  1/9!
-    sp = __builtin_fma(sp, r2, -1.9841269841269841270e-04);  // -1/7!
-    sp = __builtin_fma(sp, r2, 8.3333333333333333333e-03);   //  1/5!
-    sp = __builtin_fma(sp, r2, -1.6666666666666666667e-01);  // -1/3!
-    const double sr = __builtin_fma(sp * r2, r, r);
-    double cp = 4.7794773323873852974e-14;                   //  1/16!
-    cp = __builtin_fma(cp, r2, -1.1470745597729724714e-11);  // -1/14!
-    cp = __builtin_fma(cp, r2, 2.0876756987868098979e-09);   //  1/12!
-    cp = __builtin_fma(cp, r2, -2.7557319223985890653e-07);  // -1/10!
-    cp = __builtin_fma(cp, r2, 2.4801587301587301587e-05);   //  1/8!
-    cp = __builtin_fma(cp, r2, -1.3888888888888888889e-03);  // -1/6!
-    cp = __builtin_fma(cp, r2, 4.1666666666666666667e-02);   //  1/4!
-    cp = __builtin_fma(cp, r2, -0.5);
-    const double cr = __builtin_fma(cp, r2, 1.0);
-    const int q = int(static_cast<long long>(kd)) & 3;
-    const double sv = (q & 1) ? cr : sr, cv = (q & 1) ? sr : cr;
-    s = float((q & 2) ? -sv : sv);
-    c = float(((q + 1) & 2) ? -cv : cv);
+    double r = __builtin_fma(-kd, 1.57079632679489655800e+00, xd);
+    r = __builtin_fma(-kd, 6.12323399573676603587e-17, r);
+    const float rf = float(r);
+    const float z = rf * rf;
+    float sp = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    sp = __builtin_fmaf(sp, z, -1.6666654611e-1f);
+    const float sr = __builtin_fmaf(sp * z, rf, rf);
+    float cp = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);
+    const float cr = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    const int q = int(kd) & 3;   // |kd| < 2^31 for |x| < 3e9
+    const float sv = (q & 1) ? cr : sr, cv = (q & 1) ? sr : cr;
+    s = (q & 2) ? -sv : sv;
+    c = ((q + 1) & 2) ? -cv : cv;
 }
 
-// Rust `%` on f32 == fmodf; exact fast paths for the operating range [0, 2*len)
-__device__ __forceinline__ float fmod_pos(float t, float len) {
-    if (t >= 0.0f && t < len) return t;
-    if (t >= len && t < 2.0f * len) return t - len;      // exact (Sterbenz)
-    return fmodf(t, len);
+
+// (code_phase + i*step) % len.  FAST: the caller has checked once per epoch that code_phase lies in
+// (-len, len) and i*step in [0, 2*len), so t lies in (-len, 3*len) and each branch below is exact
+// (Sterbenz) and equals fmodf(t, len): sign of the dividend, magnitude < len.  !FAST: plain fmodf.
+template <bool FAST> __device__ __forceinline__ float fmod_code(float t, float len) {
+    if constexpr (FAST) return t < len ? t : (t < 2.0f * len ? t - len : t - 2.0f * len);
+    else return fmodf(t, len);
 }
 
 // get_ca_chip's index (:275): `(phase.floor() as usize) % 1023` — the cast saturates, so a negative
 // phase (late arm just after the code wraps) reads chip 0 in FAITHFUL mode; FIXED mode wraps.
+// phase = chip_idx +- spacing with |chip_idx| < len and spacing < len (checked at gm_trk_create), so
+// one conditional subtraction replaces the modulo.
 __device__ __forceinline__ int chip_index(float phase, int len, int mode) {
     const float f = floorf(phase);
     if (mode == GM_CODE_INDEX_FAITHFUL) {
         if (!(f > 0.0f)) return 0;
-        if (f >= 2147483648.0f) return int((unsigned long long)f % (unsigned long long)len);
-        return int(f) % len;
+        const int i = int(f);
+        return i >= len ? i - len : i;
     }
-    int i = int(f) % len;
-    return i < 0 ? i + len : i;
+    int i = int(f);
+    if (i < 0) i += len;
+    if (i < 0) i += len;
+    return i >= len ? i - len : i;
+}
+
+// LoopFilter::update (:68-70)
+__device__ __forceinline__ float loop_filter_update(float tau1, float tau2, float d_err, float err, float dt) {
+    return d_err * __fdiv_rn(dt, tau1) + (d_err - err) * __fdiv_rn(tau2, tau1);
+}
+
+// generate_ca_code_samples(..).len() = round(fs / (code_rate / len))  (ca_code.rs:13-16)
+__device__ __forceinline__ uint64_t samples_per_code(float fs, float code_rate, float lenf) {
+    const float v = roundf(__fdiv_rn(fs, __fdiv_rn(code_rate, lenf)));
+    return v > 0.0f ? uint64_t(v) : 0;
+}
+
+// TrackingChannel::reset (:311-327)
+__device__ __forceinline__ void reset_state(gm_trk_state& s) {
+    s.prn = 0; s.active = 0; s.lost_counter = 0; s.next_sample_index = 0;
+    s.carrier_freq = 0.f; s.carrier_phase = 0.f; s.carrier_error = 0.f; s.carrier_nco = 0.f;
+    s.code_phase = 0.f; s.code_error = 0.f; s.code_nco = 0.f; s.code_rate = 0.f;
+    s.i_prompt = 0.f; s.q_prompt = 0.f;
+}
+
+// per-epoch constants of one channel, derived from its state exactly once per epoch
+struct EpochConsts {
+    float carrier_phase, two_pi_f, code_phase, step, fs, lenf, el, vel;
+    int len, mode, boc11;
+};
+__device__ __forceinline__ EpochConsts epoch_consts(const TrkDevCfg& cfg, const gm_trk_state& st) {
+    EpochConsts c;
+    c.carrier_phase = st.carrier_phase;
+    c.two_pi_f = 2.0f * GM_PI_F * st.carrier_freq;      // (2.0*PI)*carrier_freq
+    c.code_phase = st.code_phase;
+    c.step = __fdiv_rn(st.code_rate, cfg.fs);           // self.code_rate / self.fs
+    c.fs = cfg.fs; c.lenf = cfg.code_len_f; c.len = cfg.code_len; c.mode = cfg.code_index_mode;
+    c.boc11 = cfg.boc11; c.el = cfg.el_space; c.vel = cfg.vel_space;
+    return c;
+}
+
+// once per epoch: may the exact fast path of fmod_code be used for samples 0..n-1 ?
+__device__ __forceinline__ bool fast_code_range(const EpochConsts& c, uint64_t n) {
+    return c.code_phase > -c.lenf && c.code_phase < c.lenf && c.step >= 0.0f && float(n) * c.step < 1.99f * c.lenf;
+}
+
+// one sample: carrier wipe-off fused with the replica multiplies (early_late_correlation :231-263)
+template <int ARMS, bool FAST>
+__device__ __forceinline__ void correlate_sample(const EpochConsts& c, const int8_t* chips, cf d, uint32_t i,
+                                                 float (&acc)[2 * ARMS]) {
+    const float fi = float(i);
+    const float phase = c.carrier_phase + __fdiv_rn(c.two_pi_f * fi, c.fs);
+    float sn, cs;
+    sincos_f32_via_f64(phase, sn, cs);
+    const float wc = cs, ws = -sn;                          // Complex32::new(cos_p, -sin)
+    const float xr = d.x * wc - d.y * ws;                   // num-complex Mul
+    const float xi = d.x * ws + d.y * wc;
+    const float chip_idx = fmod_code<FAST>(c.code_phase + fi * c.step, c.lenf);
+    float pc = float(chips[chip_index(chip_idx, c.len, c.mode)]);
+    float ec = float(chips[chip_index(chip_idx + c.el, c.len, c.mode)]);
+    float lc = float(chips[chip_index(chip_idx - c.el, c.len, c.mode)]);
+    if (c.boc11) {   // BOC(1,1): sub-carrier sign = +1 on the first half chip, -1 on the second
+        const float a = chip_idx, b = chip_idx + c.el, e = chip_idx - c.el;
+        pc = (a - floorf(a)) < 0.5f ? pc : -pc;
+        ec = (b - floorf(b)) < 0.5f ? ec : -ec;
+        lc = (e - floorf(e)) < 0.5f ? lc : -lc;
+    }
+    // chips are exactly +-1 (x BOC sign): the product is exact, so fma(x, chip, acc) == acc + x*chip bitwise
+    acc[0] = __builtin_fmaf(xr, pc, acc[0]); acc[1] = __builtin_fmaf(xi, pc, acc[1]);
+    acc[2] = __builtin_fmaf(xr, ec, acc[2]); acc[3] = __builtin_fmaf(xi, ec, acc[3]);
+    acc[4] = __builtin_fmaf(xr, lc, acc[4]); acc[5] = __builtin_fmaf(xi, lc, acc[5]);
+    if constexpr (ARMS == 5) {
+        const float ve = chip_idx + c.vel, vl = chip_idx - c.vel;
+        float vec = float(chips[chip_index(ve, c.len, c.mode)]);
+        float vlc = float(chips[chip_index(vl, c.len, c.mode)]);
+        if (c.boc11) {
+            vec = (ve - floorf(ve)) < 0.5f ? vec : -vec;
+            vlc = (vl - floorf(vl)) < 0.5f ? vlc : -vlc;
+        }
+        acc[6] = __builtin_fmaf(xr, vec, acc[6]); acc[7] = __builtin_fmaf(xi, vec, acc[7]);
+        acc[8] = __builtin_fmaf(xr, vlc, acc[8]); acc[9] = __builtin_fmaf(xi, vlc, acc[9]);
+    }
+}
+
+__device__ __forceinline__ int code_row(const TrkDevCfg& cfg, const gm_trk_state& st) {
+    // FAITHFUL indexes GPS_CA_CODE_32_PRN[prn] (:276), FIXED [prn-1]
+    return cfg.gps_ca ? (cfg.code_index_mode == GM_CODE_INDEX_FAITHFUL ? int(st.prn) : int(st.prn) - 1)
+                      : int(st.prn) - 1;
 }
 
 template <int ARMS>
@@ -94,13 +175,8 @@ __global__ __launch_bounds__(256) void trk_correlate_kernel(TrkDevCfg cfg, const
     // update(): n = generate_ca_code_samples(..).len() = round(fs/(code_rate/len)) (:165-166,
     // ca_code.rs:13-16); early_late_correlation()/do_work() on caller samples use the field (:232)
     uint64_t n = st.num_samples_per_code;
-    if (!src.linear) {
-        const float nf = roundf(__fdiv_rn(cfg.fs, __fdiv_rn(st.code_rate, cfg.code_len_f)));
-        n = nf > 0.0f ? uint64_t(nf) : 0;
-    }
-    // row of the code table: FAITHFUL indexes GPS_CA_CODE_32_PRN[prn] (:276), FIXED [prn-1]
-    int row = cfg.gps_ca ? (cfg.code_index_mode == GM_CODE_INDEX_FAITHFUL ? int(st.prn) : int(st.prn) - 1)
-                         : int(st.prn) - 1;
+    if (!src.linear) n = samples_per_code(cfg.fs, st.code_rate, cfg.code_len_f);
+    const int row = code_row(cfg, st);
     bool run = st.active && n > 0 && n < (1ull << 31) && row >= 0 && row < cfg.n_codes;
     if (run && !src.linear)   // (head - (next + n)) as isize >= 0  (:170-172)
         run = (int64_t)(src.head - (st.next_sample_index + n)) >= 0;
@@ -115,12 +191,7 @@ __global__ __launch_bounds__(256) void trk_correlate_kernel(TrkDevCfg cfg, const
     for (int i = tid; i < cfg.code_len; i += 256) chips[i] = crow[i];
     __syncthreads();
 
-    const float two_pi_f = 2.0f * GM_PI_F * st.carrier_freq;   // (2.0*PI)*carrier_freq
-    const float step = __fdiv_rn(st.code_rate, cfg.fs);        // self.code_rate / self.fs
-    const int len = cfg.code_len;
-    const float lenf = cfg.code_len_f;
-    const int mode = cfg.code_index_mode;
-
+    const EpochConsts ec = epoch_consts(cfg, st);
     // slice bounds: whole multiples of 256 samples so lanes stay coalesced
     const uint32_t per = uint32_t(((n + slices - 1) / slices + 255) / 256 * 256);
     const uint32_t i0 = uint32_t(slice) * per;
@@ -129,42 +200,15 @@ __global__ __launch_bounds__(256) void trk_correlate_kernel(TrkDevCfg cfg, const
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.0f;
-
     const uint64_t base = src.linear ? 0 : st.next_sample_index;
-    for (uint32_t i = i0 + tid; i < i1; i += 256) {
-        const cf d = src.base[(base + i) & src.mask];
-        const float fi = float(i);
-        const float phase = st.carrier_phase + __fdiv_rn(two_pi_f * fi, cfg.fs);
-        float sn, cs;
-        sincos_f32_via_f64(phase, sn, cs);
-        const float wc = cs, ws = -sn;                          // Complex32::new(cos_p, -sin)
-        const float xr = d.x * wc - d.y * ws;                   // num-complex Mul
-        const float xi = d.x * ws + d.y * wc;
-        const float chip_idx = fmod_pos(st.code_phase + fi * step, lenf);
-        float pc = float(chips[chip_index(chip_idx, len, mode)]);
-        float ec = float(chips[chip_index(chip_idx + cfg.el_space, len, mode)]);
-        float lc = float(chips[chip_index(chip_idx - cfg.el_space, len, mode)]);
-        if (cfg.boc11) {   // BOC(1,1): sub-carrier sign = +1 on the first half chip, -1 on the second
-            const float a = chip_idx, b = chip_idx + cfg.el_space, c = chip_idx - cfg.el_space;
-            pc = (a - floorf(a)) < 0.5f ? pc : -pc;
-            ec = (b - floorf(b)) < 0.5f ? ec : -ec;
-            lc = (c - floorf(c)) < 0.5f ? lc : -lc;
-        }
-        acc[0] += xr * pc; acc[1] += xi * pc;
-        acc[2] += xr * ec; acc[3] += xi * ec;
-        acc[4] += xr * lc; acc[5] += xi * lc;
-        if constexpr (ARMS == 5) {
-            const float ve = chip_idx + cfg.vel_space, vl = chip_idx - cfg.vel_space;
-            float vec = float(chips[chip_index(ve, len, mode)]);
-            float vlc = float(chips[chip_index(vl, len, mode)]);
-            if (cfg.boc11) {
-                vec = (ve - floorf(ve)) < 0.5f ? vec : -vec;
-                vlc = (vl - floorf(vl)) < 0.5f ? vlc : -vlc;
-            }
-            acc[6] += xr * vec; acc[7] += xi * vec;
-            acc[8] += xr * vlc; acc[9] += xi * vlc;
-        }
+    if (fast_code_range(ec, n)) {
+        for (uint32_t i = i0 + tid; i < i1; i += 256)
+            correlate_sample<ARMS, true>(ec, chips, src.base[(base + i) & src.mask], i, acc);
+    } else {
+        for (uint32_t i = i0 + tid; i < i1; i += 256)
+            correlate_sample<ARMS, false>(ec, chips, src.base[(base + i) & src.mask], i, acc);
     }
+
     // per-lane partial sums -> wavefront butterfly (64 lanes) -> 4 waves through LDS
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -182,22 +226,56 @@ __global__ __launch_bounds__(256) void trk_correlate_kernel(TrkDevCfg cfg, const
     if (slice == 0 && tid == 0) ready[ch] = 1;
 }
 
-// LoopFilter::update (:68-70)
-__device__ __forceinline__ float loop_filter_update(float tau1, float tau2, float d_err, float err, float dt) {
-    return d_err * __fdiv_rn(dt, tau1) + (d_err - err) * __fdiv_rn(tau2, tau1);
+// The reference's scalar epilogue of one epoch: early_late_correlation's phase advances (:240-242,
+// :265-270) and, in DO_WORK mode, do_work + run_loop_filters (:183-210, :279-302).
+// v = the 2*ARMS correlator sums; n = samples of this epoch.
+template <int ARMS>
+__device__ __forceinline__ void epoch_epilogue(const TrkDevCfg& cfg, gm_trk_state& s, const float (&v)[2 * ARMS],
+                                               uint64_t n, int mode, uint8_t& lst, uint8_t& lprn) {
+    const float nf = float(n);
+    // carrier_phase = (carrier_phase + 2*PI*carrier_freq*(n as f32 / fs)) % (2*PI)      (:240-242)
+    s.carrier_phase = fmodf(s.carrier_phase + 2.0f * GM_PI_F * s.carrier_freq * __fdiv_rn(nf, cfg.fs),
+                            2.0f * GM_PI_F);
+    // code_phase = (code_phase + (code_rate/fs) * n as f32) % 1023.0                     (:265-267)
+    s.code_phase = fmodf(s.code_phase + __fdiv_rn(s.code_rate, cfg.fs) * nf, cfg.code_len_f);
+    s.i_prompt = v[0]; s.q_prompt = v[1];
+    lst = 0; lprn = 0;
+    if (mode != TRK_MODE_DO_WORK) return;
+    const float power = v[0] * v[0] + v[1] * v[1];       // do_work (:183-210)
+    bool advance = true;
+    if (power > cfg.lock_threshold) {
+        s.lost_counter = 0;
+        // run_loop_filters (:279-302)
+        const float pll_err = __fdiv_rn(atanf(__fdiv_rn(v[1], v[0])), 2.0f * GM_PI_F);
+        s.carrier_nco = loop_filter_update(cfg.pll_tau1, cfg.pll_tau2, pll_err, s.carrier_error, cfg.pll_dt);
+        s.carrier_error = pll_err;
+        s.carrier_freq += s.carrier_nco;
+        const float pow_e = __fsqrt_rn(v[2] * v[2] + v[3] * v[3]);
+        const float pow_l = __fsqrt_rn(v[4] * v[4] + v[5] * v[5]);
+        const float dll_err = ((pow_e + pow_l) != 0.0f) ? __fdiv_rn(pow_e - pow_l, pow_e + pow_l) : 0.0f;
+        s.code_nco = loop_filter_update(cfg.dll_tau1, cfg.dll_tau2, dll_err, s.code_error, cfg.dll_dt);
+        s.code_error = dll_err;
+        s.code_rate += s.code_nco;
+    } else {
+        s.lost_counter += 1;
+        if (s.lost_counter >= cfg.max_lost_epochs) {
+            reset_state(s);                          // reset() first ...
+            lst = 1; lprn = s.prn;                   // ... so the message carries prn 0 (:199-201)
+            advance = false;
+        }
+    }
+    if (advance) {
+        s.next_sample_index += n;                    // (:192 / :203)
+        s.num_samples_per_code = samples_per_code(cfg.fs, s.code_rate, cfg.code_len_f);
+    }
 }
 
-__device__ __forceinline__ uint64_t samples_per_code(float fs, float code_rate, float lenf) {
-    const float v = roundf(__fdiv_rn(fs, __fdiv_rn(code_rate, lenf)));
-    return v > 0.0f ? uint64_t(v) : 0;
-}
-
-// TrackingChannel::reset (:311-327)
-__device__ __forceinline__ void reset_state(gm_trk_state& s) {
-    s.prn = 0; s.active = 0; s.lost_counter = 0; s.next_sample_index = 0;
-    s.carrier_freq = 0.f; s.carrier_phase = 0.f; s.carrier_error = 0.f; s.carrier_nco = 0.f;
-    s.code_phase = 0.f; s.code_error = 0.f; s.code_nco = 0.f; s.code_rate = 0.f;
-    s.i_prompt = 0.f; s.q_prompt = 0.f;
+template <int ARMS> __device__ __forceinline__ gm_trk_out make_out(const float (&v)[2 * ARMS]) {
+    gm_trk_out o;
+    o.ip = v[0]; o.qp = v[1]; o.ie = v[2]; o.qe = v[3]; o.il = v[4]; o.ql = v[5];
+    o.ive = o.qve = o.ivl = o.qvl = 0.0f;
+    if constexpr (ARMS == 5) { o.ive = v[6]; o.qve = v[7]; o.ivl = v[8]; o.qvl = v[9]; }
+    return o;
 }
 
 template <int ARMS>
@@ -209,65 +287,252 @@ __global__ void trk_update_kernel(TrkDevCfg cfg, gm_trk_state* __restrict__ stat
     int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (only_channel >= 0) { if (ch != 0) return; ch = only_channel; }
     if (ch >= cfg.n_channels) return;
-    gm_trk_out o;
-    o.ip = o.qp = o.ie = o.qe = o.il = o.ql = o.ive = o.qve = o.ivl = o.qvl = 0.0f;
+    float v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = 0.0f;
     uint8_t did = 0, lst = 0, lprn = 0;
     if (ready[ch]) {
         gm_trk_state s = states[ch];
-        float v[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = 0.0f;
         const float* p = partials + size_t(ch) * slices * NV;
         for (int sl = 0; sl < slices; ++sl)
 #pragma unroll
             for (int k = 0; k < NV; ++k) v[k] += p[sl * NV + k];
         uint64_t n = s.num_samples_per_code;
         if (!linear) { n = samples_per_code(cfg.fs, s.code_rate, cfg.code_len_f); s.num_samples_per_code = n; }  // (:166)
-        const float nf = float(n);
-        // carrier_phase = (carrier_phase + 2*PI*carrier_freq*(n as f32 / fs)) % (2*PI)      (:240-242)
-        s.carrier_phase = fmodf(s.carrier_phase + 2.0f * GM_PI_F * s.carrier_freq * __fdiv_rn(nf, cfg.fs),
-                                2.0f * GM_PI_F);
-        // code_phase = (code_phase + (code_rate/fs) * n as f32) % 1023.0                     (:265-267)
-        s.code_phase = fmodf(s.code_phase + __fdiv_rn(s.code_rate, cfg.fs) * nf, cfg.code_len_f);
-        s.i_prompt = v[0]; s.q_prompt = v[1];
-        o.ip = v[0]; o.qp = v[1]; o.ie = v[2]; o.qe = v[3]; o.il = v[4]; o.ql = v[5];
-        if constexpr (ARMS == 5) { o.ive = v[6]; o.qve = v[7]; o.ivl = v[8]; o.qvl = v[9]; }
+        epoch_epilogue<ARMS>(cfg, s, v, n, mode, lst, lprn);
         did = 1;
-        if (mode == TRK_MODE_DO_WORK) {                      // do_work (:183-210)
-            const float power = v[0] * v[0] + v[1] * v[1];
-            bool advance = true;
-            if (power > cfg.lock_threshold) {
-                s.lost_counter = 0;
-                // run_loop_filters (:279-302)
-                const float pll_err = __fdiv_rn(atanf(__fdiv_rn(v[1], v[0])), 2.0f * GM_PI_F);
-                s.carrier_nco = loop_filter_update(cfg.pll_tau1, cfg.pll_tau2, pll_err, s.carrier_error, cfg.pll_dt);
-                s.carrier_error = pll_err;
-                s.carrier_freq += s.carrier_nco;
-                const float pow_e = __fsqrt_rn(v[2] * v[2] + v[3] * v[3]);
-                const float pow_l = __fsqrt_rn(v[4] * v[4] + v[5] * v[5]);
-                const float dll_err = ((pow_e + pow_l) != 0.0f) ? __fdiv_rn(pow_e - pow_l, pow_e + pow_l) : 0.0f;
-                s.code_nco = loop_filter_update(cfg.dll_tau1, cfg.dll_tau2, dll_err, s.code_error, cfg.dll_dt);
-                s.code_error = dll_err;
-                s.code_rate += s.code_nco;
-            } else {
-                s.lost_counter += 1;
-                if (s.lost_counter >= cfg.max_lost_epochs) {
-                    reset_state(s);                          // reset() first ...
-                    lst = 1; lprn = s.prn;                   // ... so the message carries prn 0 (:199-201)
-                    advance = false;
-                }
-            }
-            if (advance) {
-                s.next_sample_index += n;                    // (:192 / :203)
-                s.num_samples_per_code = samples_per_code(cfg.fs, s.code_rate, cfg.code_len_f);
-            }
-        }
         states[ch] = s;
     }
-    if (outs) outs[ch] = o;
+    if (outs) outs[ch] = make_out<ARMS>(v);
     if (processed) processed[ch] = did;
     if (lost) lost[ch] = lst;
     if (lost_prn) lost_prn[ch] = lprn;
+}
+
+// ------------------------------------------------------------------------------------ persistent tracking
+// One launch runs `epochs` consecutive passes of process_channels (do_tracking.rs:364-371, 408-413).
+// Grid: n_channels * G workgroups of 1024 lanes, all co-resident (<= one per CU).  The G workgroups of a
+// channel each correlate one slice of every code period; per epoch they exchange their partial sums
+// through self-validating 8-byte {value, tag} granules in HBM (one sc1 store / sc1 load each, no fences:
+// MI355X_MICROARCH.md "Valid forms", R2), every workgroup adds the G partials in the same order and runs
+// the scalar epilogue redundantly, so all of them hold bit-identical channel state without a broadcast.
+// The epoch-to-epoch dependence (carrier_freq/phase, code_rate/phase, next_sample_index) never leaves the chip.
+struct TrkPersistArgs {
+    TrkDevCfg cfg;
+    const int8_t* codes;
+    gm_trk_state* states;
+    const cf* ring; uint64_t mask, head;
+    int G, epochs;
+    uint32_t per;                    // samples per workgroup slice (multiple of 64), fixed for the launch
+    uint32_t tag_base;               // unique per launch: tag = tag_base + epoch + 1
+    unsigned long long* xchg;        // [2][n_channels][G][NV] granules
+    gm_trk_out* outs; uint8_t *processed, *lost, *lost_prn;   // [epochs][n_channels] (may be null)
+    int* error_flag;                 // set to 1 if an exchange wait timed out
+    long long* stamps;               // diagnostic only (may be null): [epochs][8] s_memtime stamps of workgroup 0
+};
+
+// diagnostic stamp (gm_trk_debug_stamps): one asm statement so the wait stays with the read, fenced against
+// the scheduler on both sides (cdna_hip_programming.md §7 "In-kernel stamps")
+__device__ __forceinline__ long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return (long long)t;
+}
+
+// workgroup barrier that orders LDS traffic only: pending global loads (the sample prefetch) stay in flight
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int ARMS>
+__global__ __launch_bounds__(1024) void trk_persistent_kernel(TrkPersistArgs a) {
+    constexpr int NV = 2 * ARMS, T = 1024, NW = T / 64, KPF = 4;
+    const TrkDevCfg& cfg = a.cfg;
+    const int ch = blockIdx.x / a.G, g = blockIdx.x % a.G, tid = threadIdx.x;
+    const int C = cfg.n_channels;
+    const int wave = tid >> 6, lane = tid & 63;
+    __shared__ float wsum[NW][NV];
+    __shared__ gm_trk_state s_next;     // wave 0 -> everyone, once per epoch
+    __shared__ int ctl;                 // 0 continue, 1 exchange timed out
+    __shared__ float gathered[256];     // the G*NV partials of one epoch (wave 0 only)
+    extern __shared__ int8_t chips[];   // the channel's chip row
+
+    gm_trk_state s = a.states[ch];
+    const int row = code_row(cfg, s);
+    const bool leader = (g == 0 && tid == 0);
+    int e = 0;
+    bool timed_out = false;
+    if (s.active && row >= 0 && row < cfg.n_codes) {
+        const int8_t* crow = a.codes + size_t(row) * cfg.code_len;
+        for (int i = tid; i < cfg.code_len; i += T) chips[i] = crow[i];
+        if (tid == 0) ctl = 0;
+        __syncthreads();
+        // slice geometry, fixed for the launch: `per` samples per workgroup (multiple of 64 lanes); the last
+        // workgroup also takes whatever a longer code period adds beyond G*per
+        const uint32_t per = a.per;
+        const uint32_t i0 = uint32_t(g) * per;
+        // software prefetch: the first KPF strided samples of the NEXT epoch are requested while this
+        // epoch's partial sums travel between workgroups (its window start is known: next + n)
+        cf pf[KPF];
+#pragma unroll
+        for (int j = 0; j < KPF; ++j) pf[j] = a.ring[(s.next_sample_index + i0 + tid + j * T) & a.mask];
+
+        for (; e < a.epochs; ++e) {
+            const uint64_t n = samples_per_code(cfg.fs, s.code_rate, cfg.code_len_f);     // update() :165-166
+            bool run = s.active && n > 0 && n < (1ull << 31);
+            if (run) run = (int64_t)(a.head - (s.next_sample_index + n)) >= 0;            // :170-172
+            if (!run) break;                       // state is identical in the G workgroups: they all leave
+            s.num_samples_per_code = n;
+            const bool st_on = a.stamps && blockIdx.x == 0 && tid == 0;
+            long long* stp = a.stamps + size_t(e) * 8;
+            if (st_on) stp[0] = stamp_now();
+            const EpochConsts ec = epoch_consts(cfg, s);
+            const uint32_t i1 = (g == a.G - 1 || uint64_t(i0) + per > n) ? uint32_t(n) : i0 + per;
+            float acc[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[k] = 0.0f;
+            if (fast_code_range(ec, n)) {
+#pragma unroll
+                for (int j = 0; j < KPF; ++j) {
+                    const uint32_t i = i0 + tid + j * T;
+                    if (i < i1) correlate_sample<ARMS, true>(ec, chips, pf[j], i, acc);
+                }
+                for (uint32_t i = i0 + tid + KPF * T; i < i1; i += T)
+                    correlate_sample<ARMS, true>(ec, chips, a.ring[(s.next_sample_index + i) & a.mask], i, acc);
+            } else {   // out-of-family state (e.g. set by the caller): general fmodf, no prefetch use
+                for (uint32_t i = i0 + tid; i < i1; i += T)
+                    correlate_sample<ARMS, false>(ec, chips, a.ring[(s.next_sample_index + i) & a.mask], i, acc);
+            }
+            if (st_on) stp[1] = stamp_now();
+            {   // request the next epoch's samples now; they land during the exchange below
+                const uint64_t nb = s.next_sample_index + n;
+#pragma unroll
+                for (int j = 0; j < KPF; ++j) pf[j] = a.ring[(nb + i0 + tid + j * T) & a.mask];
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) wsum[wave][k] = acc[k];
+            }
+            lds_barrier();    // NOT __syncthreads(): its fence would wait for the prefetch loads (vmcnt(0))
+            if (st_on) stp[2] = stamp_now();
+            if (wave == 0) {
+                // this workgroup's partial (waves added in a fixed order), published as {value, tag} granules
+                const uint32_t tag = a.tag_base + uint32_t(e) + 1u;
+                unsigned long long* slot = a.xchg + (size_t(e & 1) * C + ch) * a.G * NV;
+                if (lane < NV) {
+                    float p = wsum[0][lane];
+                    for (int w = 1; w < NW; ++w) p += wsum[w][lane];
+                    const unsigned long long gran =
+                        (unsigned long long)__float_as_uint(p) | ((unsigned long long)tag << 32);
+                    __hip_atomic_store(&slot[g * NV + lane], gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (st_on) stp[3] = stamp_now();
+                // gather the G partials: lane l polls granules l, l+64, ... (G*NV <= 256)
+                const int ng = a.G * NV;
+                float val[4] = {0.f, 0.f, 0.f, 0.f};
+                const long long t0 = wall_clock64();
+                bool to = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = lane + q * 64;
+                    if (idx < ng) {
+                        unsigned long long gr;
+                        for (;;) {
+                            gr = __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (uint32_t(gr >> 32) == tag) break;
+                            if (wall_clock64() - t0 > 20000000ll) { to = true; break; }   // 0.2 s at 100 MHz
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        val[q] = __uint_as_float(uint32_t(gr));
+                    }
+                }
+                to = __any(to);
+                if (st_on) stp[4] = stamp_now();
+                // totals: the polled values are staged in LDS (this wave only: DS operations of one wave complete in
+                // order), lane k adds the G partials of arm k in workgroup order, and the NV totals are broadcast
+                // as scalars, so every lane (and every workgroup of the channel) holds the same v[]
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = lane + q * 64;
+                    if (idx < ng) gathered[idx] = val[q];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float tk = 0.0f;
+                if (lane < NV)
+                    for (int gg = 0; gg < a.G; ++gg) tk += gathered[gg * NV + lane];
+                float v[NV];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tk), k));
+                if (st_on) stp[5] = stamp_now();
+                gm_trk_state sn = s;
+                uint8_t lst = 0, lprn = 0;
+                if (!to) epoch_epilogue<ARMS>(cfg, sn, v, n, TRK_MODE_DO_WORK, lst, lprn);
+                if (st_on) stp[6] = stamp_now();
+                if (lane == 0) {
+                    s_next = sn;
+                    ctl = to ? 1 : 0;
+                    if (g == 0 && !to) {
+                        const size_t o = size_t(e) * C + ch;
+                        if (a.outs) a.outs[o] = make_out<ARMS>(v);
+                        if (a.processed) a.processed[o] = 1;
+                        if (a.lost) a.lost[o] = lst;
+                        if (a.lost_prn) a.lost_prn[o] = lprn;
+                    }
+                }
+            }
+            lds_barrier();
+            if (ctl) { timed_out = true; break; }
+            // no third barrier: wsum is rewritten only after every wave has passed the NEXT epoch's compute, and
+            // s_next only after the next epoch's first barrier, which no wave reaches before reading it here
+            s = s_next;
+            if (st_on) stp[7] = stamp_now();
+        }
+        if (tid == 0 && timed_out) *a.error_flag = 1;
+    }
+    if (leader) {
+        a.states[ch] = s;
+        gm_trk_out z;
+        z.ip = z.qp = z.ie = z.qe = z.il = z.ql = z.ive = z.qve = z.ivl = z.qvl = 0.0f;
+        for (int r = e; r < a.epochs; ++r) {   // passes in which this channel did not run
+            const size_t o = size_t(r) * C + ch;
+            if (a.outs) a.outs[o] = z;
+            if (a.processed) a.processed[o] = 0;
+            if (a.lost) a.lost[o] = 0;
+            if (a.lost_prn) a.lost_prn[o] = 0;
+        }
+    }
+}
+
+void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_codes, gm_trk_state* d_states,
+                           const cf* ring, uint64_t mask, uint64_t head, int G, int epochs, uint32_t tag_base,
+                           unsigned long long* d_xchg, gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost,
+                           uint8_t* d_lost_prn, int* d_error, long long* d_stamps) {
+    TrkPersistArgs a;
+    a.stamps = d_stamps;
+    a.cfg = cfg; a.codes = d_codes; a.states = d_states; a.ring = ring; a.mask = mask; a.head = head;
+    a.G = G; a.epochs = epochs; a.tag_base = tag_base;
+    {   // slice length from the nominal code period (+1 % margin), whole wavefronts
+        const float nn = roundf(cfg.fs / (cfg.nominal_code_rate / cfg.code_len_f));
+        const uint64_t n_nom = nn > 0 ? uint64_t(nn * 1.01f) + 64 : 64;
+        a.per = uint32_t(((n_nom + G - 1) / G + 63) / 64 * 64);
+    } a.xchg = d_xchg; a.outs = d_outs;
+    a.processed = d_processed; a.lost = d_lost; a.lost_prn = d_lost_prn; a.error_flag = d_error;
+    // dynamic LDS: chip row (padded to 16 B) + the gathered G*NV partials
+    const size_t lds = size_t((cfg.code_len + 15) & ~15);
+    const dim3 grid(cfg.n_channels * G);
+    if (cfg.n_arms == 5) hipLaunchKernelGGL(trk_persistent_kernel<5>, grid, dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL(trk_persistent_kernel<3>, grid, dim3(1024), lds, st, a);
 }
 
 void launch_trk_epoch(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_codes, gm_trk_state* d_states,

@@ -1,0 +1,20 @@
+import sys, ctypes as C, numpy as np
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gnss_sdr_rs_amd import _lib, acquisition as A, synth, tracking as T
+_lib.init(0)
+ca=A.ca_code_table(); fs=25e6; Cn=32; E=40; n=25000
+sc=synth.tracking_scene(ca, fs, 0.0, list(range(1,33)), E+2, config_id=3, cn0=47.0)
+ring=T.MulticastRingBuffer(1<<21); ring.write_samples(synth.to_c32(sc['x']))
+mgr=T.TrackingManager(fs, n_channels=Cn, code_index_mode=1)
+for i,s in enumerate(sc['sats']):
+    mgr.channels[i].start(dict(prn=s['prn'], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=s['doppler_hz']+20.0, fs=fs, mag_relative=1.0, sample_global_index=s['code_start'], doppler_bin=0))
+L=_lib.lib()
+_lib.check(L.gm_trk_debug_stamps(mgr._h, E, None),'arm')
+mgr.update_all_dev(ring, E); mgr.synchronize()
+buf=np.zeros((E,8),np.int64)
+_lib.check(L.gm_trk_debug_stamps(mgr._h, E, buf.ctypes.data_as(C.c_void_p)),'read')
+d=np.diff(buf,axis=1)
+names=['compute','reduce+barrier','wg-partial+publish','poll','totals','epilogue','barrier+copy']
+print('per-phase cycles (median over epochs 5..):')
+for i,nm in enumerate(names): print('  %-20s %8.0f'%(nm, np.median(d[5:,i])))
+print('epoch total (stamp0->stamp0 next):', np.median(np.diff(buf[5:,0])))
