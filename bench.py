@@ -168,6 +168,14 @@ def main():
                      "whole_step_algorithmic_GBs": (corr_bytes + mix_bytes) * args.steps / elapsed / 1e9},
     }
     del keep
+    if rank == 0:
+        # the drop-in host-buffer entry (gm_acq_search: H2D of the 160 KB snapshot + kernels + D2H of results);
+        # PCIe-inclusive, reported for DESIGN.md, never `value`
+        eng.search(xi8)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            eng.search(xi8)
+        out["config"]["host_buffer_api_ms_per_dwell"] = (time.perf_counter() - t1) / 20 * 1e3
 
     # ------------------------------------------------------------------ tracking leg (configs[2]), rank-local
     if not args.no_tracking:

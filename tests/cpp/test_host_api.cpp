@@ -1,0 +1,123 @@
+// C++ host-API tests over the C ABI, written to read like the reference's inline Rust tests:
+//   test_acquisition_manager_*            src/acquisition/do_acquisition.rs:339-395
+//   test_multicast_ring_buffer            src/utilities/multicast_ring_buffer.rs:147-209
+//   test_pll_frequency_pull_in            src/tracking/do_tracking.rs:464-570   (FIXED code index: the reference's
+//                                         synthetic helper indexes a resampled code by chip; here a true C/A signal)
+//   test_acquisition_with_synthetic_data  the shape of do_acquisition.rs:399-466 on a generated capture
+// Usage: test_host_api [--cpu-only]
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "gnss_sdr.hpp"
+
+using namespace gnss;
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static int test_acquisition_manager() {
+    AcquisitionManager manager;
+    CHECK(manager.mode() == SearchMode::ColdStart);
+    manager.update_mode(3); CHECK(manager.mode() == SearchMode::WarmStart);
+    manager.update_mode(5); CHECK(manager.mode() == SearchMode::SteadyState);
+    manager.update_mode(0); CHECK(manager.mode() == SearchMode::ColdStart);
+    auto [interval, mask] = manager.get_pacing_and_list({});
+    CHECK(interval == 500 && mask == 0xFFFFFFFFu);
+    manager.update_mode(3);
+    auto [i2, m2] = manager.get_pacing_and_list({1, 2, 3});
+    CHECK(i2 == 1000 && m2 == 2040);
+    return 0;
+}
+
+static int test_multicast_ring_buffer() {
+    MulticastRingBuffer ring_buf(1024);
+    std::vector<Complex32> samples;
+    for (int i = 0; i < 500; ++i) samples.push_back({float(i), 0.f});
+    ring_buf.write_samples(samples);
+    CHECK(ring_buf.get_head() == 500);
+    std::vector<Complex32> more;
+    for (int i = 500; i < 1030; ++i) more.push_back({float(i), 0.f});
+    ring_buf.write_samples(more);
+    CHECK(ring_buf.get_head() == 1030);
+    std::vector<Complex32> dest(10);
+    ring_buf.copy_to_slice(1020, dest);
+    for (int i = 0; i < 10; ++i) CHECK(dest[i] == Complex32(float(1020 + i), 0.f));
+    std::vector<Complex32> phys(6);
+    ring_buf.copy_to_slice(0, phys);   // physical slots 0..5 now hold 1024..1029
+    for (int i = 0; i < 6; ++i) CHECK(phys[i] == Complex32(float(1024 + i), 0.f));
+    return 0;
+}
+
+static std::vector<Complex32> synth(uint8_t prn, float doppler, float fs, int n_ms, int code_start, float amp) {
+    int8_t code[1023];
+    check(gm_ca_code_row(prn - 1, code), "gm_ca_code_row");
+    const int n = int(std::lround(fs / 1000.0));
+    std::vector<Complex32> x(size_t(n) * n_ms);
+    for (size_t i = 0; i < x.size(); ++i) {
+        const double t = double(i) / fs;
+        const long chip = long(std::floor((double(long(i) - code_start)) * 1.023e6 / fs));
+        const int c = code[((chip % 1023) + 1023) % 1023];
+        const double ph = 2.0 * M_PI * doppler * t;
+        x[i] = {float(amp * c * std::cos(ph)), float(amp * c * std::sin(ph))};
+    }
+    return x;
+}
+
+static int test_pll_frequency_pull_in() {
+    const uint8_t prn = 2;
+    const float f_sampling = 4096000.0f, true_doppler = 3000.0f;
+    auto signal = synth(prn, true_doppler, f_sampling, 4, 0, 1.0f);
+    MulticastRingBuffer buf(32768);
+    buf.write_samples(std::vector<Complex32>(signal.begin(), signal.begin() + 4096));
+    CHECK(buf.get_head() == 4096);
+    TrackingManager mgr(f_sampling, 1, GM_CODE_INDEX_FIXED);
+    AcquisitionResult r{};
+    r.prn = prn; r.carrier_freq = 2950.0f; r.code_phase_chips = 0.0f; r.fs = f_sampling; r.mag_relative = 10.0f;
+    mgr.channels[0].start(r);
+    CHECK(mgr.process_channels(buf, 1) == 1);
+    auto s = mgr.channels[0].state();
+    CHECK(s.carrier_error > 0.0f);      // do_tracking.rs:503-507
+    CHECK(s.carrier_nco > 0.0f);        // :509-513
+    CHECK(s.carrier_freq > 2950.0f);    // :515-519
+    CHECK(s.next_sample_index == s.num_samples_per_code);   // :525
+    CHECK(mgr.process_channels(buf, 1) == 0);               // no new data: update() returns None (:170-172)
+    buf.write_samples(std::vector<Complex32>(signal.begin() + 4096, signal.begin() + 3 * 4096));
+    const uint64_t before = s.next_sample_index;
+    CHECK(mgr.process_channels(buf, 4) == 2);
+    s = mgr.channels[0].state();
+    CHECK(s.next_sample_index == before + 2 * 4096);
+    CHECK(std::fabs(s.carrier_freq - true_doppler) < 50.0f);
+    return 0;
+}
+
+static int test_acquisition_with_synthetic_data() {
+    const float FS = 4096000.0f, IF = 0.0f;
+    const size_t NUM_INTEGRATIONS = 4, N = 4096;
+    auto raw_samples = synth(6, 1200.0f, FS, int(NUM_INTEGRATIONS), 900, 4.0f);
+    std::vector<DopplerShiftTable> doppler_tables;
+    for (float d = -2000.0f; d <= 2000.0f; d += 500.0f) doppler_tables.emplace_back(IF, d, FS, N);
+    for (uint8_t test_prn = 5; test_prn <= 7; ++test_prn) {
+        AcquisitionWorker worker(test_prn, N, FS);
+        auto result = worker.search_satellite(raw_samples, doppler_tables, 0, NUM_INTEGRATIONS);
+        if (test_prn == 6) {
+            CHECK(result.has_value());
+            CHECK(result->prn == 6 && result->code_phase_samples == 900);
+            CHECK(std::fabs(result->carrier_freq - 1200.0f) <= 500.0f);
+        } else {
+            CHECK(!result.has_value());   // "satellite likely not visible"
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const bool cpu_only = argc > 1 && !std::strcmp(argv[1], "--cpu-only");
+    int rc = test_acquisition_manager();
+    std::printf("test_acquisition_manager %s\n", rc ? "FAILED" : "ok");
+    if (cpu_only || rc) return rc;
+    init(0);
+    rc |= test_multicast_ring_buffer();            std::printf("test_multicast_ring_buffer %s\n", rc ? "FAILED" : "ok");
+    rc |= test_pll_frequency_pull_in();            std::printf("test_pll_frequency_pull_in %s\n", rc ? "FAILED" : "ok");
+    rc |= test_acquisition_with_synthetic_data();  std::printf("test_acquisition_with_synthetic_data %s\n", rc ? "FAILED" : "ok");
+    return rc;
+}
