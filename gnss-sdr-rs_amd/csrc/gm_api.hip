@@ -1057,12 +1057,12 @@ int gm_trk_debug_stamps(gm_trk* t, uint32_t cap, long long* out) {
     if (int rc = ensure_device(t->device)) return rc;
     if (!out) {   // arm
         hipFree(t->d_stamps); t->d_stamps = nullptr; t->stamps_cap = 0;
-        if (cap) { HIPC(hipMalloc(&t->d_stamps, size_t(cap) * 8 * sizeof(long long))); HIPC(hipMemset(t->d_stamps, 0, size_t(cap) * 64)); t->stamps_cap = cap; }
+        if (cap) { HIPC(hipMalloc(&t->d_stamps, size_t(cap) * 48 * sizeof(long long))); HIPC(hipMemset(t->d_stamps, 0, size_t(cap) * 384)); t->stamps_cap = cap; }
         return GM_OK;
     }
     if (!t->d_stamps || cap > t->stamps_cap) return set_err(GM_ERR_INVALID_ARG, "stamps not armed");
     HIPC(hipStreamSynchronize(t->stream));
-    HIPC(hipMemcpy(out, t->d_stamps, size_t(cap) * 64, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out, t->d_stamps, size_t(cap) * 384, hipMemcpyDeviceToHost));
     return GM_OK;
 }
 

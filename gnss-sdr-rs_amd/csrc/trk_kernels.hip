@@ -118,9 +118,13 @@ __device__ __forceinline__ bool fast_code_range(const EpochConsts& c, uint64_t n
 }
 
 // one sample: carrier wipe-off fused with the replica multiplies (early_late_correlation :231-263)
-template <int ARMS, bool FAST>
+// MODE_T / BOC_T: compile-time code-index mode and BOC flag (straight-line code the scheduler can interleave
+// across samples), or -1 to read them from the epoch constants at run time (unit-entry kernels).
+template <int ARMS, bool FAST, int MODE_T = -1, int BOC_T = -1>
 __device__ __forceinline__ void correlate_sample(const EpochConsts& c, const int8_t* chips, cf d, uint32_t i,
                                                  float (&acc)[2 * ARMS]) {
+    const int mode = MODE_T >= 0 ? MODE_T : c.mode;
+    const bool boc = BOC_T >= 0 ? (BOC_T != 0) : (c.boc11 != 0);
     const float fi = float(i);
     const float phase = c.carrier_phase + __fdiv_rn(c.two_pi_f * fi, c.fs);
     float sn, cs;
@@ -129,10 +133,10 @@ __device__ __forceinline__ void correlate_sample(const EpochConsts& c, const int
     const float xr = d.x * wc - d.y * ws;                   // num-complex Mul
     const float xi = d.x * ws + d.y * wc;
     const float chip_idx = fmod_code<FAST>(c.code_phase + fi * c.step, c.lenf);
-    float pc = float(chips[chip_index(chip_idx, c.len, c.mode)]);
-    float ec = float(chips[chip_index(chip_idx + c.el, c.len, c.mode)]);
-    float lc = float(chips[chip_index(chip_idx - c.el, c.len, c.mode)]);
-    if (c.boc11) {   // BOC(1,1): sub-carrier sign = +1 on the first half chip, -1 on the second
+    float pc = float(chips[chip_index(chip_idx, c.len, mode)]);
+    float ec = float(chips[chip_index(chip_idx + c.el, c.len, mode)]);
+    float lc = float(chips[chip_index(chip_idx - c.el, c.len, mode)]);
+    if (boc) {   // BOC(1,1): sub-carrier sign = +1 on the first half chip, -1 on the second
         const float a = chip_idx, b = chip_idx + c.el, e = chip_idx - c.el;
         pc = (a - floorf(a)) < 0.5f ? pc : -pc;
         ec = (b - floorf(b)) < 0.5f ? ec : -ec;
@@ -144,9 +148,9 @@ __device__ __forceinline__ void correlate_sample(const EpochConsts& c, const int
     acc[4] = __builtin_fmaf(xr, lc, acc[4]); acc[5] = __builtin_fmaf(xi, lc, acc[5]);
     if constexpr (ARMS == 5) {
         const float ve = chip_idx + c.vel, vl = chip_idx - c.vel;
-        float vec = float(chips[chip_index(ve, c.len, c.mode)]);
-        float vlc = float(chips[chip_index(vl, c.len, c.mode)]);
-        if (c.boc11) {
+        float vec = float(chips[chip_index(ve, c.len, mode)]);
+        float vlc = float(chips[chip_index(vl, c.len, mode)]);
+        if (boc) {
             vec = (ve - floorf(ve)) < 0.5f ? vec : -vec;
             vlc = (vl - floorf(vl)) < 0.5f ? vlc : -vlc;
         }
@@ -328,7 +332,7 @@ struct TrkPersistArgs {
     unsigned long long* xchg;        // [2][n_channels][G][NV] granules
     gm_trk_out* outs; uint8_t *processed, *lost, *lost_prn;   // [epochs][n_channels] (may be null)
     int* error_flag;                 // set to 1 if an exchange wait timed out
-    long long* stamps;               // diagnostic only (may be null): [epochs][8] s_memtime stamps of workgroup 0
+    long long* stamps;               // diagnostic only (may be null): [epochs][48] s_memtime stamps of workgroup 0 (8 phases, 16 waves x compute end, 16 x barrier arrival)
 };
 
 // diagnostic stamp (gm_trk_debug_stamps): one asm statement so the wait stays with the read, fenced against
@@ -341,6 +345,24 @@ __device__ __forceinline__ long long stamp_now() {
     return (long long)t;
 }
 
+// Sum over the 64 lanes of a wavefront without LDS traffic: an inclusive scan inside each row of 16 lanes with
+// DPP row_shr (lane 15 of a row ends with the row total), then the four row totals are read as scalars and
+// added in row order.  Wave-uniform result; fixed order (deterministic).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    int x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));   // row_shr:1
+    x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));   // row_shr:2
+    x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true));   // row_shr:4
+    x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true));   // row_shr:8
+    x = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 31));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 63));
+    return ((r0 + r1) + r2) + r3;
+}
+
 // workgroup barrier that orders LDS traffic only: pending global loads (the sample prefetch) stay in flight
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -348,7 +370,25 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int ARMS>
+// what wave 0 hands to the whole workgroup once per epoch
+struct EpochShared {
+    gm_trk_state s;
+    uint32_t n;        // samples of the coming epoch (0: channel cannot run)
+    int fast;          // fast_code_range(...) for the coming epoch
+    EpochConsts ec;
+};
+
+__device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t head, EpochShared& sh) {
+    const gm_trk_state& s = sh.s;
+    const uint64_t n = samples_per_code(cfg.fs, s.code_rate, cfg.code_len_f);     // update() :165-166
+    bool run = s.active && n > 0 && n < (1ull << 31);
+    if (run) run = (int64_t)(head - (s.next_sample_index + n)) >= 0;              // :170-172
+    sh.n = run ? uint32_t(n) : 0u;
+    sh.ec = epoch_consts(cfg, s);
+    sh.fast = fast_code_range(sh.ec, n) ? 1 : 0;
+}
+
+template <int ARMS, int MODE_T, int BOC_T>
 __global__ __launch_bounds__(1024) void trk_persistent_kernel(TrkPersistArgs a) {
     constexpr int NV = 2 * ARMS, T = 1024, NW = T / 64, KPF = 4;
     const TrkDevCfg& cfg = a.cfg;
@@ -356,20 +396,21 @@ __global__ __launch_bounds__(1024) void trk_persistent_kernel(TrkPersistArgs a) 
     const int C = cfg.n_channels;
     const int wave = tid >> 6, lane = tid & 63;
     __shared__ float wsum[NW][NV];
-    __shared__ gm_trk_state s_next;     // wave 0 -> everyone, once per epoch
+    __shared__ EpochShared sh;          // wave 0 -> everyone, once per epoch
     __shared__ int ctl;                 // 0 continue, 1 exchange timed out
     __shared__ float gathered[256];     // the G*NV partials of one epoch (wave 0 only)
     extern __shared__ int8_t chips[];   // the channel's chip row
 
-    gm_trk_state s = a.states[ch];
-    const int row = code_row(cfg, s);
+    gm_trk_state s0 = a.states[ch];
+    const int row = code_row(cfg, s0);
     const bool leader = (g == 0 && tid == 0);
     int e = 0;
     bool timed_out = false;
-    if (s.active && row >= 0 && row < cfg.n_codes) {
+    gm_trk_state s = s0;
+    if (s0.active && row >= 0 && row < cfg.n_codes) {
         const int8_t* crow = a.codes + size_t(row) * cfg.code_len;
         for (int i = tid; i < cfg.code_len; i += T) chips[i] = crow[i];
-        if (tid == 0) ctl = 0;
+        if (tid == 0) { ctl = 0; sh.s = s0; prepare_epoch(cfg, a.head, sh); }
         __syncthreads();
         // slice geometry, fixed for the launch: `per` samples per workgroup (multiple of 64 lanes); the last
         // workgroup also takes whatever a longer code period adds beyond G*per
@@ -379,49 +420,70 @@ __global__ __launch_bounds__(1024) void trk_persistent_kernel(TrkPersistArgs a) 
         // epoch's partial sums travel between workgroups (its window start is known: next + n)
         cf pf[KPF];
 #pragma unroll
-        for (int j = 0; j < KPF; ++j) pf[j] = a.ring[(s.next_sample_index + i0 + tid + j * T) & a.mask];
+        for (int j = 0; j < KPF; ++j) pf[j] = a.ring[(s0.next_sample_index + i0 + tid + j * T) & a.mask];
 
         for (; e < a.epochs; ++e) {
-            const uint64_t n = samples_per_code(cfg.fs, s.code_rate, cfg.code_len_f);     // update() :165-166
-            bool run = s.active && n > 0 && n < (1ull << 31);
-            if (run) run = (int64_t)(a.head - (s.next_sample_index + n)) >= 0;            // :170-172
-            if (!run) break;                       // state is identical in the G workgroups: they all leave
-            s.num_samples_per_code = n;
+            const uint32_t n = sh.n;
+            if (n == 0) break;                     // state is identical in the G workgroups: they all leave
+            const EpochConsts ec = sh.ec;
+            const uint64_t win = sh.s.next_sample_index;
             const bool st_on = a.stamps && blockIdx.x == 0 && tid == 0;
-            long long* stp = a.stamps + size_t(e) * 8;
+            long long* stp = a.stamps + size_t(e) * 48;
             if (st_on) stp[0] = stamp_now();
-            const EpochConsts ec = epoch_consts(cfg, s);
-            const uint32_t i1 = (g == a.G - 1 || uint64_t(i0) + per > n) ? uint32_t(n) : i0 + per;
-            float acc[NV];
+            const uint32_t i1 = (g == a.G - 1 || i0 + per > n) ? n : i0 + per;
+            const uint32_t cnt = i1 > i0 ? i1 - i0 : 0u;     // samples of this slice (workgroup-uniform)
+            const uint32_t full = cnt / T;                     // strided passes in which every lane has a sample
+            float acc[NV], acc2[NV];
 #pragma unroll
-            for (int k = 0; k < NV; ++k) acc[k] = 0.0f;
-            if (fast_code_range(ec, n)) {
-#pragma unroll
-                for (int j = 0; j < KPF; ++j) {
-                    const uint32_t i = i0 + tid + j * T;
-                    if (i < i1) correlate_sample<ARMS, true>(ec, chips, pf[j], i, acc);
+            for (int k = 0; k < NV; ++k) { acc[k] = 0.0f; acc2[k] = 0.0f; }
+            if (sh.fast) {
+                // whole passes run unpredicated and two at a time, so the scheduler interleaves two independent
+                // samples (division, f64 reduction, LDS look-ups are long dependent chains)
+                const uint32_t b0 = i0 + tid;
+                if (full >= 2) {
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[0], b0, acc);
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[1], b0 + T, acc2);
+                } else if (full == 1) {
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[0], b0, acc);
                 }
-                for (uint32_t i = i0 + tid + KPF * T; i < i1; i += T)
-                    correlate_sample<ARMS, true>(ec, chips, a.ring[(s.next_sample_index + i) & a.mask], i, acc);
+                if (full >= 4) {
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[2], b0 + 2 * T, acc);
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[3], b0 + 3 * T, acc2);
+                } else if (full == 3) {
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[2], b0 + 2 * T, acc);
+                }
+                uint32_t j = KPF;
+                for (; j + 1 < full; j += 2) {
+                    const cf d0 = a.ring[(win + b0 + j * T) & a.mask], d1 = a.ring[(win + b0 + (j + 1) * T) & a.mask];
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d0, b0 + j * T, acc);
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d1, b0 + (j + 1) * T, acc2);
+                }
+                if (j < full) correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, a.ring[(win + b0 + j * T) & a.mask], b0 + j * T, acc);
+                // ragged last pass
+                const uint32_t it = b0 + full * T;
+                if (it < i1) {
+                    cf d = full == 0 ? pf[0] : (full == 1 ? pf[1] : (full == 2 ? pf[2] : pf[3]));
+                    if (full >= uint32_t(KPF)) d = a.ring[(win + it) & a.mask];
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d, it, acc2);
+                }
             } else {   // out-of-family state (e.g. set by the caller): general fmodf, no prefetch use
                 for (uint32_t i = i0 + tid; i < i1; i += T)
-                    correlate_sample<ARMS, false>(ec, chips, a.ring[(s.next_sample_index + i) & a.mask], i, acc);
+                    correlate_sample<ARMS, false, MODE_T, BOC_T>(ec, chips, a.ring[(win + i) & a.mask], i, acc);
             }
             if (st_on) stp[1] = stamp_now();
+            if (a.stamps && blockIdx.x == 0 && lane == 0) stp[8 + wave] = stamp_now();        // per-wave compute end
             {   // request the next epoch's samples now; they land during the exchange below
-                const uint64_t nb = s.next_sample_index + n;
+                const uint64_t nb = win + n;
 #pragma unroll
                 for (int j = 0; j < KPF; ++j) pf[j] = a.ring[(nb + i0 + tid + j * T) & a.mask];
             }
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
-            }
+            for (int k = 0; k < NV; ++k) acc[k] = wave_sum_dpp(acc[k] + acc2[k]);
             if (lane == 0) {
 #pragma unroll
                 for (int k = 0; k < NV; ++k) wsum[wave][k] = acc[k];
             }
+            if (a.stamps && blockIdx.x == 0 && lane == 0) stp[24 + wave] = stamp_now();       // per-wave barrier arrival
             lds_barrier();    // NOT __syncthreads(): its fence would wait for the prefetch loads (vmcnt(0))
             if (st_on) stp[2] = stamp_now();
             if (wave == 0) {
@@ -475,12 +537,14 @@ __global__ __launch_bounds__(1024) void trk_persistent_kernel(TrkPersistArgs a) 
 #pragma unroll
                 for (int k = 0; k < NV; ++k) v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tk), k));
                 if (st_on) stp[5] = stamp_now();
-                gm_trk_state sn = s;
+                gm_trk_state sn = sh.s;
+                sn.num_samples_per_code = n;                     // update() stores the length it used (:166)
                 uint8_t lst = 0, lprn = 0;
                 if (!to) epoch_epilogue<ARMS>(cfg, sn, v, n, TRK_MODE_DO_WORK, lst, lprn);
                 if (st_on) stp[6] = stamp_now();
                 if (lane == 0) {
-                    s_next = sn;
+                    sh.s = sn;
+                    prepare_epoch(cfg, a.head, sh);              // n / constants / gate of the NEXT epoch, once
                     ctl = to ? 1 : 0;
                     if (g == 0 && !to) {
                         const size_t o = size_t(e) * C + ch;
@@ -494,11 +558,11 @@ __global__ __launch_bounds__(1024) void trk_persistent_kernel(TrkPersistArgs a) 
             lds_barrier();
             if (ctl) { timed_out = true; break; }
             // no third barrier: wsum is rewritten only after every wave has passed the NEXT epoch's compute, and
-            // s_next only after the next epoch's first barrier, which no wave reaches before reading it here
-            s = s_next;
+            // `sh` only after the next epoch's first barrier, which no wave reaches before reading it above
             if (st_on) stp[7] = stamp_now();
         }
         if (tid == 0 && timed_out) *a.error_flag = 1;
+        s = sh.s;
     }
     if (leader) {
         a.states[ch] = s;
@@ -531,8 +595,18 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     // dynamic LDS: chip row (padded to 16 B) + the gathered G*NV partials
     const size_t lds = size_t((cfg.code_len + 15) & ~15);
     const dim3 grid(cfg.n_channels * G);
-    if (cfg.n_arms == 5) hipLaunchKernelGGL(trk_persistent_kernel<5>, grid, dim3(1024), lds, st, a);
-    else hipLaunchKernelGGL(trk_persistent_kernel<3>, grid, dim3(1024), lds, st, a);
+    // compile-time arms / code-index mode / BOC: straight-line sample code
+    const int key = (cfg.n_arms == 5 ? 4 : 0) | (cfg.code_index_mode == GM_CODE_INDEX_FIXED ? 2 : 0) | (cfg.boc11 ? 1 : 0);
+    switch (key) {
+        case 0: hipLaunchKernelGGL((trk_persistent_kernel<3, 0, 0>), grid, dim3(1024), lds, st, a); break;
+        case 1: hipLaunchKernelGGL((trk_persistent_kernel<3, 0, 1>), grid, dim3(1024), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((trk_persistent_kernel<3, 1, 0>), grid, dim3(1024), lds, st, a); break;
+        case 3: hipLaunchKernelGGL((trk_persistent_kernel<3, 1, 1>), grid, dim3(1024), lds, st, a); break;
+        case 4: hipLaunchKernelGGL((trk_persistent_kernel<5, 0, 0>), grid, dim3(1024), lds, st, a); break;
+        case 5: hipLaunchKernelGGL((trk_persistent_kernel<5, 0, 1>), grid, dim3(1024), lds, st, a); break;
+        case 6: hipLaunchKernelGGL((trk_persistent_kernel<5, 1, 0>), grid, dim3(1024), lds, st, a); break;
+        default: hipLaunchKernelGGL((trk_persistent_kernel<5, 1, 1>), grid, dim3(1024), lds, st, a); break;
+    }
 }
 
 void launch_trk_epoch(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_codes, gm_trk_state* d_states,

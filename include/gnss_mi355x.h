@@ -259,7 +259,7 @@ int gm_trk_update_all_dev(gm_trk *t, gm_ring *ring, uint32_t epochs);
 int gm_trk_synchronize(gm_trk *t);
 int gm_trk_set_stream(gm_trk *t, void *hip_stream);
 /* Diagnostic (not in the reference): call with out == NULL to arm `cap` epochs of per-phase shader-clock stamps
- * of workgroup 0 in the persistent kernel, then with out = [cap][8] int64 after a launch to read them. */
+ * of workgroup 0 in the persistent kernel, then with out = [cap][48] int64 after a launch to read them. */
 int gm_trk_debug_stamps(gm_trk *t, uint32_t cap, long long *out);
 int gm_trk_enable_timing(gm_trk *t, int on);
 int gm_trk_last_timing(gm_trk *t, float *ms_correlate_total, uint32_t *launches);

@@ -576,9 +576,23 @@ static const int8_t *ca_row_cached(int row) {
     return table[row];
 }
 
+static int get_chip_general(const orc_trk_channel *c, float phase, float *chip) {
+    /* custom code table (no reference): row prn-1, wrapping index, optional BOC(1,1) sign */
+    const long len = (long)c->code_len;
+    int row = (int)c->prn - 1;
+    if (row < 0 || (uint32_t)row >= c->n_codes) return -1;
+    float f = floorf(phase);
+    long li;
+    if (c->code_index_mode == ORC_CODE_INDEX_FAITHFUL) li = (f > 0.0f) ? ((long)f % len) : 0;
+    else { li = (long)f % len; if (li < 0) li += len; }
+    *chip = (float)c->custom_codes[(size_t)row * (size_t)len + (size_t)li];
+    return 0;
+}
+
 int orc_trk_get_ca_chip(const orc_trk_channel *c, float phase, float *chip) { /* :274-277 */
     int row;
     size_t idx;
+    if (c->custom_codes) return get_chip_general(c, phase, chip);
     if (c->code_index_mode == ORC_CODE_INDEX_FAITHFUL) {
         row = (int)c->prn;                           /* GPS_CA_CODE_32_PRN[self.prn as usize] */
         idx = floor_as_usize_mod1023(phase);
@@ -628,6 +642,42 @@ int orc_trk_early_late_correlation(orc_trk_channel *c, orc_c32 *data, float out6
     c->code_phase = fmodf(c->code_phase + (c->code_rate / c->fs) * (float)n, 1023.0f); /* :265-267 */
     c->i_prompt = i_p; c->q_prompt = q_p;            /* :269-270 */
     out6[0] = i_p; out6[1] = q_p; out6[2] = i_e; out6[3] = q_e; out6[4] = i_l; out6[5] = q_l;
+    if (acc64) memcpy(acc64, a64, sizeof(a64));
+    return 0;
+}
+
+int orc_trk_early_late_correlation_ex(orc_trk_channel *c, orc_c32 *data, float out10[10], double acc64[10]) {
+    /* early_late_correlation :231-272 generalised: same per-sample f32 operations, code length / arm count /
+     * BOC(1,1) from the channel.  With n_arms 3, no BOC, no custom code it equals the function above. */
+    const size_t n = (size_t)c->num_samples_per_code;
+    const float lenf = c->custom_codes ? (float)c->code_len : 1023.0f;
+    const float el = c->el_space > 0.0f ? c->el_space : EARLY_LATE_SPACE;
+    const float vel = c->vel_space > 0.0f ? c->vel_space : 1.0f;
+    const int arms = c->n_arms == 5 ? 5 : 3;
+    for (size_t i = 0; i < n; i++) {
+        float phase = c->carrier_phase + (2.0f * PI_F * c->carrier_freq * (float)i / c->fs);
+        orc_c32 w = {cosf(phase), -sinf(phase)};
+        data[i] = cmul(data[i], w);
+    }
+    c->carrier_phase = fmodf(c->carrier_phase + 2.0f * PI_F * c->carrier_freq * ((float)n / c->fs), 2.0f * PI_F);
+    float acc[10] = {0};
+    double a64[10] = {0};
+    for (size_t i = 0; i < n; i++) {
+        float chip_idx = fmodf(c->code_phase + ((float)i * (c->code_rate / c->fs)), lenf);
+        float ph[5] = {chip_idx, chip_idx + el, chip_idx - el, chip_idx + vel, chip_idx - vel};
+        for (int a = 0; a < arms; a++) {
+            float chip;
+            if (orc_trk_get_ca_chip(c, ph[a], &chip)) return -1;
+            if (c->boc11 && !((ph[a] - floorf(ph[a])) < 0.5f)) chip = -chip;
+            acc[2 * a] += data[i].re * chip;
+            acc[2 * a + 1] += data[i].im * chip;
+            a64[2 * a] += (double)(data[i].re * chip);
+            a64[2 * a + 1] += (double)(data[i].im * chip);
+        }
+    }
+    c->code_phase = fmodf(c->code_phase + (c->code_rate / c->fs) * (float)n, lenf);
+    c->i_prompt = acc[0]; c->q_prompt = acc[1];
+    memcpy(out10, acc, sizeof(acc));
     if (acc64) memcpy(acc64, a64, sizeof(a64));
     return 0;
 }

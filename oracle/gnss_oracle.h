@@ -142,6 +142,14 @@ typedef struct {            /* TrackingChannel :88-116 (fields that carry state)
     float i_prompt, q_prompt;
     orc_loop_filter pll_filter, dll_filter;
     int32_t code_index_mode; /* extra: ORC_CODE_INDEX_* (SURVEY §4 off-by-one switch) */
+    /* generalisation for the constellations the reference does not implement (no reference code,
+     * parity unpinned): 0 / NULL = the reference's GPS C/A E/P/L behaviour */
+    int32_t n_arms;           /* 0 or 3: E/P/L; 5: + very early / very late */
+    float el_space;           /* 0 -> EARLY_LATE_SPACE 0.5 */
+    float vel_space;          /* 0 -> 1.0 */
+    int32_t boc11;            /* chip x BOC(1,1) sub-carrier sign (+ first half chip, - second) */
+    const int8_t *custom_codes; /* [n_codes][code_len] +-1 chips, row = prn-1 (FIXED) */
+    uint32_t n_codes, code_len;
 } orc_trk_channel;
 
 void orc_trk_new(orc_trk_channel *c, uint8_t id, float fs);                 /* :118-146 */
@@ -154,6 +162,8 @@ int orc_trk_get_ca_chip(const orc_trk_channel *c, float phase, float *chip);
  * reference.  out6 = (i_p,q_p,i_e,q_e,i_l,q_l).  If acc64 != NULL the same per-sample f32 products
  * are ALSO accumulated in double (accuracy yardstick for the GPU's tree sums). Returns 0 / -1 OOB. */
 int orc_trk_early_late_correlation(orc_trk_channel *c, orc_c32 *data, float out6[6], double acc64[6]);
+/* generalised form: out10 = (i_p,q_p,i_e,q_e,i_l,q_l,i_ve,q_ve,i_vl,q_vl); arms/BOC/custom code from the channel */
+int orc_trk_early_late_correlation_ex(orc_trk_channel *c, orc_c32 *data, float out10[10], double acc64[10]);
 void orc_trk_run_loop_filters(orc_trk_channel *c, float i_p, float q_p, float i_e, float q_e,
                               float i_l, float q_l);                        /* :279-302 */
 /* do_work :183-210 on caller-supplied samples.  returns 0 none, 1 SatelliteLost (msg_prn as the

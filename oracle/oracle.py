@@ -32,7 +32,9 @@ class TrkChannel(C.Structure):
                 ("carrier_phase", C.c_float), ("carrier_error", C.c_float), ("carrier_nco", C.c_float),
                 ("code_phase", C.c_float), ("code_error", C.c_float), ("code_nco", C.c_float),
                 ("code_rate", C.c_float), ("i_prompt", C.c_float), ("q_prompt", C.c_float),
-                ("pll_filter", LoopFilter), ("dll_filter", LoopFilter), ("code_index_mode", C.c_int32)]
+                ("pll_filter", LoopFilter), ("dll_filter", LoopFilter), ("code_index_mode", C.c_int32),
+                ("n_arms", C.c_int32), ("el_space", C.c_float), ("vel_space", C.c_float), ("boc11", C.c_int32),
+                ("custom_codes", C.c_void_p), ("n_codes", C.c_uint32), ("code_len", C.c_uint32)]
 
 
 class Ring(C.Structure):
@@ -101,6 +103,7 @@ def lib(native=False):
     L.orc_trk_reset.argtypes = [TP]
     L.orc_trk_get_ca_chip.argtypes = [TP, f32, C.POINTER(f32)]
     L.orc_trk_early_late_correlation.argtypes = [TP, vp, vp, vp]
+    L.orc_trk_early_late_correlation_ex.argtypes = [TP, vp, vp, vp]
     L.orc_trk_run_loop_filters.argtypes = [TP, f32, f32, f32, f32, f32, f32]
     L.orc_trk_do_work.argtypes = [TP, vp, vp, C.POINTER(C.c_uint8)]
     RP = C.POINTER(Ring)
@@ -295,10 +298,19 @@ def loop_filter_new(bw, zeta, gain):
 class TrackingChannel:
     """tracking::do_tracking::TrackingChannel (do_tracking.rs:88-327)"""
 
-    def __init__(self, id, fs, code_index_mode=CODE_INDEX_FAITHFUL):
+    def __init__(self, id, fs, code_index_mode=CODE_INDEX_FAITHFUL, n_arms=3, el_space=0.0, vel_space=0.0, boc11=False,
+                 codes=None, code_rate=None):
         self.c = TrkChannel()
         lib().orc_trk_new(C.byref(self.c), id, fs)
         self.c.code_index_mode = code_index_mode
+        self.c.n_arms, self.c.el_space, self.c.vel_space, self.c.boc11 = n_arms, el_space, vel_space, int(boc11)
+        self._codes = None
+        if codes is not None:   # generalisation (no reference code): custom chip table
+            self._codes = np.ascontiguousarray(codes, np.int8)
+            self.c.custom_codes, self.c.n_codes, self.c.code_len = self._codes.ctypes.data, self._codes.shape[0], self._codes.shape[1]
+            if code_rate:
+                self.c.code_rate = code_rate
+            self.c.num_samples_per_code = int(np.round(np.float32(fs) / (np.float32(self.c.code_rate) / np.float32(self._codes.shape[1]))))
 
     def start(self, result):
         r = result if isinstance(result, AcqResult) else AcqResult(**result)
@@ -325,6 +337,16 @@ class TrackingChannel:
         if rc:
             raise IndexError("get_ca_chip out of bounds")
         return (out, acc) if want_f64 else out
+
+    def early_late_correlation_ex(self, data_samples):
+        """generalised (arms / BOC / custom code): returns (out10 f32, acc10 f64)"""
+        d = _c64(data_samples).copy()
+        assert d.size >= self.c.num_samples_per_code
+        out = np.zeros(10, np.float32)
+        acc = np.zeros(10, np.float64)
+        if lib().orc_trk_early_late_correlation_ex(C.byref(self.c), _p(d), _p(out), _p(acc)):
+            raise IndexError("code table row out of bounds")
+        return out, acc
 
     def run_loop_filters(self, i_p, q_p, i_e, q_e, i_l, q_l):
         lib().orc_trk_run_loop_filters(C.byref(self.c), i_p, q_p, i_e, q_e, i_l, q_l)

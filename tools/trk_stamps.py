@@ -11,10 +11,14 @@ for i,s in enumerate(sc['sats']):
 L=_lib.lib()
 _lib.check(L.gm_trk_debug_stamps(mgr._h, E, None),'arm')
 mgr.update_all_dev(ring, E); mgr.synchronize()
-buf=np.zeros((E,8),np.int64)
+buf=np.zeros((E,48),np.int64)
 _lib.check(L.gm_trk_debug_stamps(mgr._h, E, buf.ctypes.data_as(C.c_void_p)),'read')
-d=np.diff(buf,axis=1)
+d=np.diff(buf[:,:8],axis=1)
 names=['compute','reduce+barrier','wg-partial+publish','poll','totals','epilogue','barrier+copy']
 print('per-phase cycles (median over epochs 5..):')
 for i,nm in enumerate(names): print('  %-20s %8.0f'%(nm, np.median(d[5:,i])))
 print('epoch total (stamp0->stamp0 next):', np.median(np.diff(buf[5:,0])))
+
+ce=buf[5:,8:24]-buf[5:,0:1]; ba=buf[5:,24:40]-buf[5:,0:1]
+print('per-wave compute end (cycles after wave0 epoch start), median:', np.median(ce,axis=0).astype(int))
+print('per-wave barrier arrival, median:', np.median(ba,axis=0).astype(int))
