@@ -91,6 +91,7 @@ SIGNATURES = {
     "gm_acq_enable_timing": (_i, [_vp, _i]),
     "gm_acq_last_timing": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f)]),
     "gm_acq_timing_summary": (_i, [_vp, C.POINTER(_u32), C.POINTER(_f), C.POINTER(_f)]),
+    "gm_acq_debug_stamps": (_i, [_vp, _vp]),
     "gm_acq_manager_mode_for": (_i, [_sz]),
     "gm_acq_manager_pacing_and_list": (_i, [_i, _u32, C.POINTER(_u64), C.POINTER(_u32)]),
     "gm_ring_create": (_i, [_sz, C.POINTER(_vp)]),

@@ -23,14 +23,22 @@
 
 namespace gm {
 
+struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
+
 template <class PL, bool INV, int S> struct MiddlePasses {
-    static __device__ __forceinline__ void run(cf* lds, const cf* tw, int tid) {
+    // st(k): optional diagnostic stamp hook, called only next to barriers (k = 4.. in program order)
+    template <class St = NoStamp>
+    static __device__ __forceinline__ void run(cf* lds, const cf* tw, int tid, St st = St()) {
         if constexpr (S <= PL::NP - 2) {
             cf v[PL::IT(S)][PL::R[S]];
             Fft<PL, INV>::template mid_stage1<S>(v, lds, tw, tid);
+            st(4);
             __syncthreads();   // every lane has read its inputs: the image may be overwritten
+            st(5);
             Fft<PL, INV>::template mid_stage2<S>(v, lds, tid);
+            st(6);
             __syncthreads();
+            st(7);
             MiddlePasses<PL, INV, S + 1>::run(lds, tw, tid);
         }
     }
@@ -105,13 +113,31 @@ __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restri
         [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
 }
 
+// diagnostic phase stamps of the correlation kernel (gm_acq_debug_stamps): s_memtime of lane 0 of every wave of
+// workgroup 0 at the phase boundaries of each transform; null in normal operation
+__device__ long long* g_corr_stamps = nullptr;
+__device__ __forceinline__ void corr_stamp(long long* base, int m, int wave, int phase) {
+    if (base) {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        base[(size_t(m) * 8 + wave) * 8 + phase] = (long long)t;
+    }
+}
+static bool g_corr_stamps_armed = false;
+void set_corr_stamps(long long* d_ptr) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_corr_stamps), &d_ptr, sizeof(d_ptr));
+    g_corr_stamps_armed = d_ptr != nullptr;
+}
+
 // ------------------------------------------------------------------------------------ stage C
 // (value, index) reduction: larger value wins, equal values -> lower index (first strict maximum)
 __device__ __forceinline__ void take_better(float& bv, uint32_t& bi, float v, uint32_t i) {
     if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
 }
 
-template <class PL, bool KEEP_CODE>
+template <class PL, bool KEEP_CODE, bool STAMPS>
 __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ tw_inv,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
@@ -154,19 +180,40 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
 #pragma unroll
         for (int r = 0; r < PL::RL; ++r) acc[it][r] = 0.0f;
 
+    long long* stbase = nullptr;
+    if constexpr (STAMPS) stbase = (blockIdx.x == 0 && (tid & 63) == 0 && PL::T / 64 <= 8) ? g_corr_stamps : nullptr;
+    const int wv = tid >> 6;
     for (int m = 0; m < n_int; ++m) {
-        lds_transform<PL, true>(
-            [&](int it, int r) {
-                const int voff = (tid + it * PL::T) * 8;
-                const cf a = buf_load_cf(xrs, voff, (m * PL::N + r * NB0) * 8);
-                cf c;
-                if constexpr (KEEP_CODE) c = cc[it][r];
-                else { const cf g = buf_load_cf(crs, voff, r * NB0 * 8); c = cf_make(g.x, -g.y); }
-                // result_buf[i] *= conj(code[i])  (:184-186), num-complex Mul, no FMA
-                return cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
-            },
-            [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y); },   // += norm_sqr() (:190-192)
-            lds, tw, tid);
+        auto in = [&](int it, int r) {
+            const int voff = (tid + it * PL::T) * 8;
+            const cf a = buf_load_cf(xrs, voff, (m * PL::N + r * NB0) * 8);
+            cf c;
+            if constexpr (KEEP_CODE) c = cc[it][r];
+            else { const cf g = buf_load_cf(crs, voff, r * NB0 * 8); c = cf_make(g.x, -g.y); }
+            // result_buf[i] *= conj(code[i])  (:184-186), num-complex Mul, no FMA
+            return cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
+        };
+        auto out = [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y); };   // += norm_sqr() (:190-192)
+        if constexpr (!STAMPS) {
+            lds_transform<PL, true>(in, out, lds, tw, tid);
+        } else {   // diagnostic variant: the same phases with stamps next to the barriers
+            auto st = [&](int k) { corr_stamp(stbase, m, wv, k); };
+            st(0);
+            {
+                cf v0[PL::IT0][PL::R0];
+                Fft<PL, true>::pass0_stage1(v0, in, tid);
+                st(1);
+                __syncthreads();
+                st(2);
+                Fft<PL, true>::pass0_stage2(v0, lds, tid);
+            }
+            st(3);
+            __syncthreads();
+            MiddlePasses<PL, true, 1>::run(lds, tw, tid, st);
+            cf vl[PL::ITL][PL::RL];
+            Fft<PL, true>::last_stage1(vl, lds, tw, tid);
+            Fft<PL, true>::last_stage2(vl, out, tid);
+        }
     }
 
     // per-lane: first strict maximum + partial sum
@@ -256,8 +303,12 @@ template <class PL> struct Launch {
                      int n_int) {
         if (n_workers <= 0) return;
         const int groups = (n_bins + 7) / 8;
-        hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE>), dim3(8 * groups * n_workers), dim3(PL::T), 0, st, spectra,
-                           code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int);
+        if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
+            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, true>), dim3(8 * groups * n_workers), dim3(PL::T), 0, st,
+                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int);
+        else
+            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, false>), dim3(8 * groups * n_workers), dim3(PL::T), 0, st,
+                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int);
     }
     static void code_fft(hipStream_t st, const int8_t* code_samples, const cf* tw_fwd, cf* out, int n_codes) {
         hipLaunchKernelGGL(acq_code_fft_kernel<PL>, dim3(n_codes), dim3(PL::T), 0, st, code_samples, tw_fwd, out);

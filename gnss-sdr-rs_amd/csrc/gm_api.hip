@@ -628,6 +628,28 @@ int gm_acq_decide_host(const float* mmax, const uint32_t* margmax, const float* 
     return GM_OK;
 }
 
+// Diagnostic (not in the reference): arm (out == NULL) / read back phase stamps of workgroup 0 of acq_corr_kernel:
+// out = [n_integrations][8 waves][8 phases] shader-clock values of the last search.
+int gm_acq_debug_stamps(gm_acq* a, long long* out) {
+    if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(a->device)) return rc;
+    static long long* d_st = nullptr;
+    const size_t bytes = size_t(a->M) * 64 * sizeof(long long);
+    if (!out) {
+        if (d_st) { gm::set_corr_stamps(nullptr); hipFree(d_st); d_st = nullptr; }
+        HIPC(hipMalloc(&d_st, bytes));
+        HIPC(hipMemset(d_st, 0, bytes));
+        gm::set_corr_stamps(d_st);
+        return GM_OK;
+    }
+    if (!d_st) return set_err(GM_ERR_INVALID_ARG, "stamps not armed");
+    HIPC(hipStreamSynchronize(a->stream));
+    HIPC(hipMemcpy(out, d_st, bytes, hipMemcpyDeviceToHost));
+    gm::set_corr_stamps(nullptr);
+    hipFree(d_st); d_st = nullptr;
+    return GM_OK;
+}
+
 int gm_acq_manager_mode_for(size_t n) { return n == 0 ? 0 : (n <= 4 ? 1 : 2); }   // update_mode :50-56
 
 int gm_acq_manager_pacing_and_list(int mode, uint32_t active, uint64_t* interval_ms, uint32_t* mask) {

@@ -32,6 +32,9 @@ struct PlanOps {
 const PlanOps* find_plan(int n);
 int list_plans(uint32_t* sizes, int cap);
 
+// diagnostic: device buffer [n_int][8 waves][8 phases] of s_memtime stamps written by workgroup 0 of acq_corr_kernel
+void set_corr_stamps(long long* d_ptr);
+
 // elementwise apply_doppler_shift (doppler_shift.rs:25-58)
 void launch_apply_doppler(hipStream_t, const cf* s, const cf* t, cf* out, size_t n);
 // |X|^2 (fft.rs:27-29)

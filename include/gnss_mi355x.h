@@ -170,6 +170,10 @@ int gm_acq_last_timing(gm_acq *a, float *ms_mix_fft, float *ms_corr, float *ms_d
 /* Averages over every gm_acq_search_dev call since timing was enabled (the last 512 at most). */
 int gm_acq_timing_summary(gm_acq *a, uint32_t *launches, float *avg_ms_mix_fft, float *avg_ms_corr);
 
+/* Diagnostic (not in the reference): out == NULL arms, then out = [n_integrations][8][8] int64 shader-clock stamps
+ * of workgroup 0's waves at the phase boundaries of each transform of the last search. */
+int gm_acq_debug_stamps(gm_acq *a, long long *out);
+
 /* AcquisitionManager (do_acquisition.rs:39-74): mode 0 ColdStart / 1 WarmStart / 2 SteadyState. */
 int gm_acq_manager_mode_for(size_t tracked_count);
 int gm_acq_manager_pacing_and_list(int mode, uint32_t active_prn_mask, uint64_t *interval_ms, uint32_t *mask);
