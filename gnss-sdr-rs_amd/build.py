@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgnss_mi355x.so")
 SOURCES = ["acq_kernels.hip", "trk_kernels.hip", "gm_api.hip"]
 HEADERS = ["fft_core.h", "fft_plans.h", "gm_internal.h", os.path.join("..", "..", "include", "gnss_mi355x.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
          "-Wall", "-Wno-unused-function"]
 
 
