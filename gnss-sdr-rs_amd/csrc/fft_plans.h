@@ -11,7 +11,7 @@
 #include "fft_core.h"
 
 namespace gm {
-using Plan8000 = Plan<8000, 512, 20, 20, 20>;
+using Plan8000 = Plan<8000, 512, 25, 20, 16>;
 using Plan16368 = Plan<16368, 576, 33, 31, 16>;   // last pass: 1023 butterflies -> 2 per thread
 using Plan4096 = Plan<4096, 256, 16, 16, 16>;
 using Plan2048 = Plan<2048, 256, 8, 16, 16>;
