@@ -78,6 +78,7 @@ SIGNATURES = {
     "gm_acq_search": (_i, [_vp, _vp, _sz, _i, _u64, _u64, _vp, _vp]),
     "gm_acq_search_c32": (_i, [_vp, _vp, _sz, _u64, _u64, _vp, _vp]),
     "gm_acq_search_i8": (_i, [_vp, _vp, _sz, _u64, _u64, _vp, _vp]),
+    "gm_acq_search_ring": (_i, [_vp, _vp, _u64, _vp, _vp, C.POINTER(_u64)]),
     "gm_acq_search_dev": (_i, [_vp, _vp, _i, _vp]),
     "gm_acq_set_prn_mask": (_i, [_vp, _u64]),
     "gm_acq_decide_dev": (_i, [_vp, _vp, _u32, _vp, _u64]),

@@ -124,6 +124,19 @@ class AcquisitionEngine:
                                   C.cast(res, C.c_void_p), _p(found)), "gm_acq_search")
         return [res[i].as_dict() if found[i] else None for i in range(self.P)]
 
+    def search_ring(self, ring, prn_mask=0xFFFFFFFFFFFFFFFF):
+        """run()'s snapshot + fan-out against the device ring (do_acquisition.rs:297-313): -> (results, local_tail),
+        or (None, None) while the ring holds fewer than M*N samples (:299)."""
+        res = (AcqResult * self.P)()
+        found = np.zeros(self.P, np.uint8)
+        tail = C.c_uint64(0)
+        st = lib().gm_acq_search_ring(self._h, ring._h, int(prn_mask) & (2**64 - 1), C.cast(res, C.c_void_p), _p(found),
+                                      C.byref(tail))
+        if st == -5:
+            return None, None
+        check(st, "gm_acq_search_ring")
+        return [res[i].as_dict() if found[i] else None for i in range(self.P)], tail.value
+
     def metrics(self):
         mx = np.zeros((self.P, self.D), np.float32)
         am = np.zeros((self.P, self.D), np.uint32)

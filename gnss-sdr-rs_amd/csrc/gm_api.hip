@@ -107,6 +107,14 @@ struct Timing {
 
 }  // namespace
 
+// device mirror of MulticastRingBuffer (functions further down)
+struct gm_ring {
+    int device = -1;
+    cf* d_buf = nullptr;
+    size_t size = 0, mask = 0;
+    uint64_t head = 0;
+};
+
 // ====================================================================== acquisition handle
 struct gm_acq {
     int device = -1;
@@ -512,6 +520,34 @@ int gm_acq_search(gm_acq* a, const void* samples, size_t n_samples, int fmt, uin
     return gm_acq_fetch_results(a, a->P, results, found);
 }
 
+// run()'s snapshot + search (do_acquisition.rs:297-313) against the DEVICE ring: the n_integrations*fft_size
+// samples ending at `head` (local_tail = head - M*N) are copied device-to-device (wrap-aware, like
+// copy_to_slice :107-129) and searched; no host round trip of the samples.
+int gm_acq_search_ring(gm_acq* a, gm_ring* ring, uint64_t prn_mask, gm_acq_result* results, uint8_t* found,
+                       uint64_t* local_tail_out) {
+    if (!a || !ring || !results || !found) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (a->device != ring->device) return set_err(GM_ERR_INVALID_ARG, "ring lives on another device");
+    const size_t need = size_t(a->M) * a->N;
+    if (need > ring->size) return set_err(GM_ERR_OUT_OF_RANGE, "ring smaller than num_integrations*fft_size");
+    if ((int64_t)(ring->head - need) < 0) return set_err(GM_ERR_OUT_OF_RANGE, "not enough samples yet (head < M*N)");   // :299
+    if (int rc = ensure_device(a->device)) return rc;
+    const uint64_t local_tail = ring->head - need;
+    const size_t ps = size_t(local_tail & ring->mask);
+    cf* dst = static_cast<cf*>(a->d_samples);
+    if (ps + need <= ring->size) {
+        HIPC(hipMemcpyAsync(dst, ring->d_buf + ps, need * 8, hipMemcpyDeviceToDevice, a->stream));
+    } else {
+        const size_t first = ring->size - ps;
+        HIPC(hipMemcpyAsync(dst, ring->d_buf + ps, first * 8, hipMemcpyDeviceToDevice, a->stream));
+        HIPC(hipMemcpyAsync(dst + first, ring->d_buf, (need - first) * 8, hipMemcpyDeviceToDevice, a->stream));
+    }
+    if (int rc = acq_set_mask(a, prn_mask)) return rc;
+    if (int rc = gm_acq_search_dev(a, a->d_samples, GM_FMT_C32, nullptr)) return rc;
+    if (int rc = gm_acq_decide_dev(a, nullptr, a->P, nullptr, local_tail)) return rc;
+    if (local_tail_out) *local_tail_out = local_tail;
+    return gm_acq_fetch_results(a, a->P, results, found);
+}
+
 int gm_acq_search_c32(gm_acq* a, const gm_c32* s, size_t n, uint64_t tail, uint64_t mask, gm_acq_result* r, uint8_t* f) {
     return gm_acq_search(a, s, n, GM_FMT_C32, tail, mask, r, f);
 }
@@ -670,13 +706,7 @@ int gm_acq_manager_pacing_and_list(int mode, uint32_t active, uint64_t* interval
 
 }  // extern "C"
 
-// ====================================================================== ring mirror
-struct gm_ring {
-    int device = -1;
-    cf* d_buf = nullptr;
-    size_t size = 0, mask = 0;
-    uint64_t head = 0;
-};
+// ====================================================================== ring mirror (struct gm_ring is defined above)
 
 extern "C" {
 
@@ -925,6 +955,9 @@ int gm_trk_start(gm_trk* t, uint32_t ch, const gm_acq_result* r) {   // :148-154
     s.code_phase = r->code_phase_chips;
     s.next_sample_index = r->sample_global_index;
     s.active = 1;
+    // FIXED: sample_global_index already points at the code start, so the replica starts at chip 0 (the reference
+    // passes the acquisition delay in chips AND the aligned sample index)
+    if (t->cfg.code_index_mode == GM_CODE_INDEX_FIXED) s.code_phase = 0.0f;
     if (t->cfg.code_index_mode == GM_CODE_INDEX_FIXED && s.code_rate == 0.0f)
         s.code_rate = t->dc.nominal_code_rate;   // FIXED: undo reset()'s code_rate = 0 (reference bug)
     return gm_trk_set_state(t, ch, &s);

@@ -117,6 +117,18 @@ public:
         for (uint32_t i = 0; i < n_prn_; ++i) if (f[i]) out[i] = r[i];
         return out;
     }
+    // run()'s snapshot + fan-out against the device ring (:297-313); nullopt while head < M*N (:299)
+    std::optional<std::vector<std::optional<AcquisitionResult>>> search_ring(gm_ring* ring, uint64_t prn_mask = ~0ull,
+                                                                             uint64_t* local_tail = nullptr) {
+        std::vector<gm_acq_result> r(n_prn_);
+        std::vector<uint8_t> f(n_prn_);
+        const int st = gm_acq_search_ring(h_, ring, prn_mask, r.data(), f.data(), local_tail);
+        if (st == GM_ERR_OUT_OF_RANGE) return std::nullopt;
+        check(st, "search_ring");
+        std::vector<std::optional<AcquisitionResult>> out(n_prn_);
+        for (uint32_t i = 0; i < n_prn_; ++i) if (f[i]) out[i] = r[i];
+        return out;
+    }
     std::vector<std::optional<AcquisitionResult>> search_i8(const std::vector<int8_t>& iq_interleaved, uint64_t local_tail,
                                                             uint64_t prn_mask = ~0ull) {
         std::vector<gm_acq_result> r(n_prn_);

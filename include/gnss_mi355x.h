@@ -135,6 +135,13 @@ int gm_acq_search_c32(gm_acq *a, const gm_c32 *samples, size_t n_samples, uint64
 int gm_acq_search_i8(gm_acq *a, const int8_t *iq_interleaved, size_t n_samples, uint64_t local_tail,
                      uint64_t prn_mask, gm_acq_result *results, uint8_t *found);
 
+/* run()'s snapshot + fan-out (do_acquisition.rs:297-313) against the device ring mirror: searches the
+ * n_integrations*fft_size samples ending at the ring's head (device-to-device, wrap-aware); *local_tail_out =
+ * head - M*N.  GM_ERR_OUT_OF_RANGE while head < M*N (the reference skips the round, :299). */
+typedef struct gm_ring gm_ring;
+int gm_acq_search_ring(gm_acq *a, gm_ring *ring, uint64_t prn_mask, gm_acq_result *results, uint8_t *found,
+                       uint64_t *local_tail_out);
+
 /* Device-resident form: samples already in HBM; kernels are enqueued on the handle's stream and the
  * call returns without synchronising.  d_metrics (optional, may be NULL -> internal buffer) receives
  * 3*n_prn*n_bins 32-bit words: max f32 [P][D], argmax u32 [P][D], sum f32 [P][D]. */
@@ -181,7 +188,6 @@ int gm_acq_manager_pacing_and_list(int mode, uint32_t active_prn_mask, uint64_t 
 /* ------------------------------------------------------------------ MulticastRingBuffer device mirror
  * (src/utilities/multicast_ring_buffer.rs:36-130): power-of-two ring of Complex32 addressed by the
  * absolute sample index `head`; the mirror keeps the same bytes in HBM for the tracking kernels. */
-typedef struct gm_ring gm_ring;
 int gm_ring_create(size_t buf_size, gm_ring **out);                      /* ::new :46-61 */
 int gm_ring_destroy(gm_ring *r);
 int gm_ring_write_samples(gm_ring *r, const gm_c32 *samples, size_t n);  /* :66-101 */
@@ -232,7 +238,9 @@ typedef struct gm_trk gm_trk;
 
 int gm_trk_create(const gm_trk_cfg *cfg, gm_trk **out);   /* TrackingManager::new :336-348 + Channel::new :118-146 */
 int gm_trk_destroy(gm_trk *t);
-int gm_trk_start(gm_trk *t, uint32_t ch, const gm_acq_result *r);      /* TrackingChannel::start :148-154 */
+/* TrackingChannel::start :148-154.  FIXED mode starts code_phase at 0 (sample_global_index is already the code
+ * start) and restores the nominal code_rate after a reset(); FAITHFUL copies code_phase_chips like the reference. */
+int gm_trk_start(gm_trk *t, uint32_t ch, const gm_acq_result *r);
 int gm_trk_reset(gm_trk *t, uint32_t ch);                              /* ::reset :311-327 */
 int gm_trk_get_state(gm_trk *t, uint32_t ch, gm_trk_state *out);
 int gm_trk_set_state(gm_trk *t, uint32_t ch, const gm_trk_state *in);

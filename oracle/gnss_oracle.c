@@ -535,6 +535,9 @@ void orc_trk_start(orc_trk_channel *c, const orc_acq_result *r) { /* :148-154 */
     c->carrier_freq = r->carrier_freq;
     c->code_phase = r->code_phase_chips;
     c->next_sample_index = r->sample_global_index;
+    /* FIXED (our documented deviation): sample_global_index already points at the code start,
+     * so the replica starts at chip 0; FAITHFUL copies the acquisition delay like the reference */
+    if (c->code_index_mode == ORC_CODE_INDEX_FIXED) c->code_phase = 0.0f;
     c->state = ORC_STATE_TRACKING;
     c->state_prn = r->prn;
 }

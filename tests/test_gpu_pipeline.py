@@ -1,0 +1,59 @@
+"""End-to-end on the GPU: samples -> device ring -> acquisition on a ring snapshot (do_acquisition.rs:297-313) ->
+AcquisitionResult -> TrackingChannel::start -> process_channels on the same ring (do_tracking.rs:351-371), i.e. the
+two stages of src/main.rs:204-227 chained through the reference's own message types.  FIXED code indexing (the
+FAITHFUL mode correlates PRN p against PRN p+1's code and cannot hold lock on a real signal)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_acquire_then_track_from_device_ring(gpu, oracle):
+    from gnss_sdr_rs_amd import acquisition as A, tracking as T, synth
+    t = oracle.ca_code_table()
+    fs, N, M, n_ms = 4_096_000.0, 4096, 10, 75
+    truth = {4: (-1730.0, 1111), 11: (640.0, 4000), 23: (2210.0, 77), 30: (-420.0, 2500)}
+    sats = [dict(prn=p, prn_row=p - 1, cn0_dbhz=49.0, doppler_hz=d, code_start=c, phase=0.1 * p) for p, (d, c) in truth.items()]
+    x = synth.to_c32(synth.make_scene(t, fs, 0.0, n_ms * N, sats, config_id=61))
+    ring = T.MulticastRingBuffer(1 << 19)
+    dop = np.arange(-2500.0, 2500.1, 100.0, dtype=np.float32)          # fine grid: the PLL pulls in from <= 50 Hz
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, n_integrations=M)
+    # not enough samples yet: the reference skips the round (:299)
+    ring.write_samples(x[:5 * N])
+    assert eng.search_ring(ring) == (None, None)
+    ring.write_samples(x[5 * N:12 * N])
+    res, local_tail = eng.search_ring(ring)
+    assert local_tail == 2 * N                                            # head - M*N
+    found = {r["prn"]: r for r in res if r}
+    assert set(found) == set(truth)
+    # identical to searching the same samples through the host-buffer entry
+    assert eng.search(x[2 * N:12 * N], local_tail=local_tail) == res
+    mx, am, sm = eng.metrics()
+    mgr = T.TrackingManager(fs, n_channels=6, code_index_mode=T.CODE_INDEX_FIXED)
+    for i, (prn, r) in enumerate(sorted(found.items())):
+        assert r["code_phase_samples"] == truth[prn][1] and r["sample_global_index"] == local_tail + truth[prn][1]
+        best = int(np.argmax(mx[prn - 1]))                                # strongest bin (the early exit may stop earlier)
+        assert abs(dop[best] - truth[prn][0]) <= 50.0
+        r = dict(r, carrier_freq=float(eng.table_freq[best]))
+        mgr.channels[i].start(r)
+        assert mgr.channels[i].is_active()
+    ring.write_samples(x[12 * N:])
+    outs, proc, lost, done = mgr.update_all(ring, 80)
+    assert not lost.any()
+    for i, (prn, r) in enumerate(sorted(found.items())):
+        n_run = int(proc[:, i].sum())
+        assert n_run == (n_ms * N - r["sample_global_index"]) // N        # every whole code period in the ring
+        s = mgr.channels[i].state
+        assert s.active and s.prn == prn and s.lost_counter == 0
+        assert abs(s.carrier_freq - truth[prn][0]) < 15.0                 # PLL settled on the true Doppler
+        assert abs(s.code_rate - 1.023e6) < 30.0
+        ip, qp = outs[:n_run, i, 0], outs[:n_run, i, 1]
+        # carrier phase lock: the prompt energy ends up in I
+        assert np.mean(np.abs(ip[-20:])) > 4.0 * np.mean(np.abs(qp[-20:]))
+        # code lock: early and late envelopes balanced, prompt above both
+        e = np.hypot(outs[n_run - 20:n_run, i, 2], outs[n_run - 20:n_run, i, 3]).mean()
+        l = np.hypot(outs[n_run - 20:n_run, i, 4], outs[n_run - 20:n_run, i, 5]).mean()
+        p = np.hypot(ip[-20:], qp[-20:]).mean()
+        assert abs(e - l) < 0.2 * p and p > e and p > l
+    assert not proc[:, 4:].any()
+    mgr.close(); eng.close(); ring.close()
