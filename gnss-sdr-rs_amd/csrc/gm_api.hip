@@ -908,7 +908,7 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
         const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
         const int nv = 2 * d.n_arms;
         int g = 1;
-        while (g * 2 <= 16 && size_t(g) * 2 * t->C <= size_t(cus) && g * 2 * nv <= 256) g *= 2;
+        while (g * 2 <= 32 && size_t(g) * 2 * t->C <= size_t(cus) * gm::TRK_PERSIST_WG_PER_CU && g * 2 * nv <= 256) g *= 2;
         t->G = g;
         const size_t xb = size_t(2) * t->C * g * nv * sizeof(unsigned long long);
         HIPT(hipMalloc(&t->d_xchg, xb));

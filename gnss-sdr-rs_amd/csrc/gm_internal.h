@@ -77,6 +77,12 @@ void launch_trk_epoch(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_t
                       const TrkSrc&, int slices, float* d_partials, uint8_t* d_ready, int mode,
                       gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost, uint8_t* d_lost_prn);
 
+// Persistent tracking geometry: workgroups of TRK_PERSIST_THREADS lanes, TRK_PERSIST_WG_PER_CU of them per CU.
+// Two independent workgroups per CU let one channel's serial exchange + loop-filter epilogue (one wave) overlap
+// the other's correlation phase.
+constexpr int TRK_PERSIST_THREADS = 512;
+constexpr int TRK_PERSIST_WG_PER_CU = 2;
+
 // persistent multi-epoch tracking (one launch = `epochs` passes over all channels); G workgroups per channel
 void launch_trk_persistent(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_trk_state* d_states,
                            const cf* ring, uint64_t mask, uint64_t head, int G, int epochs, uint32_t tag_base,

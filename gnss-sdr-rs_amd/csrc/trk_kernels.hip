@@ -388,9 +388,9 @@ __device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t hea
     sh.fast = fast_code_range(sh.ec, n) ? 1 : 0;
 }
 
-template <int ARMS, int MODE_T, int BOC_T>
-__global__ __launch_bounds__(1024) void trk_persistent_kernel(TrkPersistArgs a) {
-    constexpr int NV = 2 * ARMS, T = 1024, NW = T / 64, KPF = 4;
+template <int ARMS, int MODE_T, int BOC_T, int T>
+__global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
+    constexpr int NV = 2 * ARMS, NW = T / 64, KPF = 4;
     const TrkDevCfg& cfg = a.cfg;
     const int ch = blockIdx.x / a.G, g = blockIdx.x % a.G, tid = threadIdx.x;
     const int C = cfg.n_channels;
@@ -597,15 +597,16 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     const dim3 grid(cfg.n_channels * G);
     // compile-time arms / code-index mode / BOC: straight-line sample code
     const int key = (cfg.n_arms == 5 ? 4 : 0) | (cfg.code_index_mode == GM_CODE_INDEX_FIXED ? 2 : 0) | (cfg.boc11 ? 1 : 0);
+    constexpr int T = TRK_PERSIST_THREADS;
     switch (key) {
-        case 0: hipLaunchKernelGGL((trk_persistent_kernel<3, 0, 0>), grid, dim3(1024), lds, st, a); break;
-        case 1: hipLaunchKernelGGL((trk_persistent_kernel<3, 0, 1>), grid, dim3(1024), lds, st, a); break;
-        case 2: hipLaunchKernelGGL((trk_persistent_kernel<3, 1, 0>), grid, dim3(1024), lds, st, a); break;
-        case 3: hipLaunchKernelGGL((trk_persistent_kernel<3, 1, 1>), grid, dim3(1024), lds, st, a); break;
-        case 4: hipLaunchKernelGGL((trk_persistent_kernel<5, 0, 0>), grid, dim3(1024), lds, st, a); break;
-        case 5: hipLaunchKernelGGL((trk_persistent_kernel<5, 0, 1>), grid, dim3(1024), lds, st, a); break;
-        case 6: hipLaunchKernelGGL((trk_persistent_kernel<5, 1, 0>), grid, dim3(1024), lds, st, a); break;
-        default: hipLaunchKernelGGL((trk_persistent_kernel<5, 1, 1>), grid, dim3(1024), lds, st, a); break;
+        case 0: hipLaunchKernelGGL((trk_persistent_kernel<3, 0, 0, T>), grid, dim3(T), lds, st, a); break;
+        case 1: hipLaunchKernelGGL((trk_persistent_kernel<3, 0, 1, T>), grid, dim3(T), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((trk_persistent_kernel<3, 1, 0, T>), grid, dim3(T), lds, st, a); break;
+        case 3: hipLaunchKernelGGL((trk_persistent_kernel<3, 1, 1, T>), grid, dim3(T), lds, st, a); break;
+        case 4: hipLaunchKernelGGL((trk_persistent_kernel<5, 0, 0, T>), grid, dim3(T), lds, st, a); break;
+        case 5: hipLaunchKernelGGL((trk_persistent_kernel<5, 0, 1, T>), grid, dim3(T), lds, st, a); break;
+        case 6: hipLaunchKernelGGL((trk_persistent_kernel<5, 1, 0, T>), grid, dim3(T), lds, st, a); break;
+        default: hipLaunchKernelGGL((trk_persistent_kernel<5, 1, 1, T>), grid, dim3(T), lds, st, a); break;
     }
 }
 
