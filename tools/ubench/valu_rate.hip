@@ -31,14 +31,15 @@ __global__ void k(float* out, int iters, long long* cyc) {
 int main() {
     float* out; long long* cyc; hipMalloc(&out, 1 << 22); hipMalloc(&cyc, 8);
     const int iters = 2000;
-    for (int kind = 0; kind < 3; ++kind)
-        for (int threads : {64, 256, 512, 1024}) {     // 1 block per CU: waves/SIMD = threads/256 (min 1 wave on 1 SIMD)
+    for (int nblk : {256, 1})
+    for (int kind = 0; kind < 2; ++kind)
+        for (int threads : {256, 1024}) {     // 1 block per CU: waves/SIMD = threads/256 (min 1 wave on 1 SIMD)
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             for (int rep = 0; rep < 2; ++rep) {
                 if (rep == 1) hipEventRecord(e0, 0);
-                if (kind == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, out, iters, cyc);
-                if (kind == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, out, iters, cyc);
-                if (kind == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(threads), 0, 0, out, iters, cyc);
+                if (kind == 0) hipLaunchKernelGGL(k<0>, dim3(nblk), dim3(threads), 0, 0, out, iters, cyc);
+                if (kind == 1) hipLaunchKernelGGL(k<1>, dim3(nblk), dim3(threads), 0, 0, out, iters, cyc);
+                if (kind == 2) hipLaunchKernelGGL(k<2>, dim3(nblk), dim3(threads), 0, 0, out, iters, cyc);
                 if (rep == 1) hipEventRecord(e1, 0);
                 hipDeviceSynchronize();
             }
@@ -46,7 +47,7 @@ int main() {
             long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
             const double instr_per_wave = iters * 64.0;
             const double waves_per_simd = threads >= 256 ? threads / 256.0 : 1.0;
-            printf("kind %d threads %4d: %.2f ticks per wave-instr (one wave), %.2f ticks/instr/SIMD; kernel %.3f ms -> %.3f ns per wave-instr per SIMD, tick = %.3f ns\n", kind, threads,
+            printf("blocks %3d kind %d threads %4d: %.2f ticks per wave-instr (one wave), %.2f ticks/instr/SIMD; kernel %.3f ms -> %.3f ns per wave-instr per SIMD, tick = %.3f ns\n", nblk, kind, threads,
                    c / instr_per_wave, c / (instr_per_wave * waves_per_simd), ms, ms * 1e6 / (instr_per_wave * waves_per_simd), ms * 1e6 / c);
         }
     return 0;
