@@ -29,7 +29,8 @@ class AcqCfg(C.Structure):
     _fields_ = [("fs", C.c_float), ("f_if", C.c_float), ("fft_size", C.c_uint32), ("n_integrations", C.c_uint32),
                 ("n_bins", C.c_uint32), ("doppler_hz", C.c_void_p), ("tables", C.c_void_p),
                 ("table_freq", C.c_void_p), ("n_prn", C.c_uint32), ("prn_ids", C.c_void_p), ("codes", C.c_void_p),
-                ("code_len", C.c_uint32), ("code_rate", C.c_float), ("threshold", C.c_float)]
+                ("code_len", C.c_uint32), ("code_rate", C.c_float), ("threshold", C.c_float),
+                ("decision_mode", C.c_int32)]
 
 
 class TrkState(C.Structure):

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(64) void decide_kernel(DecideArgs a) {
         for (int d = 0; d < D; ++d) {                      // ascending Doppler (:171)
             const float lm = smax[d];
             if (lm > gmax) { gmax = lm; bphase = sarg[d]; bsum = ssum[d]; bbin = d; }
+            if (a.best_bin_mode && d + 1 < D) continue;      // strongest-bin mode: test once, after the last bin
             const float avg = __fdiv_rn(bsum - gmax, nm1);  // (sum - max) / (N-1)  (:236)
             if (__fdiv_rn(gmax, avg) > a.threshold) {       // max/avg > 7.0       (:237)
                 r.code_phase_samples = bphase;

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -112,7 +113,9 @@ struct gm_ring {
     int device = -1;
     cf* d_buf = nullptr;
     size_t size = 0, mask = 0;
-    uint64_t head = 0;
+    // single writer / many readers like the reference ring: the writer publishes `head` (release) after its
+    // synchronous H2D copy, readers load it (acquire) before launching kernels on the mirror
+    std::atomic<uint64_t> head{0};
 };
 
 // ====================================================================== acquisition handle
@@ -477,6 +480,7 @@ int gm_acq_decide_dev(gm_acq* a, const void* d_metrics, uint32_t n_prn, const ui
     da.mask_lo = (d_metrics && n_prn != a->P) ? ~0ull : a->mask;
     da.n_prn = int(n_prn); da.n_bins = int(a->D); da.fft_size = int(a->N);
     da.fs = a->cfg.fs; da.threshold = a->cfg.threshold; da.code_rate = a->code_rate;
+    da.best_bin_mode = a->cfg.decision_mode == GM_DECIDE_BEST_BIN ? 1 : 0;
     da.local_tail = local_tail;
     da.results = a->d_results; da.found = a->d_found;
     gm::launch_decide(a->stream, da);
@@ -529,9 +533,10 @@ int gm_acq_search_ring(gm_acq* a, gm_ring* ring, uint64_t prn_mask, gm_acq_resul
     if (a->device != ring->device) return set_err(GM_ERR_INVALID_ARG, "ring lives on another device");
     const size_t need = size_t(a->M) * a->N;
     if (need > ring->size) return set_err(GM_ERR_OUT_OF_RANGE, "ring smaller than num_integrations*fft_size");
-    if ((int64_t)(ring->head - need) < 0) return set_err(GM_ERR_OUT_OF_RANGE, "not enough samples yet (head < M*N)");   // :299
+    const uint64_t head = ring->head.load(std::memory_order_acquire);
+    if ((int64_t)(head - need) < 0) return set_err(GM_ERR_OUT_OF_RANGE, "not enough samples yet (head < M*N)");   // :299
     if (int rc = ensure_device(a->device)) return rc;
-    const uint64_t local_tail = ring->head - need;
+    const uint64_t local_tail = head - need;
     const size_t ps = size_t(local_tail & ring->mask);
     cf* dst = static_cast<cf*>(a->d_samples);
     if (ps + need <= ring->size) {
@@ -736,7 +741,8 @@ int gm_ring_write_samples(gm_ring* r, const gm_c32* s, size_t n) {
     if (!r || (!s && n)) return set_err(GM_ERR_INVALID_ARG, "null pointer");
     if (n > r->size) return set_err(GM_ERR_OUT_OF_RANGE, "write larger than the ring");
     if (int rc = ensure_device(r->device)) return rc;
-    const size_t start = size_t(r->head & r->mask);
+    const uint64_t cur = r->head.load(std::memory_order_relaxed);
+    const size_t start = size_t(cur & r->mask);
     if (start + n <= r->size) {
         HIPC(hipMemcpy(r->d_buf + start, s, n * 8, hipMemcpyHostToDevice));
     } else {
@@ -744,13 +750,13 @@ int gm_ring_write_samples(gm_ring* r, const gm_c32* s, size_t n) {
         HIPC(hipMemcpy(r->d_buf + start, s, first * 8, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(r->d_buf, s + first, (n - first) * 8, hipMemcpyHostToDevice));
     }
-    r->head += n;
+    r->head.store(cur + n, std::memory_order_release);
     return GM_OK;
 }
 
 int gm_ring_get_head(gm_ring* r, uint64_t* head) {
     if (!r || !head) return set_err(GM_ERR_INVALID_ARG, "null pointer");
-    *head = r->head;
+    *head = r->head.load(std::memory_order_acquire);
     return GM_OK;
 }
 
@@ -1056,7 +1062,7 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
         const size_t o = size_t(e0) * t->C;
         t->launch_seq = (t->launch_seq + 1) & 0xfffffu;
         if (t->launch_seq == 0) t->launch_seq = 1;
-        gm::launch_trk_persistent(t->stream, t->dc, t->d_codes, t->d_states, ring->d_buf, ring->mask, ring->head, t->G,
+        gm::launch_trk_persistent(t->stream, t->dc, t->d_codes, t->d_states, ring->d_buf, ring->mask, ring->head.load(std::memory_order_acquire), t->G,
                                   int(ne), t->launch_seq << 12, t->d_xchg, t->d_outs + o, t->d_proc + o, t->d_lost + o,
                                   t->d_lostprn + o, t->d_error, (t->d_stamps && e0 == 0 && ne <= t->stamps_cap) ? t->d_stamps : nullptr);
     }

@@ -48,6 +48,7 @@ struct DecideArgs {
     uint64_t mask_lo;                                               // worker i searched <-> bit i (i < 64), else all
     int n_prn, n_bins, fft_size;
     float fs, threshold, code_rate;
+    int best_bin_mode;                                              // 0: reference early exit, 1: strongest bin
     uint64_t local_tail;
     gm_acq_result* results; uint8_t* found;                         // [n_prn]
 };

@@ -3,9 +3,15 @@
 // reference (file:line in the comments) so call sites port one to one; errors the reference turns into panics
 // become gnss::Panic exceptions HERE (above the ABI — nothing unwinds across it).
 #pragma once
+#include <atomic>
+#include <chrono>
 #include <complex>
+#include <deque>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdint>
+#include <cmath>
 #include <optional>
 #include <set>
 #include <stdexcept>
@@ -78,8 +84,10 @@ class AcquisitionEngine {
     uint32_t n_prn_ = 0;
 public:
     AcquisitionEngine(float fs, float f_if, uint32_t fft_size, const std::vector<float>& doppler_hz,
-                      const std::vector<uint8_t>& prn_ids, uint32_t n_integrations = 10, float threshold = 7.0f) {
+                      const std::vector<uint8_t>& prn_ids, uint32_t n_integrations = 10, float threshold = 7.0f,
+                      int decision_mode = GM_DECIDE_REFERENCE) {
         gm_acq_cfg c{};
+        c.decision_mode = decision_mode;
         c.fs = fs; c.f_if = f_if; c.fft_size = fft_size; c.n_integrations = n_integrations;
         c.n_bins = uint32_t(doppler_hz.size()); c.doppler_hz = doppler_hz.data();
         c.n_prn = uint32_t(prn_ids.size()); c.prn_ids = prn_ids.data(); c.threshold = threshold;
@@ -234,6 +242,109 @@ public:
         return done;
     }
 };
+
+// ---- the two stage drivers: do_acquisition::run (do_acquisition.rs:241-327) and
+// do_tracking::run (do_tracking.rs:384-415), talking through the reference's two unbounded channels
+// (main.rs:183-184).  The reference loops forever; here a StageControl stops the loops and can scale the pacing.
+template <class T> class Channel {           // crossbeam_channel::unbounded()
+    std::deque<T> q_;
+    mutable std::mutex m_;
+public:
+    bool send(T v) { std::lock_guard<std::mutex> g(m_); q_.push_back(std::move(v)); return true; }
+    std::optional<T> try_recv() {
+        std::lock_guard<std::mutex> g(m_);
+        if (q_.empty()) return std::nullopt;
+        T v = std::move(q_.front()); q_.pop_front();
+        return v;
+    }
+    size_t len() const { std::lock_guard<std::mutex> g(m_); return q_.size(); }
+};
+
+struct StageControl {
+    std::atomic<bool> stop{false};
+    double pacing_scale = 1.0;            // 1.0 = the reference's 500 / 1000 / 2000 ms search intervals (:59-63)
+    std::atomic<uint64_t> acq_rounds{0}, trk_passes{0};
+};
+
+struct AcquisitionRunOptions {            // the reference's compile-time constants (:20-23) as run-time values
+    float freq_search_hz = 14e3f;         // FREQ_SEARCH_ACQUISITION_HZ
+    float freq_step_hz = 500.0f;          // FREQ_SEARCH_STEP_HZ
+    uint32_t long_samples_length = 10;    // LONG_SAMPLES_LENGTH (ms)
+    int decision_mode = GM_DECIDE_REFERENCE;
+};
+
+inline void run_acquisition(MulticastRingBuffer& multi_buffer, float freq_sampling_hz, float f_if,
+                            Channel<AcquisitionResult>& to_tracking, Channel<TrackingMessage>& from_tracking,
+                            StageControl& ctl, const AcquisitionRunOptions& opt = {}) {
+    const size_t capacity = size_t(uint16_t(opt.freq_search_hz) / uint16_t(opt.freq_step_hz)) + 1;        // :248
+    const uint32_t fft_size = uint32_t(std::lround(freq_sampling_hz / (1.023e6f / 1023.0f)));              // :249-251
+    std::vector<float> doppler(capacity);
+    for (size_t i = 0; i < capacity; ++i) doppler[i] = -opt.freq_search_hz / 2.0f + float(i) * opt.freq_step_hz;   // :253-255
+    std::vector<uint8_t> prns(PRN_SEARCH_ACQUISITION_TOTAL);
+    for (uint8_t p = 0; p < PRN_SEARCH_ACQUISITION_TOTAL; ++p) prns[p] = uint8_t(p + 1);
+    AcquisitionEngine workers(freq_sampling_hz, f_if, fft_size, doppler, prns, opt.long_samples_length, 7.0f,
+                              opt.decision_mode);                                                            // :252-271
+    std::set<uint8_t> active_prns;
+    AcquisitionManager acq_manager;
+    auto last_run = std::chrono::steady_clock::now();
+    const auto ms = [&](double v) { return std::chrono::duration<double, std::milli>(v * ctl.pacing_scale); };
+    while (!ctl.stop.load()) {
+        while (auto msg = from_tracking.try_recv()) {                                                       // :278-287
+            if (msg->kind == TrackingMessageKind::SatelliteLost) active_prns.erase(msg->prn);
+            else active_prns.insert(msg->prn);
+        }
+        acq_manager.update_mode(active_prns.size());                                                        // :289
+        auto [interval_ms, mask] = acq_manager.get_pacing_and_list(active_prns);                            // :290
+        if (std::chrono::steady_clock::now() - last_run < ms(double(interval_ms))) {                        // :292-295
+            std::this_thread::sleep_for(ms(50.0));
+            continue;
+        }
+        uint64_t local_tail = 0;
+        auto results = workers.search_ring(multi_buffer.handle(), uint64_t(mask), &local_tail);             // :297-313
+        if (!results) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }              // :324-326
+        for (auto& r : *results)                                                                            // :315-320
+            if (r && to_tracking.send(*r)) active_prns.insert(r->prn);
+        last_run = std::chrono::steady_clock::now();                                                        // :322
+        ctl.acq_rounds++;
+    }
+}
+
+inline void run_tracking(MulticastRingBuffer& multi_ring_buf, Channel<AcquisitionResult>& acq_to_trk,
+                         Channel<TrackingMessage>& trk_to_acq, float fs, StageControl& ctl,
+                         int code_index_mode = GM_CODE_INDEX_FIXED, uint32_t n_channels = 15,
+                         std::vector<gm_trk_state>* final_states = nullptr) {
+    TrackingManager manager(fs, n_channels, code_index_mode);                                               // :390
+    std::vector<uint8_t> channel_prn(n_channels, 0), lost;
+    constexpr uint32_t LOOP_MS = 10;                                                                        // :29
+    while (!ctl.stop.load()) {
+        // process_channels (:351-371): hand new acquisitions to idle channels ...
+        while (auto msg = acq_to_trk.try_recv()) {
+            for (uint32_t c = 0; c < n_channels; ++c) {
+                if (!manager.channels[c].is_active()) {
+                    trk_to_acq.send(TrackingMessage{TrackingMessageKind::SatelliteLocked, msg->prn});
+                    manager.channels[c].start(*msg);
+                    channel_prn[c] = msg->prn;
+                    break;
+                }
+            }
+        }
+        // ... then every active channel with a whole code period available runs update(), up to LOOP_MS passes
+        const uint32_t done = manager.process_channels(multi_ring_buf, LOOP_MS, nullptr, nullptr, &lost);
+        for (uint32_t e = 0; e < LOOP_MS; ++e)
+            for (uint32_t c = 0; c < n_channels; ++c)
+                if (lost[size_t(e) * n_channels + c]) {
+                    // the reference's message carries prn 0 (reset() runs first, :199-201); FIXED reports the real one
+                    const uint8_t prn = code_index_mode == GM_CODE_INDEX_FAITHFUL ? uint8_t(0) : channel_prn[c];
+                    trk_to_acq.send(TrackingMessage{TrackingMessageKind::SatelliteLost, prn});
+                }
+        ctl.trk_passes += done;
+        if (done == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));   // Condvar wait (:392-406)
+    }
+    if (final_states) {
+        final_states->resize(n_channels);
+        for (uint32_t c = 0; c < n_channels; ++c) (*final_states)[c] = manager.channels[c].state();
+    }
+}
 
 // ---- crate root FFT<T> / RealFFT<T> (src/fft.rs:5-56), T = f32
 class FFT {

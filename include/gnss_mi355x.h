@@ -113,7 +113,12 @@ typedef struct {
     uint32_t code_len;         /* chips per period of `codes` (ignored when NULL: 1023) */
     float code_rate;           /* chips/s of `codes` (ignored when NULL: 1.023e6) */
     float threshold;           /* is_good_satellite ratio, 7.0 (:237); 0 -> 7.0 */
+    int32_t decision_mode;     /* GM_DECIDE_REFERENCE (0): first ascending bin whose running best passes the ratio test
+                                  (the reference's early exit, :211-222).  GM_DECIDE_BEST_BIN (1): strongest bin of the
+                                  whole grid, reported if IT passes the ratio test — not the reference's behaviour; for
+                                  callers that hand the carrier to a PLL (a strong signal passes the test 1-2 kHz early) */
 } gm_acq_cfg;
+typedef enum { GM_DECIDE_REFERENCE = 0, GM_DECIDE_BEST_BIN = 1 } gm_decision_mode;
 
 typedef struct gm_acq gm_acq;
 

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 #include "gnss_sdr.hpp"
 
@@ -124,6 +125,55 @@ static int test_acquisition_with_synthetic_data() {
     return 0;
 }
 
+// The live receiver path of src/main.rs:204-227: a feeder thread (the RF stage's 2048-sample block pump,
+// rf_thread.rs:12-59) + do_acquisition::run + do_tracking::run on their own threads, talking through the two channels.
+static int test_receiver_threads() {
+    const float fs = 4096000.0f;
+    const int n_ms = 260;
+    struct Sat { uint8_t prn; float dop; int start; };
+    const Sat sats[] = {{4, -1730.0f, 1111}, {11, 640.0f, 4000}, {23, 2210.0f, 77}};
+    std::vector<Complex32> x(size_t(4096) * n_ms, Complex32(0.f, 0.f));
+    for (const Sat& s : sats) {
+        auto one = synth(s.prn, s.dop, fs, n_ms, s.start, 3.0f, 0.0f);
+        for (size_t i = 0; i < x.size(); ++i) x[i] += one[i];
+    }
+    uint64_t st = 12345;
+    for (auto& v : x) v += Complex32(float(16.0 * gauss(st)), float(16.0 * gauss(st)));   // C/N0 ~ 48.6 dB-Hz each
+    MulticastRingBuffer ring(1 << 21);
+    Channel<AcquisitionResult> acq_to_trk;
+    Channel<TrackingMessage> trk_to_acq;
+    StageControl ctl;
+    ctl.pacing_scale = 0.02;     // 500 ms cold-start interval -> 10 ms, so the test lasts a fraction of a second
+    AcquisitionRunOptions opt;
+    opt.freq_search_hz = 6000.0f; opt.freq_step_hz = 100.0f;   // fine grid + strongest bin: the PLL pulls in from <= 50 Hz
+    opt.decision_mode = GM_DECIDE_BEST_BIN;
+    std::vector<gm_trk_state> finals;
+    std::thread t_acq([&] { init(0); run_acquisition(ring, fs, 0.0f, acq_to_trk, trk_to_acq, ctl, opt); });
+    std::thread t_trk([&] { init(0); run_tracking(ring, acq_to_trk, trk_to_acq, fs, ctl, GM_CODE_INDEX_FIXED, 15, &finals); });
+    for (size_t off = 0; off < x.size(); off += 2048) {           // the block pump, ~1 ms of signal per ms of wall time x 4
+        ring.write_samples(std::vector<Complex32>(x.begin() + off, x.begin() + off + 2048));
+        std::this_thread::sleep_for(std::chrono::microseconds(120));
+    }
+    for (int i = 0; i < 400 && ctl.trk_passes.load() < 120; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    ctl.stop = true;
+    t_acq.join(); t_trk.join();
+    CHECK(ctl.acq_rounds.load() >= 1);
+    int locked = 0;
+    for (const Sat& s : sats) {
+        bool ok = false;
+        for (const auto& c : finals)
+            if (c.active && c.prn == s.prn && std::fabs(c.carrier_freq - s.dop) < 25.0f && c.lost_counter == 0) ok = true;
+        if (!ok) std::printf("  PRN %d not locked\n", int(s.prn));
+        locked += ok;
+    }
+    CHECK(locked == 3);
+    int active = 0;
+    for (const auto& c : finals) active += c.active != 0;
+    CHECK(active == 3);                                            // nothing else was handed to tracking
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const bool cpu_only = argc > 1 && !std::strcmp(argv[1], "--cpu-only");
     int rc = test_acquisition_manager();
@@ -133,5 +183,6 @@ int main(int argc, char** argv) {
     rc |= test_multicast_ring_buffer();            std::printf("test_multicast_ring_buffer %s\n", rc ? "FAILED" : "ok");
     rc |= test_pll_frequency_pull_in();            std::printf("test_pll_frequency_pull_in %s\n", rc ? "FAILED" : "ok");
     rc |= test_acquisition_with_synthetic_data();  std::printf("test_acquisition_with_synthetic_data %s\n", rc ? "FAILED" : "ok");
+    rc |= test_receiver_threads();                 std::printf("test_receiver_threads %s\n", rc ? "FAILED" : "ok");
     return rc;
 }

@@ -14,7 +14,7 @@ def _build(gm):
     libdir = os.path.dirname(gm.library_path())
     cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "gnss-sdr-rs_amd", "host"),
            os.path.join(ROOT, "tests", "cpp", "test_host_api.cpp"), "-o", exe, "-L", libdir, "-lgnss_mi355x",
-           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-pthread"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     return exe
@@ -31,5 +31,6 @@ def test_cpp_host_api_gpu(gm):
     exe = _build(gm)
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0, r.stdout
-    for name in ("test_multicast_ring_buffer", "test_pll_frequency_pull_in", "test_acquisition_with_synthetic_data"):
+    for name in ("test_multicast_ring_buffer", "test_pll_frequency_pull_in", "test_acquisition_with_synthetic_data",
+                 "test_receiver_threads"):
         assert name + " ok" in r.stdout, r.stdout

@@ -57,3 +57,25 @@ def test_acquire_then_track_from_device_ring(gpu, oracle):
         assert abs(e - l) < 0.2 * p and p > e and p > l
     assert not proc[:, 4:].any()
     mgr.close(); eng.close(); ring.close()
+
+
+def test_best_bin_decision_mode(gpu, oracle):
+    """GM_DECIDE_BEST_BIN (not the reference's early exit): the strongest bin of the grid is reported when it passes
+    the ratio test; GM_DECIDE_REFERENCE on the same metrics stops at the first passing bin."""
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    t = oracle.ca_code_table()
+    fs, N, M = 4_096_000.0, 4096, 4
+    sats = [dict(prn_row=6, cn0_dbhz=55.0, doppler_hz=1210.0, code_start=321)]
+    x = synth.to_c32(synth.make_scene(t, fs, 0.0, M * N, sats, config_id=62))
+    dop = np.arange(-2500.0, 2500.1, 100.0, dtype=np.float32)
+    ref = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=[7, 8], n_integrations=M)
+    best = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=[7, 8], n_integrations=M, decision_mode=1)
+    r_ref, r_best = ref.search(x), best.search(x)
+    mx, am, sm = best.metrics()
+    assert r_ref[1] is None and r_best[1] is None
+    b = int(np.argmax(mx[0]))
+    assert r_best[0]["doppler_bin"] == b and abs(dop[b] - 1210.0) <= 50.0 and r_best[0]["code_phase_samples"] == 321
+    assert r_best[0]["mag_relative"] == mx[0, b] and r_best[0]["code_phase_samples"] == am[0, b]
+    # the reference mode stops earlier on this strong signal (a sinc sidelobe already passes peak/mean > 7)
+    assert r_ref[0]["doppler_bin"] < b and r_ref[0]["code_phase_samples"] == 321
+    ref.close(); best.close()
