@@ -62,9 +62,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GM_BENCH_DEBUG_GLOO=1: rehearse the N > 1 code path on ONE GPU (all ranks on cuda:0, gloo exchange through host
+    # memory); RCCL refuses two ranks on one device.  Never used for reported numbers.
+    debug_gloo = os.environ.get("GM_BENCH_DEBUG_GLOO") == "1"
+    if debug_gloo:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if debug_gloo:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -99,7 +107,12 @@ def main():
     def step():
         eng.search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, d_metrics.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(d_gather, d_metrics)        # the path's one exchange step
+            if debug_gloo:   # rehearsal only: exchange through host memory
+                h = [torch.empty(3 * P * D, dtype=torch.int32) for _ in range(world)]
+                dist.all_gather(h, d_metrics.cpu())
+                d_gather.copy_(torch.cat(h))
+            else:
+                dist.all_gather_into_tensor(d_gather, d_metrics)    # the path's one exchange step
             g = d_gather.view(world, 3, P * D).permute(1, 0, 2).contiguous()   # -> [3][world*P][D]
             eng.decide_dev(g.data_ptr(), n_prn=world * P, prn_ids=ids_all)
             return g
@@ -153,7 +166,7 @@ def main():
         "metric": "acq PRN×Doppler cells/s + tracking ch×Msps at 1/2/4/8 GPU; % HBM roofline",
         "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (DEBUG gloo rehearsal, one GPU shared)" if debug_gloo else ""),
         "config": {"workload": "GPS L1 C/A 32-PRN x +-5 kHz/250 Hz (41 bins) acquisition, 8 Msps complex int8, "
                                "N=8000, 10 x 1 ms non-coherent, per GPU" + ("; all-gather of {max,argmax,sum}[P][D]" if world > 1 else ""),
                    "prns_per_gpu": P, "doppler_bins": D, "fft_size": N, "integrations": M,
