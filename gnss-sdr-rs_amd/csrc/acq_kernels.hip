@@ -20,6 +20,7 @@
 // (no FMA); the FFT butterflies use explicit __builtin_fmaf.
 #include "gm_internal.h"
 #include "fft_plans.h"
+#include <cstdlib>
 
 namespace gm {
 
@@ -141,13 +142,36 @@ template <class PL, bool KEEP_CODE, bool STAMPS>
 __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ tw_inv,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
-    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int) {
-    // XCD-aware tile map: blocks b and b+8 share an XCD (round-robin dispatch, speed only).  All
-    // workers of one Doppler bin go to one XCD so that bin's M spectra (M*8N bytes) stay in its L2.
+    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int map_mode) {
+    // XCD-aware tile map: blocks b and b+8 share an XCD (round-robin dispatch, speed only).  The (bin, worker)
+    // items are numbered bin-major and every XCD takes one contiguous, EQUAL share of them: the workers of a
+    // Doppler bin stay on one XCD (at most two), so that bin's M spectra (M*8N bytes) are served by that XCD's L2,
+    // and no XCD gets a whole extra bin (41 bins over 8 XCDs used to give XCD 0 a full third round).
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int d = xcd + 8 * (slot / n_workers);
-    if (d >= n_bins) return;
-    const int p = int(worker_list[slot % n_workers]);
+    int d, p;
+    if (map_mode == 0) {          // equal contiguous share of the bin-major item list per XCD
+        const int items = n_bins * n_workers, share = (items + 7) >> 3;
+        const int item = xcd * share + slot;
+        if (slot >= share || item >= items) return;
+        d = item / n_workers;
+        p = int(worker_list[item - d * n_workers]);
+    } else if (map_mode == 1) {   // whole bins per XCD (bin d on XCD d % 8)
+        d = xcd + 8 * (slot / n_workers);
+        if (d >= n_bins) return;
+        p = int(worker_list[slot % n_workers]);
+    } else {                      // whole bins for the first 8*floor(D/8) bins, the leftover bins' workers split evenly
+        const int q = n_bins >> 3, whole = q * n_workers;
+        if (slot < whole) {
+            d = xcd + 8 * (slot / n_workers);
+            p = int(worker_list[slot % n_workers]);
+        } else {
+            const int left = (n_bins - 8 * q) * n_workers, each = (left + 7) >> 3;
+            const int j = slot - whole, item = xcd * each + j;
+            if (j >= each || item >= left) return;
+            d = 8 * q + item / n_workers;
+            p = int(worker_list[item % n_workers]);
+        }
+    }
 
     __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
     cf* tw = lds + PL::LDS_ELEMS;
@@ -302,13 +326,24 @@ template <class PL> struct Launch {
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
                      int n_int) {
         if (n_workers <= 0) return;
-        const int groups = (n_bins + 7) / 8;
+        // Tile map: whole Doppler bins per XCD (best L2 locality) unless that costs an XCD an extra round of
+        // workgroups (2 x 32 resident per XCD) compared with equal shares of the item list.  Measured on configs[1]
+        // geometry: P = 12: 125 -> 88 us, P = 24: 195 -> 165 us with equal shares; P = 32: whole bins 3 % faster.
+        static const int forced = getenv("GM_CORR_MAP") ? atoi(getenv("GM_CORR_MAP")) : -1;   // diagnostic override
+        const int per_xcd_bins = ((n_bins + 7) / 8) * n_workers, per_xcd_even = (n_bins * n_workers + 7) / 8;
+        const int slots = 32 * PL::WG_PER_CU;
+        const int q = n_bins / 8, left = (n_bins - 8 * q) * n_workers;
+        const int per_xcd_mixed = q * n_workers + (left + 7) / 8;
+        int map_mode = ((per_xcd_bins + slots - 1) / slots > (per_xcd_even + slots - 1) / slots) ? 0 : 1;
+        if (map_mode == 1 && per_xcd_mixed < per_xcd_bins) map_mode = 2;   // same locality, balanced leftovers
+        if (forced >= 0) map_mode = forced;
+        const int share = map_mode == 0 ? per_xcd_even : (map_mode == 1 ? per_xcd_bins : per_xcd_mixed);
         if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
-            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, true>), dim3(8 * groups * n_workers), dim3(PL::T), 0, st,
-                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int);
+            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, true>), dim3(8 * share), dim3(PL::T), 0, st,
+                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode);
         else
-            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, false>), dim3(8 * groups * n_workers), dim3(PL::T), 0, st,
-                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int);
+            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, false>), dim3(8 * share), dim3(PL::T), 0, st,
+                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode);
     }
     static void code_fft(hipStream_t st, const int8_t* code_samples, const cf* tw_fwd, cf* out, int n_codes) {
         hipLaunchKernelGGL(acq_code_fft_kernel<PL>, dim3(n_codes), dim3(PL::T), 0, st, code_samples, tw_fwd, out);
