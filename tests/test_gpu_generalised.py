@@ -131,3 +131,41 @@ def test_acquisition_edge_cases(gpu, oracle):
     mx, am, sm = eng.metrics()
     assert (mx == 0).all() and (am == 0).all()
     eng.close()
+
+
+def test_five_arm_boc_persistent_kernel_first_epoch(gpu, oracle):
+    """The persistent multi-epoch kernel in its 5-arm / BOC / custom-code instantiation: epoch 0 of update_all on the
+    device ring equals the generalised oracle's correlation of the same window, and later epochs keep lock."""
+    from gnss_sdr_rs_amd import tracking as T
+    fs, L, rate = 4_096_000.0, 4092, 1.023e6
+    n = int(round(fs / (rate / L)))
+    rng = np.random.default_rng(17)
+    codes = np.where(rng.integers(0, 2, (2, L)) > 0, 1, -1).astype(np.int8)
+    n_ep = 6
+    t = np.arange((n_ep + 1) * n, dtype=np.float64)
+    chip_phase = (t * rate / fs) % L
+    sub = np.where((chip_phase - np.floor(chip_phase)) < 0.5, 1.0, -1.0)
+    sig = 5.0 * codes[0][np.floor(chip_phase).astype(int)] * sub * np.exp(2j * np.pi * (-333.0) * t / fs)
+    x = (sig + np.random.default_rng(18).standard_normal((t.size, 2)) @ np.array([1, 1j]) * 8.0).astype(np.complex64)
+    ring = T.MulticastRingBuffer(1 << 18)
+    ring.write_samples(x)
+    mgr = T.TrackingManager(fs, n_channels=3, n_arms=5, code_index_mode=1, early_late_space=0.25, very_early_late_space=0.6,
+                            boc11=True, codes=codes, nominal_code_rate=rate)
+    oc = oracle.TrackingChannel(0, fs, code_index_mode=1, n_arms=5, el_space=0.25, vel_space=0.6, boc11=True, codes=codes,
+                                code_rate=rate)
+    r = dict(prn=1, code_phase_samples=0, code_phase_chips=0.0, carrier_freq=-330.0, fs=fs, mag_relative=1.0,
+             sample_global_index=0, doppler_bin=0)
+    mgr.channels[2].start(r)
+    oc.start(r)
+    outs, proc, lost, done = mgr.update_all(ring, n_ep + 2)
+    assert done == n_ep + 1 and proc[:n_ep + 1, 2].all() and not proc[:, :2].any() and not lost.any()
+    exp, exp64 = oc.early_late_correlation_ex(x[:n])
+    env = float(np.hypot(exp[0], exp[1]))
+    assert outs.shape[2] == 10 and np.max(np.abs(outs[0, 2] - exp)) <= REL * env
+    s = mgr.channels[2].state
+    assert s.next_sample_index == (n_ep + 1) * n and s.lost_counter == 0 and abs(s.carrier_freq + 333.0) < 20.0
+    # prompt stays the strongest arm while the loops run
+    for ep in range(1, n_ep + 1):
+        o = outs[ep, 2]
+        assert np.hypot(o[0], o[1]) > np.hypot(o[6], o[7]) and np.hypot(o[0], o[1]) > np.hypot(o[8], o[9])
+    mgr.close(); ring.close()
