@@ -262,8 +262,10 @@ template <int A, int B, bool INV> struct DftPFA {
 
 template <bool INV> struct Dft<8, INV> { static GM_HD void run(cf (&u)[8]) { DftCT<2, 4, INV>::run(u); } };
 template <bool INV> struct Dft<10, INV> { static GM_HD void run(cf (&u)[10]) { DftPFA<2, 5, INV>::run(u); } };
+template <bool INV> struct Dft<15, INV> { static GM_HD void run(cf (&u)[15]) { DftPFA<3, 5, INV>::run(u); } };
 template <bool INV> struct Dft<16, INV> { static GM_HD void run(cf (&u)[16]) { DftCT<4, 4, INV>::run(u); } };
 template <bool INV> struct Dft<20, INV> { static GM_HD void run(cf (&u)[20]) { DftPFA<4, 5, INV>::run(u); } };
+template <bool INV> struct Dft<24, INV> { static GM_HD void run(cf (&u)[24]) { DftPFA<3, 8, INV>::run(u); } };
 template <bool INV> struct Dft<25, INV> { static GM_HD void run(cf (&u)[25]) { DftCT<5, 5, INV>::run(u); } };
 template <bool INV> struct Dft<32, INV> { static GM_HD void run(cf (&u)[32]) { DftCT<4, 8, INV>::run(u); } };
 template <bool INV> struct Dft<33, INV> { static GM_HD void run(cf (&u)[33]) { DftPFA<3, 11, INV>::run(u); } };
@@ -278,8 +280,10 @@ template <bool INV> struct Dft<33, INV> { static GM_HD void run(cf (&u)[33]) { D
 template <int R> struct Fac { static constexpr int A = R, B = 1, KIND = 0; };
 template <> struct Fac<8> { static constexpr int A = 2, B = 4, KIND = 1; };
 template <> struct Fac<10> { static constexpr int A = 2, B = 5, KIND = 2; };
+template <> struct Fac<15> { static constexpr int A = 3, B = 5, KIND = 2; };
 template <> struct Fac<16> { static constexpr int A = 4, B = 4, KIND = 1; };
 template <> struct Fac<20> { static constexpr int A = 4, B = 5, KIND = 2; };
+template <> struct Fac<24> { static constexpr int A = 3, B = 8, KIND = 2; };
 template <> struct Fac<25> { static constexpr int A = 5, B = 5, KIND = 1; };
 template <> struct Fac<32> { static constexpr int A = 4, B = 8, KIND = 1; };
 template <> struct Fac<33> { static constexpr int A = 3, B = 11, KIND = 2; };

@@ -4,7 +4,7 @@
 //   16368 : 16.3676 Msps      (BASELINE config 1, the reference's test capture geometry) 2^4*3*11*31
 //   4096  : 4.096 Msps        (the reference's synthetic tracking tests, do_tracking.rs:467)
 //   2048, 1024 : small parity cases
-//   4000, 10000, 12000, 16000 : other common front-end rates (4, 10, 12, 16 Msps)
+//   2000, 4000, 5000, 6000, 8192, 10000, 12000, 15000, 16000, 16384 : other common front-end rates
 // Plan<N, T, radices...>: first radix odd where possible (conflict-free stride-R scatter),
 // T >= N / R for every pass so each thread owns at most one butterfly per pass (except where noted).
 #pragma once
@@ -20,8 +20,15 @@ using Plan4000 = Plan<4000, 256, 25, 16, 10>;
 using Plan10000 = Plan<10000, 512, 25, 20, 20>;
 using Plan12000 = Plan<12000, 512, 25, 3, 10, 16>;
 using Plan16000 = Plan<16000, 1024, 25, 20, 32>;
+using Plan2000 = Plan<2000, 128, 25, 10, 8>;      // 2 Msps
+using Plan5000 = Plan<5000, 256, 25, 25, 8>;      // 5 Msps (last pass: 625 butterflies -> 3 per thread)
+using Plan6000 = Plan<6000, 512, 25, 15, 16>;     // 6 Msps
+using Plan8192 = Plan<8192, 512, 16, 32, 16>;     // 8.192 Msps
+using Plan15000 = Plan<15000, 1024, 25, 25, 24>;  // 15 Msps
+using Plan16384 = Plan<16384, 1024, 32, 32, 16>;  // 16.384 Msps
 }  // namespace gm
 
 #define GM_FOR_EACH_PLAN(X) \
     X(gm::Plan8000) X(gm::Plan16368) X(gm::Plan4096) X(gm::Plan2048) X(gm::Plan1024) \
-    X(gm::Plan4000) X(gm::Plan10000) X(gm::Plan12000) X(gm::Plan16000)
+    X(gm::Plan4000) X(gm::Plan10000) X(gm::Plan12000) X(gm::Plan16000) \
+    X(gm::Plan2000) X(gm::Plan5000) X(gm::Plan6000) X(gm::Plan8192) X(gm::Plan15000) X(gm::Plan16384)

@@ -208,3 +208,24 @@ def test_error_behaviour(gpu):
         eng.search(np.zeros(2048, np.complex64))                                     # chunk shorter than M*N
     assert e.value.status == -5
     eng.close()
+
+
+@pytest.mark.parametrize("fs,N", [(2.0e6, 2000), (5.0e6, 5000), (6.0e6, 6000), (8.192e6, 8192), (10.0e6, 10000),
+                                  (12.0e6, 12000), (15.0e6, 15000), (16.0e6, 16000), (16.384e6, 16384), (4.0e6, 4000)])
+def test_every_other_plan_small_scene(gpu, oracle, fs, N):
+    """One small scene per remaining fft_size plan (3 PRNs x 3 bins x 2 ms): planes and decisions vs the oracle."""
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    t = oracle.ca_code_table()
+    M = 2
+    dop = np.array([-500.0, 0.0, 500.0], np.float32)
+    sats = [dict(prn_row=12, cn0_dbhz=48.0, doppler_hz=130.0, code_start=N // 3)]
+    x = synth.to_c32(synth.make_scene(t, fs, 0.0, M * N, sats, config_id=int(N)))
+    prns = [13, 14, 2]
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=prns, n_integrations=M)
+    tables = _tables(oracle, 0.0, dop, fs, N)
+    # whatever the reference's detector says about the absent PRNs (a strong signal's Gold cross-correlation can pass
+    # peak/mean > 7), the GPU must say the same: _compare_search checks every plane and every decision
+    assert _compare_search(eng, oracle, x, tables, prns, N, fs, M) >= 1
+    # within half a chip of the simulated code start (the top of the correlation triangle is several samples wide)
+    assert abs(eng.search(x)[0]["code_phase_samples"] - N // 3) <= max(1, int(fs / 1.023e6 / 2))
+    eng.close()
