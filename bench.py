@@ -204,6 +204,13 @@ def main():
         except Exception as e:   # the headline number stands on its own
             out["tracking"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ configs[4] geometry (informative, no reference code)
+    if rank == 0 and world == 1 and not args.no_tracking:
+        try:
+            out["cfg5_geometry"] = cfg5_leg(torch, stream, T)
+        except Exception as e:
+            out["cfg5_geometry"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc, args.cpu_seconds)
@@ -246,6 +253,54 @@ def cfg1_leg(torch, dev, stream, ca, A, synth):
             "cells_per_s": P * D * N / dt, "ms_per_dwell": dt * 1e3, "corr_kernel_ms": ts["avg_corr_ms"],
             "corr_algorithmic_GBs": corr_bytes / (ts["avg_corr_ms"] * 1e-3) / 1e9 if ts["avg_corr_ms"] > 0 else None,
             "prns_found": found, "prns_in_scene": sorted(s["prn"] for s in sc["sats"])}
+
+
+def cfg5_leg(torch, stream, T):
+    """BASELINE configs[4] geometry: 36 channels, 50 Msps, 4092-chip codes at 1.023 Mcps (4 ms period, 200 000 samples),
+    BOC(1,1), five arms (VE/E/P/L/VL).  The reference has no Galileo/BOC code: stand-in random codes, GPU-only number."""
+    fs, L, rate, C, periods = 50.0e6, 4092, 1.023e6, 36, 6
+    n = int(round(fs / (rate / L)))
+    rng = np.random.default_rng(5)
+    codes = np.where(rng.integers(0, 2, (C, L)) > 0, 1, -1).astype(np.int8)
+    tt = np.arange((periods + 1) * n, dtype=np.float64)
+    cp = (tt * rate / fs) % L
+    sub = np.where((cp - np.floor(cp)) < 0.5, 1.0, -1.0).astype(np.float32)
+    ci = np.floor(cp).astype(np.int64)
+    x = (rng.standard_normal(tt.size) + 1j * rng.standard_normal(tt.size)).astype(np.complex64) * np.float32(8.0)
+    dopp = rng.uniform(-2000, 2000, C)
+    for c in range(C):   # all satellites code-aligned at sample 0 (keeps the generator cheap)
+        x += (np.float32(0.6) * codes[c][ci] * sub * np.exp(2j * np.pi * dopp[c] * tt / fs)).astype(np.complex64)
+    ring = T.MulticastRingBuffer(1 << 21)
+    ring.write_samples(x)
+    mgr = T.TrackingManager(fs, n_channels=C, n_arms=5, code_index_mode=T.CODE_INDEX_FIXED, early_late_space=0.25,
+                            very_early_late_space=0.6, boc11=True, codes=codes, nominal_code_rate=rate)
+    mgr.set_stream(stream)
+
+    def restart():
+        for c in range(C):
+            mgr.channels[c].start(dict(prn=c + 1, code_phase_samples=0, code_phase_chips=0.0, carrier_freq=float(dopp[c]) + 10.0,
+                                       fs=fs, mag_relative=1.0, sample_global_index=0, doppler_bin=0))
+            mgr.channels[c].set_state(code_rate=rate, num_samples_per_code=n, carrier_phase=0.0, code_error=0.0,
+                                      carrier_error=0.0, lost_counter=0)
+    restart()
+    mgr.update_all_dev(ring, periods)
+    mgr.synchronize()
+    locked = sum(1 for c in mgr.channels if c.is_active() and c.lost_counter == 0)
+    times = []
+    for _ in range(3):
+        restart()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mgr.update_all_dev(ring, periods)
+        mgr.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    mgr.close()
+    ring.close()
+    sig_s = periods * n / fs
+    return {"workload": "36 ch x 50 Msps, 4092-chip BOC(1,1), 5 arms, 4 ms code periods (no reference code: stand-in codes)",
+            "ch_msps": C * fs / 1e6 * (sig_s / dt), "ms_per_code_period": dt / periods * 1e3, "channels_locked": locked,
+            "algorithmic_GBs": C * n * 8 * periods / dt / 1e9}
 
 
 def tracking_leg(torch, dev, stream, ca, T, synth, world, dist):
