@@ -100,12 +100,22 @@ def main():
     eng.set_stream(stream)
     d_samples = torch.from_numpy(xi8).to(dev)                       # IF snapshot resident in HBM
     d_metrics = torch.zeros(3 * P * D, dtype=torch.int32, device=dev)
-    if world > 1:
+    # GM_BENCH_NATIVE_COMM=1: exchange through the C ABI's own RCCL communicator (gm_comm_*, what a Rust host would
+    # call) instead of torch.distributed's; default off at N > 1 only because this round could rehearse it on one GPU only
+    native_comm = None
+    if os.environ.get("GM_BENCH_NATIVE_COMM") == "1" and not debug_gloo:
+        from gnss_sdr_rs_amd import distributed as Dm
+        native_comm = Dm.NativeComm.from_torch_dist() if world > 1 else Dm.NativeComm(1, 0, Dm.NativeComm.unique_id())
+    if world > 1 or native_comm:
         d_gather = torch.zeros(world * 3 * P * D, dtype=torch.int32, device=dev)
         ids_all = np.tile(np.arange(1, 33, dtype=np.uint8), world)
 
     def step():
         eng.search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, d_metrics.data_ptr())
+        if native_comm:      # all-gather + regroup inside the library, on the handle's stream
+            native_comm.allgather_metrics(eng, d_gather.data_ptr(), d_metrics.data_ptr())
+            eng.decide_dev(d_gather.data_ptr(), n_prn=world * P, prn_ids=ids_all)
+            return None
         if world > 1:
             if debug_gloo:   # rehearsal only: exchange through host memory
                 h = [torch.empty(3 * P * D, dtype=torch.int32) for _ in range(world)]
@@ -171,7 +181,7 @@ def main():
                                "N=8000, 10 x 1 ms non-coherent, per GPU" + ("; all-gather of {max,argmax,sum}[P][D]" if world > 1 else ""),
                    "prns_per_gpu": P, "doppler_bins": D, "fft_size": N, "integrations": M,
                    "cells_per_step": cells_per_step, "cell_integrations_per_s": value * M,
-                   "parallelism": f"prn-shard x{world}", "detections_ok": bool(detections_ok)},
+                   "parallelism": f"prn-shard x{world}", "exchange": ("gm_comm (RCCL via the C ABI)" if native_comm else "torch.distributed nccl" if world > 1 else None), "detections_ok": bool(detections_ok)},
         "roofline": {"bound": "hbm", "kernel": "acq_corr_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": corr_bytes, "avg_launch_ms": tsum["avg_corr_ms"],
@@ -181,6 +191,13 @@ def main():
                      "whole_step_algorithmic_GBs": (corr_bytes + mix_bytes) * args.steps / elapsed / 1e9},
     }
     del keep
+    if rank == 0 and world == 1:
+        try:
+            c = hbm_ceiling(torch, dev)
+            out["roofline"]["measured_d2d_copy_GBs"] = c
+            out["roofline"]["frac_of_measured_copy"] = achieved / c
+        except Exception as e:
+            out["roofline"]["measured_d2d_copy_GBs"] = repr(e)
     if rank == 0:
         # the drop-in host-buffer entry (gm_acq_search: H2D of the 160 KB snapshot + kernels + D2H of results);
         # PCIe-inclusive, reported for DESIGN.md, never `value`
@@ -200,7 +217,8 @@ def main():
     # ------------------------------------------------------------------ tracking leg (configs[2]), rank-local
     if not args.no_tracking:
         try:
-            out["tracking"] = tracking_leg(torch, dev, stream, ca, T, synth, world, dist)
+            out["tracking"] = tracking_leg(torch, dev, stream, ca, T, synth, world, dist,
+                                           0.0 if (args.no_cpu_baseline or rank != 0) else min(args.cpu_seconds, 8.0))
         except Exception as e:   # the headline number stands on its own
             out["tracking"] = {"error": repr(e)}
 
@@ -303,7 +321,7 @@ def cfg5_leg(torch, stream, T):
             "algorithmic_GBs": C * n * 8 * periods / dt / 1e9}
 
 
-def tracking_leg(torch, dev, stream, ca, T, synth, world, dist):
+def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0):
     """32 channels x 25 Msps, 1 ms E/P/L correlators + DLL/PLL on-device, FIXED code indexing
     (FAITHFUL cannot run PRN 32: the reference indexes GPS_CA_CODE_32_PRN[32])."""
     fs, C, epochs, reps = 25.0e6, 32, 40, 5
@@ -341,10 +359,69 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist):
     gbs = bytes_per_epoch * epochs / dt / 1e9
     mgr.close()
     ring.close()
-    return {"metric": "tracking ch×Msps", "value": ch_msps * world, "unit": "ch*Msps", "channels_per_gpu": C,
+    trk_cpu = None
+    if world == 1 and cpu_seconds > 0:
+        trk_cpu = tracking_cpu_baseline(sc, fs, n, cpu_seconds)
+    return {"metric": "tracking ch×Msps", "cpu_baseline": trk_cpu, "value": ch_msps * world, "unit": "ch*Msps", "channels_per_gpu": C,
             "fs_msps": 25.0, "epochs": epochs, "ms_per_epoch": dt / epochs * 1e3, "channels_locked": locked,
             "roofline": {"bound": "hbm", "kernel": "trk_correlate_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_epoch": bytes_per_epoch}}
+
+
+def tracking_cpu_baseline(sc, fs, n, budget_s):
+    """The oracle's TrackingManager::process_channels (do_tracking.rs:351-371: one rayon task per channel ->
+    OpenMP) on this host: the same 32 channels and ring contents as the GPU leg, FIXED code index, whole passes of
+    all channels until ~budget_s seconds.  Per-sample libm cosf/sinf + fmodf like the reference (:233-252)."""
+    from oracle import oracle as O
+    from gnss_sdr_rs_amd import synth
+    O.build(native=True)
+    nthreads = min(32, os.cpu_count() or 1)
+    ring = O.MulticastRingBuffer(1 << 21)
+    ring.write_samples(synth.to_c32(sc["x"]))
+    avail = int(sc["x"].size // n) - 2
+
+    def fresh():
+        chans = []
+        for i, s_ in enumerate(sc["sats"]):
+            ch = O.TrackingChannel(i, fs, code_index_mode=O.CODE_INDEX_FIXED)
+            ch.start(dict(prn=s_["prn"], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=s_["doppler_hz"] + 20.0,
+                          fs=fs, mag_relative=1.0, sample_global_index=s_["code_start"]))
+            ch.c.code_rate, ch.c.num_samples_per_code = 1.023e6, n
+            chans.append(ch)
+        return chans
+    O.process_channels(fresh(), ring, 2, n_threads=nthreads, native=True)     # warm-up
+    done, secs, t_start = 0, [], time.perf_counter()
+    while time.perf_counter() - t_start < budget_s or not secs:
+        chans = fresh()
+        t0 = time.perf_counter()
+        got = O.process_channels(chans, ring, avail, n_threads=nthreads, native=True)
+        secs.append((time.perf_counter() - t0) / max(got, 1))
+        done += got
+    per_ch_epoch = float(np.median(secs))                       # seconds per channel-epoch with all threads busy
+    t0 = time.perf_counter()
+    got1 = O.process_channels(fresh()[:1], ring, min(avail, 20), n_threads=1, native=True)
+    one = (time.perf_counter() - t0) / max(got1, 1)
+    return {"value": n / per_ch_epoch / 1e6, "unit": "ch*Msps", "cores": nthreads, "kind": "port",
+            "sample": f"{done} channel-epochs (32 ch x 25 Msps scene of the GPU leg, 1 ms epochs)",
+            "single_thread_ch_msps": n / one / 1e6}
+
+
+def hbm_ceiling(torch, dev):
+    """the measured device-to-device copy ceiling next to the 8 TB/s datasheet peak (1 GiB -> 1 GiB,
+    read + write counted)."""
+    nbytes = 1 << 30
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    del a, b
+    return 2 * nbytes / (ms * 1e-3) / 1e9
 
 
 def cpu_baseline(sc, budget_s):

@@ -83,6 +83,11 @@ SIGNATURES = {
     "gm_acq_search_dev": (_i, [_vp, _vp, _i, _vp]),
     "gm_acq_set_prn_mask": (_i, [_vp, _u64]),
     "gm_acq_decide_dev": (_i, [_vp, _vp, _u32, _vp, _u64]),
+    "gm_comm_get_unique_id": (_i, [_vp]),
+    "gm_comm_init": (_i, [_i, _i, _vp, _vp]),
+    "gm_comm_destroy": (_i, [_vp]),
+    "gm_comm_info": (_i, [_vp, _vp, _vp]),
+    "gm_acq_allgather_metrics": (_i, [_vp, _vp, _vp, _vp]),
     "gm_acq_fetch_results": (_i, [_vp, _u32, _vp, _vp]),
     "gm_acq_decide_host": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _f, _f, _f, _u64, _vp, _vp]),
     "gm_acq_synchronize": (_i, [_vp]),

@@ -2,6 +2,7 @@
 // Host-side scalar pieces of the reference API (code table, Doppler table construction, manager,
 // loop-filter constants) are restated here in C++; everything that touches sample data runs on the GPU.
 // There is no CPU fallback for the compute entries: without a device they return GM_ERR_NO_DEVICE.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -1145,3 +1146,131 @@ int gm_trk_last_timing(gm_trk* t, float* ms_total, uint32_t* launches) {
 }
 
 }  // extern "C"
+
+// ====================================================================== multi-GPU exchange
+// The path's ONE exchange step: all-gather of the per-(worker, bin) metrics over RCCL, enqueued on the acquisition
+// handle's stream, followed by the regroup to the [3][nranks*P][D] layout gm_acq_decide_dev replays.  RCCL is bound
+// lazily (dlopen of librccl.so.1 — inside a PyTorch process that is the copy PyTorch already loaded), so single-GPU
+// hosts never need it.
+#include <rccl/rccl.h>
+
+namespace {
+struct RcclApi {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char* n : names)
+            if ((api.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!api.so) return;
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.so, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.so, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.so, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.so, "ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.so, "ncclGetErrorString"));
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+    });
+    return api;
+}
+int rccl_fail(ncclResult_t r, const char* where) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", where, rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error");
+    g_last_error = buf;
+    return GM_ERR_HIP;
+}
+#define RCCLC(expr)                                           \
+    do {                                                      \
+        ncclResult_t _r = (expr);                             \
+        if (_r != ncclSuccess) return rccl_fail(_r, #expr);   \
+    } while (0)
+
+// gathered [R][3][PD] -> out [3][R][PD]  (== [3][R*P][D])
+__global__ void regroup_metrics_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t R, uint32_t PD) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = R * 3u * PD;
+    if (i >= total) return;
+    const uint32_t e = i % PD, q = (i / PD) % 3u, r = i / (3u * PD);
+    out[(size_t(q) * R + r) * PD + e] = in[i];
+}
+}  // namespace
+
+struct gm_comm {
+    int device = -1;
+    int nranks = 0, rank = 0;
+    ncclComm_t comm = nullptr;
+    uint32_t* d_stage = nullptr;   // [nranks][3][PD] as the all-gather lays it out
+    size_t stage_words = 0;
+};
+
+extern "C" {
+
+int gm_comm_get_unique_id(uint8_t id[GM_COMM_ID_BYTES]) {
+    if (!id) return set_err(GM_ERR_INVALID_ARG, "null id");
+    static_assert(GM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!rccl().ok) return set_err(GM_ERR_UNSUPPORTED, "librccl.so.1 not found");
+    ncclUniqueId u;
+    RCCLC(rccl().GetUniqueId(&u));
+    memcpy(id, u.internal, GM_COMM_ID_BYTES);
+    return GM_OK;
+}
+
+int gm_comm_init(int nranks, int rank, const uint8_t id[GM_COMM_ID_BYTES], gm_comm** out) {
+    if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return set_err(GM_ERR_INVALID_ARG, "bad nranks/rank/id");
+    if (int rc = ensure_device(g_device)) return rc;
+    if (!rccl().ok) return set_err(GM_ERR_UNSUPPORTED, "librccl.so.1 not found");
+    ncclUniqueId u;
+    memcpy(u.internal, id, GM_COMM_ID_BYTES);
+    gm_comm* c = new gm_comm;
+    c->device = g_device; c->nranks = nranks; c->rank = rank;
+    ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
+    if (r != ncclSuccess) { delete c; return rccl_fail(r, "ncclCommInitRank"); }
+    *out = c;
+    return GM_OK;
+}
+
+int gm_comm_destroy(gm_comm* c) {
+    if (!c) return GM_OK;
+    if (c->device >= 0) hipSetDevice(c->device);
+    if (c->comm) rccl().CommDestroy(c->comm);
+    hipFree(c->d_stage);
+    delete c;
+    return GM_OK;
+}
+
+int gm_comm_info(gm_comm* c, int* nranks, int* rank) {
+    if (!c) return set_err(GM_ERR_INVALID_ARG, "null comm");
+    if (nranks) *nranks = c->nranks;
+    if (rank) *rank = c->rank;
+    return GM_OK;
+}
+
+int gm_acq_allgather_metrics(gm_acq* a, gm_comm* c, const void* d_local, void* d_all) {
+    if (!a || !c || !d_all) return set_err(GM_ERR_INVALID_ARG, "null handle/comm/output");
+    if (a->device != c->device) return set_err(GM_ERR_INVALID_ARG, "handle and communicator live on different devices");
+    if (int rc = ensure_device(a->device)) return rc;
+    const size_t PD = size_t(a->P) * a->D, words = 3 * PD;
+    const uint32_t* src = d_local ? static_cast<const uint32_t*>(d_local) : a->d_metrics;
+    if (c->stage_words < words * c->nranks) {
+        hipFree(c->d_stage); c->d_stage = nullptr; c->stage_words = 0;
+        HIPC(hipMalloc(&c->d_stage, words * c->nranks * sizeof(uint32_t)));
+        c->stage_words = words * c->nranks;
+    }
+    RCCLC(rccl().AllGather(src, c->d_stage, words, ncclInt32, c->comm, a->stream));
+    const uint32_t total = uint32_t(words * c->nranks);
+    regroup_metrics_kernel<<<(total + 255) / 256, 256, 0, a->stream>>>(c->d_stage, static_cast<uint32_t*>(d_all),
+                                                                      uint32_t(c->nranks), uint32_t(PD));
+    HIPC(hipGetLastError());
+    return GM_OK;
+}
+
+}  // extern "C"
+

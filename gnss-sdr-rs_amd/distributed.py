@@ -39,6 +39,51 @@ def all_gather_metrics(local_block, world, P, D):
     return regroup_gathered(out, world, P, D)
 
 
+COMM_ID_BYTES = 128
+
+
+class NativeComm:
+    """gm_comm_* — the C-ABI exchange a host without PyTorch (the reference is Rust) uses: RCCL all-gather of the
+    metrics block on the acquisition handle's stream + regroup, no torch types.  The 128-byte id is created on
+    rank 0 and carried to the other ranks by whatever channel the host has; `from_torch_dist` uses a
+    torch.distributed broadcast for that (plumbing only)."""
+
+    def __init__(self, nranks, rank, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        check(lib().gm_comm_init(nranks, rank, C.cast(buf, C.c_void_p), C.byref(self._h)), "gm_comm_init")
+        self.nranks, self.rank = nranks, rank
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        check(lib().gm_comm_get_unique_id(C.cast(buf, C.c_void_p)), "gm_comm_get_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_dist(cls):
+        import torch.distributed as dist
+        box = [cls.unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(dist.get_world_size(), dist.get_rank(), box[0])
+
+    def allgather_metrics(self, engine, d_all_ptr, d_local_ptr=None):
+        """engine: AcquisitionEngine; d_all_ptr: device pointer to 3*nranks*P*D words; asynchronous on the handle's stream."""
+        check(lib().gm_acq_allgather_metrics(engine._h, self._h, d_local_ptr, d_all_ptr), "gm_acq_allgather_metrics")
+
+    def close(self):
+        if self._h:
+            lib().gm_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def decide_host(block, prn_ids, table_freq, fft_size, fs, local_tail=0, code_rate=1.023e6, threshold=7.0):
     """Decision replay (do_acquisition.rs:195-238) on a host int32 block [3][P][D]."""
     P = len(prn_ids)

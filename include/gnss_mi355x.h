@@ -39,7 +39,8 @@ typedef enum {
     GM_ERR_OUT_OF_RANGE = -5,  /* slice/index out of range (the reference panics: index out of bounds) */
     GM_ERR_ALIGNMENT = -6,     /* fft_size % 8 != 0: the reference's SIMD tails (doppler_shift.rs:26,
                                   do_acquisition.rs:230-234) would leave stale / uncounted elements */
-    GM_ERR_NOMEM = -7
+    GM_ERR_NOMEM = -7,
+    GM_ERR_UNSUPPORTED = -8    /* optional component absent (RCCL for the gm_comm_* entries) */
 } gm_status;
 
 /* num_complex::Complex32 */
@@ -153,6 +154,23 @@ int gm_acq_search_ring(gm_acq *a, gm_ring *ring, uint64_t prn_mask, gm_acq_resul
 int gm_acq_search_dev(gm_acq *a, const void *d_samples, int fmt, void *d_metrics);
 /* Which workers the device-resident form searches (bit i <-> worker i); default: all. */
 int gm_acq_set_prn_mask(gm_acq *a, uint64_t prn_mask);
+/* ---- multi-GPU exchange (nothing distributed exists in the reference: do_acquisition.rs:302-313
+ * fans the PRNs out over rayon threads of one host).  One process per GPU; PRNs are sharded in contiguous blocks of
+ * n_prn per rank.  gm_comm_get_unique_id on rank 0, the 128 bytes travel out of band (file, socket, MPI, the host
+ * application's own channel), gm_comm_init on every rank after gm_init(device).  RCCL (librccl.so.1) is bound at the
+ * first call; GM_ERR_UNSUPPORTED if it is not installed. */
+#define GM_COMM_ID_BYTES 128
+typedef struct gm_comm gm_comm;
+int gm_comm_get_unique_id(uint8_t id[GM_COMM_ID_BYTES]);
+int gm_comm_init(int nranks, int rank, const uint8_t id[GM_COMM_ID_BYTES], gm_comm **out);
+int gm_comm_destroy(gm_comm *c);
+int gm_comm_info(gm_comm *c, int *nranks, int *rank);
+/* The path's one exchange step, enqueued on the handle's stream (no host synchronisation): all-gather this rank's
+ * metrics block d_local ([3][P][D] words as written by gm_acq_search_dev; NULL -> the handle's internal block) from
+ * every rank and regroup into d_all = [3][nranks*P][D] (rank-major worker order), the layout gm_acq_decide_dev
+ * takes with n_prn = nranks*P.  Every rank obtains the same block, so every rank's decision is identical. */
+int gm_acq_allgather_metrics(gm_acq *a, gm_comm *c, const void *d_local, void *d_all);
+
 /* Replay the reference's decision (running best + ratio test + early exit) on the GPU from a metrics
  * block laid out as above for `n_prn` workers (e.g. an all-gathered one).  prn_ids: host [n_prn].
  * Asynchronous; results land in an internal device buffer read back by gm_acq_fetch_results. */

@@ -769,3 +769,28 @@ int orc_trk_update(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, f
     if (rc < 0) return -1;
     return rc == 1 ? 2 : 1;
 }
+
+/* TrackingManager::process_channels :351-371 — par_iter_mut over the channels, one task per channel, repeated
+ * while any channel still finds a whole code period in the ring (the run() loop of :384-415 without the Condvar).
+ * scratch: n_channels blocks of scratch_stride samples.  Returns channel-epochs processed, -1 on OOB. */
+int64_t orc_trk_process_channels(orc_trk_channel *ch, int n_channels, const orc_ring *ring, orc_c32 *scratch,
+                                 size_t scratch_stride, int max_passes, int n_threads) {
+    int64_t done = 0;
+    int err = 0;
+    for (int pass = 0; pass < max_passes; ++pass) {
+        int64_t got = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : got) reduction(| : err)
+        for (int i = 0; i < n_channels; ++i) {
+            float out6[6];
+            uint8_t prn = 255;
+            int rc = orc_trk_update(&ch[i], ring, scratch + (size_t)i * scratch_stride, out6, &prn);
+            if (rc < 0) err |= 1;
+            else if (rc > 0) got += 1;
+        }
+        if (err) return -1;
+        if (!got) break;
+        done += got;
+    }
+    return done;
+}
+

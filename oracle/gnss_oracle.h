@@ -186,6 +186,10 @@ void orc_ring_copy_to_slice(const orc_ring *r, uint64_t start, orc_c32 *dest, si
 int orc_trk_update(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float out6[6],
                    uint8_t *msg_prn);
 
+/* TrackingManager::process_channels :351-371 (rayon par_iter_mut -> OpenMP), looped like run() :384-415 */
+int64_t orc_trk_process_channels(orc_trk_channel *ch, int n_channels, const orc_ring *ring, orc_c32 *scratch,
+                                 size_t scratch_stride, int max_passes, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

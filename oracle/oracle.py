@@ -114,6 +114,8 @@ def lib(native=False):
     L.orc_ring_get_head.restype = u64
     L.orc_ring_copy_to_slice.argtypes = [RP, u64, vp, sz]
     L.orc_trk_update.argtypes = [TP, RP, vp, vp, C.POINTER(C.c_uint8)]
+    L.orc_trk_process_channels.argtypes = [vp, C.c_int, RP, vp, C.c_size_t, C.c_int, C.c_int]
+    L.orc_trk_process_channels.restype = C.c_int64
     _libs[key] = L
     return L
 
@@ -368,6 +370,22 @@ class TrackingChannel:
         if rc < 0:
             raise IndexError("update: the reference would panic")
         return rc, out, (("SatelliteLost", mp.value) if rc == 2 else None)
+
+
+def process_channels(channels, ring, max_passes, n_threads=1, native=False):
+    """TrackingManager::process_channels (do_tracking.rs:351-371) looped like run() (:384-415): one task per channel.
+    channels: list of TrackingChannel; their state is updated in place.  Returns channel-epochs processed."""
+    arr = (TrkChannel * len(channels))(*[ch.c for ch in channels])
+    stride = max(int(max(ch.c.num_samples_per_code for ch in channels)) * 2, 16)
+    stride = max(stride, int(channels[0].c.fs / 1000.0) * 2)
+    scratch = np.zeros(stride * len(channels), np.complex64)
+    done = lib(native).orc_trk_process_channels(C.cast(arr, C.c_void_p), len(channels), C.byref(ring.r), _p(scratch), stride,
+                                                max_passes, n_threads)
+    if done < 0:
+        raise IndexError("process_channels: the reference would panic")
+    for ch, c in zip(channels, arr):
+        C.memmove(C.byref(ch.c), C.byref(c), C.sizeof(TrkChannel))
+    return int(done)
 
 
 class MulticastRingBuffer:

@@ -229,3 +229,34 @@ def test_every_other_plan_small_scene(gpu, oracle, fs, N):
     # within half a chip of the simulated code start (the top of the correlation triangle is several samples wide)
     assert abs(eng.search(x)[0]["code_phase_samples"] - N // 3) <= max(1, int(fs / 1.023e6 / 2))
     eng.close()
+
+
+def test_native_comm_single_rank_allgather_and_decide(gpu, hipbuf):
+    """gm_comm_* / gm_acq_allgather_metrics through a real RCCL communicator of one rank, driven
+    without PyTorch like a Rust host would: the regrouped block equals the local metrics bit for bit and the decision
+    on it equals gm_acq_search's."""
+    from gnss_sdr_rs_amd import acquisition as A, distributed as Dm, synth
+    t = A.ca_code_table()
+    fs, N, M = 2.048e6, 2048, 3
+    dop = np.array([-1000.0, -500.0, 0.0, 500.0, 1000.0], np.float32)
+    sats = [dict(prn_row=4, cn0_dbhz=52.0, doppler_hz=-430.0, code_start=1234),
+            dict(prn_row=9, cn0_dbhz=50.0, doppler_hz=610.0, code_start=7)]
+    x = synth.to_c32(synth.make_scene(t, fs, 10_000.0, M * N, sats, config_id=11))
+    prns = [5, 10, 31, 1, 2, 20]
+    P, D = len(prns), dop.size
+    eng = A.AcquisitionEngine(fs, 10_000.0, N, doppler_hz=dop, prn_ids=prns, n_integrations=M)
+    ref = eng.search(x)
+    d_x = hipbuf.upload(x)
+    d_met = hipbuf.alloc(3 * P * D * 4)
+    d_all = hipbuf.alloc(3 * P * D * 4, fill=0xFF)
+    comm = Dm.NativeComm(1, 0, Dm.NativeComm.unique_id())
+    eng.search_dev(d_x, A.FMT_C32, d_met)
+    comm.allgather_metrics(eng, d_all, d_met)
+    eng.decide_dev(d_all, n_prn=P, prn_ids=np.asarray(prns, np.uint8))
+    got = eng.fetch_results(P)
+    assert (hipbuf.download(d_all, 3 * P * D * 4, np.uint32) == hipbuf.download(d_met, 3 * P * D * 4, np.uint32)).all()
+    key = lambda r: r and (r["prn"], r["code_phase_samples"], r["doppler_bin"], r["mag_relative"])
+    assert [key(r) for r in got] == [key(r) for r in ref]
+    assert sum(r is not None for r in got) == 2
+    comm.close()
+    eng.close()

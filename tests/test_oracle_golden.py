@@ -141,3 +141,36 @@ def test_is_good_satellite_lane_order(oracle):
     assert got == float(s)
     avg = np.float32(np.float32(s - p.max()) / np.float32(8002))
     assert ok == bool(np.float32(p.max() / avg) > 7.0)
+
+
+def test_process_channels_equals_per_channel_update():
+    """orc_trk_process_channels (the rayon fan-out of do_tracking.rs:364-371 as an OpenMP loop, used by bench.py's
+    tracking cpu_baseline) leaves exactly the state that per-channel update() calls leave."""
+    import numpy as np
+    from oracle import oracle as O
+    from gnss_sdr_rs_amd import synth
+    ca = O.ca_code_table()
+    fs = 4.0e6
+    sc = synth.tracking_scene(ca, fs, 0.0, [3, 7, 12], 8, config_id=9, cn0=50.0)
+    ring = O.MulticastRingBuffer(1 << 16)
+    ring.write_samples(synth.to_c32(sc["x"]))
+
+    def fresh():
+        out = []
+        for i, s in enumerate(sc["sats"]):
+            ch = O.TrackingChannel(i, fs, code_index_mode=O.CODE_INDEX_FIXED)
+            ch.start(dict(prn=s["prn"], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=s["doppler_hz"] + 15.0, fs=fs,
+                          mag_relative=1.0, sample_global_index=s["code_start"]))
+            out.append(ch)
+        return out
+    a, b = fresh(), fresh()
+    done = O.process_channels(a, ring, 100, n_threads=3)
+    n_seq = 0
+    for ch in b:
+        while ch.update(ring)[0] > 0:
+            n_seq += 1
+    assert done == n_seq and done >= 3 * 5
+    for x, y in zip(a, b):
+        for f in ("carrier_freq", "carrier_phase", "code_phase", "code_rate", "i_prompt", "q_prompt", "next_sample_index",
+                  "lost_counter"):
+            assert getattr(x.c, f) == getattr(y.c, f), f
