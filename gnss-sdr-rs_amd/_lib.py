@@ -106,6 +106,9 @@ SIGNATURES = {
     "gm_ring_write_samples": (_i, [_vp, _vp, _sz]),
     "gm_ring_get_head": (_i, [_vp, C.POINTER(_u64)]),
     "gm_ring_copy_to_slice": (_i, [_vp, _u64, _vp, _sz]),
+    "gm_ring_write_samples_async": (_i, [_vp, _vp, _sz]),
+    "gm_ring_flush": (_i, [_vp]),
+    "gm_ring_wait_head": (_i, [_vp, _u64, _u32, _vp]),
     "gm_trk_create": (_i, [C.POINTER(TrkCfg), C.POINTER(_vp)]),
     "gm_trk_destroy": (_i, [_vp]),
     "gm_trk_start": (_i, [_vp, _u32, C.POINTER(AcqResult)]),

@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -117,7 +119,32 @@ struct gm_ring {
     // single writer / many readers like the reference ring: the writer publishes `head` (release) after its
     // synchronous H2D copy, readers load it (acquire) before launching kernels on the mirror
     std::atomic<uint64_t> head{0};
+    // `notifier` + `condvar` of the reference ring (multicast_ring_buffer.rs:42-43,95-98): gm_ring_wait_head sleeps here
+    std::mutex notifier;
+    std::condition_variable condvar;
+    // asynchronous writer (gm_ring_write_samples_async): pinned staging slots, a copy stream, and `head` published
+    // by a host callback that the stream runs after the copy has landed
+    static constexpr int SLOTS = 4;
+    static constexpr size_t SLOT_SAMPLES = size_t(1) << 16;
+    cf* staging[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t slot_done[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool slot_used[SLOTS] = {false, false, false, false};
+    hipStream_t copy_stream = nullptr;
+    uint64_t write_pos = 0;       // writer-private: samples enqueued so far (>= head)
+    uint64_t slot_seq = 0;
+    struct Publish { gm_ring* r; uint64_t new_head; };
+    std::vector<Publish*> publish_pool;
 };
+
+static void ring_publish(gm_ring* r, uint64_t new_head) {
+    r->head.store(new_head, std::memory_order_release);
+    std::lock_guard<std::mutex> g(r->notifier);     // "Wake up Tracking after writing new samples" (:94-98)
+    r->condvar.notify_all();
+}
+static void ring_publish_cb(void* p) {              // runs on a HIP runtime thread after the copy; no HIP calls here
+    auto* pub = static_cast<gm_ring::Publish*>(p);
+    ring_publish(pub->r, pub->new_head);
+}
 
 // ====================================================================== acquisition handle
 struct gm_acq {
@@ -733,8 +760,78 @@ int gm_ring_create(size_t buf_size, gm_ring** out) {
 int gm_ring_destroy(gm_ring* r) {
     if (!r) return GM_OK;
     hipSetDevice(r->device);
+    if (r->copy_stream) { hipStreamSynchronize(r->copy_stream); hipStreamDestroy(r->copy_stream); }
+    for (int i = 0; i < gm_ring::SLOTS; ++i) {
+        if (r->staging[i]) hipHostFree(r->staging[i]);
+        if (r->slot_done[i]) hipEventDestroy(r->slot_done[i]);
+    }
+    for (auto* p : r->publish_pool) delete p;
     hipFree(r->d_buf);
     delete r;
+    return GM_OK;
+}
+
+// write_samples without blocking the producer on the H2D copy: the samples are staged in pinned host
+// memory, copied on the ring's own stream, and `head` advances (and the Condvar fires) only once they are in HBM, so a
+// reader that sees the new head may launch kernels on the mirror without any stream dependency.  Single writer, like
+// the reference ring; do not mix with gm_ring_write_samples without a gm_ring_flush in between.
+int gm_ring_write_samples_async(gm_ring* r, const gm_c32* s, size_t n) {
+    if (!r || (!s && n)) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (n > r->size) return set_err(GM_ERR_OUT_OF_RANGE, "write larger than the ring");
+    if (int rc = ensure_device(r->device)) return rc;
+    if (!r->copy_stream) {
+        HIPC(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < gm_ring::SLOTS; ++i) {
+            HIPC(hipHostMalloc(reinterpret_cast<void**>(&r->staging[i]), gm_ring::SLOT_SAMPLES * 8, hipHostMallocDefault));
+            HIPC(hipEventCreateWithFlags(&r->slot_done[i], hipEventDisableTiming));
+        }
+        r->write_pos = r->head.load(std::memory_order_relaxed);
+    }
+    const cf* src = reinterpret_cast<const cf*>(s);
+    while (n) {
+        const size_t chunk = n < gm_ring::SLOT_SAMPLES ? n : gm_ring::SLOT_SAMPLES;
+        const int slot = int(r->slot_seq++ % gm_ring::SLOTS);
+        if (r->slot_used[slot]) HIPC(hipEventSynchronize(r->slot_done[slot]));
+        memcpy(r->staging[slot], src, chunk * 8);
+        const size_t start = size_t(r->write_pos & r->mask);
+        const size_t first = start + chunk <= r->size ? chunk : r->size - start;
+        HIPC(hipMemcpyAsync(r->d_buf + start, r->staging[slot], first * 8, hipMemcpyHostToDevice, r->copy_stream));
+        if (first < chunk)
+            HIPC(hipMemcpyAsync(r->d_buf, r->staging[slot] + first, (chunk - first) * 8, hipMemcpyHostToDevice, r->copy_stream));
+        HIPC(hipEventRecord(r->slot_done[slot], r->copy_stream));
+        r->slot_used[slot] = true;
+        r->write_pos += chunk;
+        auto* pub = new gm_ring::Publish{r, r->write_pos};
+        r->publish_pool.push_back(pub);
+        HIPC(hipLaunchHostFunc(r->copy_stream, ring_publish_cb, pub));
+        src += chunk; n -= chunk;
+    }
+    if (r->publish_pool.size() > 4096) {     // bound the bookkeeping: everything before the last sync has run
+        HIPC(hipStreamSynchronize(r->copy_stream));
+        for (auto* p : r->publish_pool) delete p;
+        r->publish_pool.clear();
+    }
+    return GM_OK;
+}
+
+int gm_ring_flush(gm_ring* r) {
+    if (!r) return set_err(GM_ERR_INVALID_ARG, "null ring");
+    if (!r->copy_stream) return GM_OK;
+    if (int rc = ensure_device(r->device)) return rc;
+    HIPC(hipStreamSynchronize(r->copy_stream));
+    for (auto* p : r->publish_pool) delete p;
+    r->publish_pool.clear();
+    return GM_OK;
+}
+
+// The Condvar wait of do_tracking::run (do_tracking.rs:392-406): sleep until head has reached `required_idx`
+// (wrapping signed comparison like :393) or timeout_ms has passed.  *reached = 1 / 0.
+int gm_ring_wait_head(gm_ring* r, uint64_t required_idx, uint32_t timeout_ms, int* reached) {
+    if (!r) return set_err(GM_ERR_INVALID_ARG, "null ring");
+    auto ok = [&] { return int64_t(r->head.load(std::memory_order_acquire) - required_idx) >= 0; };
+    std::unique_lock<std::mutex> g(r->notifier);
+    const bool got = r->condvar.wait_for(g, std::chrono::milliseconds(timeout_ms), ok);
+    if (reached) *reached = got ? 1 : 0;
     return GM_OK;
 }
 
@@ -751,7 +848,8 @@ int gm_ring_write_samples(gm_ring* r, const gm_c32* s, size_t n) {
         HIPC(hipMemcpy(r->d_buf + start, s, first * 8, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(r->d_buf, s + first, (n - first) * 8, hipMemcpyHostToDevice));
     }
-    r->head.store(cur + n, std::memory_order_release);
+    r->write_pos = cur + n;
+    ring_publish(r, cur + n);
     return GM_OK;
 }
 

@@ -178,6 +178,11 @@ public:
     MulticastRingBuffer(const MulticastRingBuffer&) = delete;
     gm_ring* handle() const { return h_; }
     void write_samples(const std::vector<Complex32>& s) { check(gm_ring_write_samples(h_, reinterpret_cast<const gm_c32*>(s.data()), s.size()), "write_samples"); }
+    // producer side that never waits for the H2D copy (pinned staging, head published when the data is in HBM)
+    void write_samples_async(const Complex32* s, size_t n) { check(gm_ring_write_samples_async(h_, reinterpret_cast<const gm_c32*>(s), n), "write_samples_async"); }
+    void flush() { check(gm_ring_flush(h_), "flush"); }
+    // notifier / condvar (:42-43): true once head >= required_idx
+    bool wait_head(uint64_t required_idx, uint32_t timeout_ms) const { int r = 0; check(gm_ring_wait_head(h_, required_idx, timeout_ms, &r), "wait_head"); return r != 0; }
     uint64_t get_head() const { uint64_t h = 0; check(gm_ring_get_head(h_, &h), "get_head"); return h; }
     void copy_to_slice(uint64_t start, std::vector<Complex32>& dest) const {
         check(gm_ring_copy_to_slice(h_, start, reinterpret_cast<gm_c32*>(dest.data()), dest.size()), "copy_to_slice");
@@ -338,7 +343,18 @@ inline void run_tracking(MulticastRingBuffer& multi_ring_buf, Channel<Acquisitio
                     trk_to_acq.send(TrackingMessage{TrackingMessageKind::SatelliteLost, prn});
                 }
         ctl.trk_passes += done;
-        if (done == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));   // Condvar wait (:392-406)
+        if (done == 0) {                                                                // Condvar wait (:392-406)
+            uint64_t required_idx = 0; bool any = false;                                // next_tracking_index (:373-381)
+            for (uint32_t c = 0; c < n_channels; ++c) {
+                const gm_trk_state st = manager.channels[c].state();
+                if (!st.active) continue;
+                const uint64_t need = st.next_sample_index + st.num_samples_per_code;
+                if (!any || need < required_idx) required_idx = need;
+                any = true;
+            }
+            if (any) multi_ring_buf.wait_head(required_idx, 2);     // bounded so that `stop` and new acquisitions are seen
+            else std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
     }
     if (final_states) {
         final_states->resize(n_channels);

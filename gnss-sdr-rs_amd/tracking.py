@@ -51,6 +51,20 @@ class MulticastRingBuffer:
         s = np.ascontiguousarray(samples, np.complex64)
         check(lib().gm_ring_write_samples(self._h, _p(s), s.size), "write_samples")
 
+    def write_samples_async(self, samples):
+        """write_samples without blocking on the H2D copy: head advances once the samples are in HBM."""
+        s = np.ascontiguousarray(samples, np.complex64)
+        check(lib().gm_ring_write_samples_async(self._h, _p(s), s.size), "write_samples_async")
+
+    def flush(self):
+        check(lib().gm_ring_flush(self._h), "flush")
+
+    def wait_head(self, required_idx, timeout_ms=1000):
+        """The Condvar wait of do_tracking::run (:392-406).  True if head reached required_idx."""
+        r = C.c_int(0)
+        check(lib().gm_ring_wait_head(self._h, int(required_idx), int(timeout_ms), C.byref(r)), "wait_head")
+        return bool(r.value)
+
     def get_head(self):
         h = C.c_uint64(0)
         check(lib().gm_ring_get_head(self._h, C.byref(h)), "get_head")

@@ -216,6 +216,13 @@ int gm_ring_destroy(gm_ring *r);
 int gm_ring_write_samples(gm_ring *r, const gm_c32 *samples, size_t n);  /* :66-101 */
 int gm_ring_get_head(gm_ring *r, uint64_t *head);                        /* :103-105 */
 int gm_ring_copy_to_slice(gm_ring *r, uint64_t start, gm_c32 *dest, size_t n); /* :107-129 */
+/* write_samples that does not block the producer on the H2D copy: pinned staging + the ring's own copy stream; `head`
+ * advances (and the Condvar fires) only after the samples have landed in HBM.  gm_ring_flush waits for all of it. */
+int gm_ring_write_samples_async(gm_ring *r, const gm_c32 *samples, size_t n);
+int gm_ring_flush(gm_ring *r);
+/* The notifier/Condvar of the reference ring (:42-43, :94-98) as used by do_tracking::run (do_tracking.rs:392-406):
+ * sleep until head >= required_idx (wrapping signed comparison) or timeout_ms elapsed; *reached = 1 / 0. */
+int gm_ring_wait_head(gm_ring *r, uint64_t required_idx, uint32_t timeout_ms, int *reached);
 
 /* ------------------------------------------------------------------ Tracking
  * The evolving fields of TrackingChannel (src/tracking/do_tracking.rs:88-116). */

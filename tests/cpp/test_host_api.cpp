@@ -151,9 +151,11 @@ static int test_receiver_threads() {
     std::thread t_acq([&] { init(0); run_acquisition(ring, fs, 0.0f, acq_to_trk, trk_to_acq, ctl, opt); });
     std::thread t_trk([&] { init(0); run_tracking(ring, acq_to_trk, trk_to_acq, fs, ctl, GM_CODE_INDEX_FIXED, 15, &finals); });
     for (size_t off = 0; off < x.size(); off += 2048) {           // the block pump, ~1 ms of signal per ms of wall time x 4
-        ring.write_samples(std::vector<Complex32>(x.begin() + off, x.begin() + off + 2048));
+        ring.write_samples_async(x.data() + off, 2048);           // pinned staging, head published once in HBM
         std::this_thread::sleep_for(std::chrono::microseconds(120));
     }
+    ring.flush();
+    CHECK(ring.get_head() == x.size());
     for (int i = 0; i < 400 && ctl.trk_passes.load() < 120; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(5));
     std::this_thread::sleep_for(std::chrono::milliseconds(50));
     ctl.stop = true;

@@ -192,3 +192,39 @@ def test_update_all_matches_per_channel_oracle(gpu, oracle):
         assert s.carrier_freq == pytest.approx(oc.c.carrier_freq, abs=5e-3)
     assert not proc[:, 6:].any()             # idle channels never run
     mgr.close(); ring.close()
+
+
+def test_ring_async_writer_and_condvar(gpu):
+    """gm_ring_write_samples_async / gm_ring_flush / gm_ring_wait_head: same bytes and head as the
+    synchronous writer (multicast_ring_buffer.rs:66-101), wrap-around included; the Condvar wakes a waiting reader
+    (do_tracking.rs:392-406)."""
+    import threading
+    import time
+    from gnss_sdr_rs_amd import tracking as T
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal(200_000) + 1j * rng.standard_normal(200_000)).astype(np.complex64)
+    a, b = T.MulticastRingBuffer(1 << 16), T.MulticastRingBuffer(1 << 16)
+    off = 0
+    for n in (1000, 65536, 7, 40_000, 65_000, 28_457):      # slots, multi-chunk writes and wraps
+        a.write_samples(x[off:off + n])
+        b.write_samples_async(x[off:off + n])
+        off += n
+    b.flush()
+    assert a.get_head() == b.get_head() == off
+    assert (a.copy_to_slice(off - 65536, 65536).view(np.uint32) == b.copy_to_slice(off - 65536, 65536).view(np.uint32)).all()
+    assert (b.copy_to_slice(off - 65536, 65536) == x[off - 65536:off]).all()
+    assert b.wait_head(off, 0) and not b.wait_head(off + 1, 5)
+    woke = {}
+
+    def reader():
+        t0 = time.perf_counter()
+        woke["ok"] = b.wait_head(off + 500, 5000)
+        woke["dt"] = time.perf_counter() - t0
+    th = threading.Thread(target=reader)
+    th.start()
+    time.sleep(0.05)
+    b.write_samples_async(x[:500])
+    th.join()
+    assert woke["ok"] and woke["dt"] < 2.0
+    a.close()
+    b.close()
