@@ -109,6 +109,15 @@ SIGNATURES = {
     "gm_ring_write_samples_async": (_i, [_vp, _vp, _sz]),
     "gm_ring_flush": (_i, [_vp]),
     "gm_ring_wait_head": (_i, [_vp, _u64, _u32, _vp]),
+    "gm_frontend_create": (_i, [_f, _f, _f, _vp]),
+    "gm_frontend_destroy": (_i, [_vp]),
+    "gm_frontend_lut": (_i, [_vp, _vp, _vp, _vp]),
+    "gm_frontend_get_state": (_i, [_vp, _vp, _vp, _vp]),
+    "gm_frontend_set_state": (_i, [_vp, _f, _vp, _vp]),
+    "gm_frontend_process_block": (_i, [_vp, _vp, _sz]),
+    "gm_frontend_process_dev": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
+    "gm_frontend_synchronize": (_i, [_vp]),
+    "gm_frontend_write_ring": (_i, [_vp, _vp, _vp, _sz, _i]),
     "gm_trk_create": (_i, [C.POINTER(TrkCfg), C.POINTER(_vp)]),
     "gm_trk_destroy": (_i, [_vp]),
     "gm_trk_start": (_i, [_vp, _u32, C.POINTER(AcqResult)]),

@@ -145,6 +145,28 @@ static void ring_publish_cb(void* p) {              // runs on a HIP runtime thr
     auto* pub = static_cast<gm_ring::Publish*>(p);
     ring_publish(pub->r, pub->new_head);
 }
+static int ring_async_init(gm_ring* r) {
+    if (r->copy_stream) return GM_OK;
+    HIPC(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < gm_ring::SLOTS; ++i) {
+        HIPC(hipHostMalloc(reinterpret_cast<void**>(&r->staging[i]), gm_ring::SLOT_SAMPLES * 8, hipHostMallocDefault));
+        HIPC(hipEventCreateWithFlags(&r->slot_done[i], hipEventDisableTiming));
+    }
+    r->write_pos = r->head.load(std::memory_order_relaxed);
+    return GM_OK;
+}
+// after the work of one chunk has been enqueued on copy_stream: publish head = write_pos once it has run
+static int ring_enqueue_publish(gm_ring* r) {
+    if (r->publish_pool.size() > 4096) {     // bound the bookkeeping: everything enqueued before this sync has run
+        HIPC(hipStreamSynchronize(r->copy_stream));
+        for (auto* p : r->publish_pool) delete p;
+        r->publish_pool.clear();
+    }
+    auto* pub = new gm_ring::Publish{r, r->write_pos};
+    r->publish_pool.push_back(pub);
+    HIPC(hipLaunchHostFunc(r->copy_stream, ring_publish_cb, pub));
+    return GM_OK;
+}
 
 // ====================================================================== acquisition handle
 struct gm_acq {
@@ -779,14 +801,7 @@ int gm_ring_write_samples_async(gm_ring* r, const gm_c32* s, size_t n) {
     if (!r || (!s && n)) return set_err(GM_ERR_INVALID_ARG, "null pointer");
     if (n > r->size) return set_err(GM_ERR_OUT_OF_RANGE, "write larger than the ring");
     if (int rc = ensure_device(r->device)) return rc;
-    if (!r->copy_stream) {
-        HIPC(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
-        for (int i = 0; i < gm_ring::SLOTS; ++i) {
-            HIPC(hipHostMalloc(reinterpret_cast<void**>(&r->staging[i]), gm_ring::SLOT_SAMPLES * 8, hipHostMallocDefault));
-            HIPC(hipEventCreateWithFlags(&r->slot_done[i], hipEventDisableTiming));
-        }
-        r->write_pos = r->head.load(std::memory_order_relaxed);
-    }
+    if (int rc = ring_async_init(r)) return rc;
     const cf* src = reinterpret_cast<const cf*>(s);
     while (n) {
         const size_t chunk = n < gm_ring::SLOT_SAMPLES ? n : gm_ring::SLOT_SAMPLES;
@@ -801,15 +816,8 @@ int gm_ring_write_samples_async(gm_ring* r, const gm_c32* s, size_t n) {
         HIPC(hipEventRecord(r->slot_done[slot], r->copy_stream));
         r->slot_used[slot] = true;
         r->write_pos += chunk;
-        auto* pub = new gm_ring::Publish{r, r->write_pos};
-        r->publish_pool.push_back(pub);
-        HIPC(hipLaunchHostFunc(r->copy_stream, ring_publish_cb, pub));
+        if (int rc = ring_enqueue_publish(r)) return rc;
         src += chunk; n -= chunk;
-    }
-    if (r->publish_pool.size() > 4096) {     // bound the bookkeeping: everything before the last sync has run
-        HIPC(hipStreamSynchronize(r->copy_stream));
-        for (auto* p : r->publish_pool) delete p;
-        r->publish_pool.clear();
     }
     return GM_OK;
 }
@@ -1240,6 +1248,163 @@ int gm_trk_last_timing(gm_trk* t, float* ms_total, uint32_t* launches) {
     HIPC(hipEventElapsedTime(&ms, t->ev0, t->ev1));
     if (ms_total) *ms_total = ms;
     if (launches) *launches = t->timed_launches;
+    return GM_OK;
+}
+
+}  // extern "C"
+
+// ====================================================================== digital front-end
+struct gm_frontend {
+    int device = -1;
+    float f_if = 0, fs_in = 0, fs_out = 0, phase_step = 0, alpha = 0.001f, con = 0;
+    std::vector<float> lut;                 // [2][2048]
+    float* d_lut = nullptr;
+    gm::FeState* d_state = nullptr;
+    hipStream_t stream = nullptr;
+    void* d_io = nullptr;                   // scratch for the host-buffer entry
+    size_t io_cap = 0;
+    void* d_raw[gm_ring::SLOTS] = {nullptr, nullptr, nullptr, nullptr};   // raw-format landing zones of the ring writer
+};
+
+static int frontend_launch(gm_frontend* f, hipStream_t st, const void* d_in, int fmt, void* d_out, uint64_t out_start,
+                           uint64_t out_mask, size_t n) {
+    gm::FrontendArgs a{};
+    a.streams[0] = {d_in, d_out, out_start, out_mask, n, f->d_state};
+    a.lut = f->d_lut; a.phase_step = f->phase_step; a.alpha = f->alpha; a.con = f->con;
+    a.fast_fmod = fabsf(f->phase_step) < 2048.0f ? 1 : 0;     // false for NaN too
+    gm::launch_frontend(st, a, 1, fmt);
+    HIPC(hipGetLastError());
+    return GM_OK;
+}
+
+extern "C" {
+
+int gm_frontend_create(float f_if, float fs_in, float fs_out, gm_frontend** out) {   // DigitalFrontend::new frontend.rs:19-30
+    if (!out) return set_err(GM_ERR_INVALID_ARG, "null out");
+    *out = nullptr;
+    if (int rc = ensure_device(g_device)) return rc;
+    gm_frontend* f = new gm_frontend;
+    f->device = g_device; f->f_if = f_if; f->fs_in = fs_in; f->fs_out = fs_out;
+    f->lut.resize(2 * 2048);
+    for (int i = 0; i < 2048; ++i) {                          // NcoLut::new nco_lut.rs:28-32
+        const float angle = ((2.0f * PI_F) * float(i)) / 2048.0f;
+        f->lut[i] = cosf(angle);
+        f->lut[2048 + i] = -sinf(angle);
+    }
+    f->phase_step = (f_if / fs_in) * 2048.0f;                 // :34
+    f->alpha = 0.001f;                                        // DcRemoverSimd::new(0.001), frontend.rs:21
+    f->con = 1.0f - f->alpha;                                 // dc_remove.rs:12
+    hipError_t e = hipMalloc(&f->d_lut, 2 * 2048 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(f->d_lut, f->lut.data(), 2 * 2048 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&f->d_state, sizeof(gm::FeState));
+    if (e == hipSuccess) e = hipMemset(f->d_state, 0, sizeof(gm::FeState));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { gm_frontend_destroy(f); return hip_fail(e, "gm_frontend_create"); }
+    *out = f;
+    return GM_OK;
+}
+
+int gm_frontend_destroy(gm_frontend* f) {
+    if (!f) return GM_OK;
+    hipSetDevice(f->device);
+    if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
+    hipFree(f->d_lut); hipFree(f->d_state); hipFree(f->d_io);
+    for (void* p : f->d_raw) hipFree(p);
+    delete f;
+    return GM_OK;
+}
+
+int gm_frontend_lut(gm_frontend* f, float* lut_re, float* lut_im, float* phase_step) {
+    if (!f) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (lut_re) memcpy(lut_re, f->lut.data(), 2048 * sizeof(float));
+    if (lut_im) memcpy(lut_im, f->lut.data() + 2048, 2048 * sizeof(float));
+    if (phase_step) *phase_step = f->phase_step;
+    return GM_OK;
+}
+
+int gm_frontend_get_state(gm_frontend* f, float* phase_accumulator, float bias_re[8], float bias_im[8]) {
+    if (!f) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(f->device)) return rc;
+    gm::FeState s;
+    HIPC(hipStreamSynchronize(f->stream));
+    HIPC(hipMemcpy(&s, f->d_state, sizeof(s), hipMemcpyDeviceToHost));
+    if (phase_accumulator) *phase_accumulator = s.phase_accumulator;
+    if (bias_re) memcpy(bias_re, s.bias_re, sizeof(s.bias_re));
+    if (bias_im) memcpy(bias_im, s.bias_im, sizeof(s.bias_im));
+    return GM_OK;
+}
+
+int gm_frontend_set_state(gm_frontend* f, float phase_accumulator, const float bias_re[8], const float bias_im[8]) {
+    if (!f || !bias_re || !bias_im) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (int rc = ensure_device(f->device)) return rc;
+    gm::FeState s;
+    s.phase_accumulator = phase_accumulator;
+    memcpy(s.bias_re, bias_re, sizeof(s.bias_re));
+    memcpy(s.bias_im, bias_im, sizeof(s.bias_im));
+    HIPC(hipStreamSynchronize(f->stream));
+    HIPC(hipMemcpy(f->d_state, &s, sizeof(s), hipMemcpyHostToDevice));
+    return GM_OK;
+}
+
+// DigitalFrontend::process_block (frontend.rs:33-62) on a host buffer, in place: H2D, kernel, D2H.
+int gm_frontend_process_block(gm_frontend* f, float* raw_floats, size_t n_floats) {
+    if (!f || (!raw_floats && n_floats)) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (int rc = ensure_device(f->device)) return rc;
+    const size_t n = n_floats / 2;                // whole samples; an odd trailing float is never inside a 16-float chunk
+    if (!n) return GM_OK;
+    if (f->io_cap < n) {
+        hipFree(f->d_io); f->d_io = nullptr; f->io_cap = 0;
+        HIPC(hipMalloc(&f->d_io, n * 8));
+        f->io_cap = n;
+    }
+    HIPC(hipMemcpyAsync(f->d_io, raw_floats, n * 8, hipMemcpyHostToDevice, f->stream));
+    if (int rc = frontend_launch(f, f->stream, f->d_io, GM_FMT_C32, f->d_io, 0, ~0ull, n)) return rc;
+    HIPC(hipMemcpyAsync(raw_floats, f->d_io, n * 8, hipMemcpyDeviceToHost, f->stream));
+    HIPC(hipStreamSynchronize(f->stream));
+    return GM_OK;
+}
+
+// Device-resident form: d_in (c32 or int8 IQ) -> d_out (c32), asynchronous on `stream` (NULL: the handle's own).
+int gm_frontend_process_dev(gm_frontend* f, const void* d_in, int fmt, void* d_out, size_t n_samples, void* stream) {
+    if (!f || !d_in || !d_out) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (fmt != GM_FMT_C32 && fmt != GM_FMT_I8_IQ) return set_err(GM_ERR_INVALID_ARG, "front-end input is c32 or int8 IQ");
+    if (int rc = ensure_device(f->device)) return rc;
+    return frontend_launch(f, stream ? static_cast<hipStream_t>(stream) : f->stream, d_in, fmt, d_out, 0, ~0ull, n_samples);
+}
+
+int gm_frontend_synchronize(gm_frontend* f) {
+    if (!f) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(f->device)) return rc;
+    HIPC(hipStreamSynchronize(f->stream));
+    return GM_OK;
+}
+
+// rf_thread's block step (rf_thread.rs:43-48): process_block + shared_ring_buffer.write_samples, fused and
+// non-blocking: raw samples (c32, or int8 IQ = 2 B/sample over PCIe) are staged in the ring's pinned slots, copied on
+// the ring's stream, processed there straight into the ring mirror, and `head` is published when they have landed.
+int gm_frontend_write_ring(gm_frontend* f, gm_ring* r, const void* samples, size_t n_samples, int fmt) {
+    if (!f || !r || (!samples && n_samples)) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (fmt != GM_FMT_C32 && fmt != GM_FMT_I8_IQ) return set_err(GM_ERR_INVALID_ARG, "front-end input is c32 or int8 IQ");
+    if (f->device != r->device) return set_err(GM_ERR_INVALID_ARG, "front-end and ring live on different devices");
+    if (n_samples > r->size) return set_err(GM_ERR_OUT_OF_RANGE, "write larger than the ring");
+    if (int rc = ensure_device(r->device)) return rc;
+    if (int rc = ring_async_init(r)) return rc;
+    const size_t bps = fmt == GM_FMT_C32 ? 8 : 2;
+    const uint8_t* src = static_cast<const uint8_t*>(samples);
+    while (n_samples) {
+        const size_t chunk = n_samples < gm_ring::SLOT_SAMPLES ? n_samples : gm_ring::SLOT_SAMPLES;
+        const int slot = int(r->slot_seq++ % gm_ring::SLOTS);
+        if (r->slot_used[slot]) HIPC(hipEventSynchronize(r->slot_done[slot]));
+        if (!f->d_raw[slot]) HIPC(hipMalloc(&f->d_raw[slot], gm_ring::SLOT_SAMPLES * 8));
+        memcpy(r->staging[slot], src, chunk * bps);
+        HIPC(hipMemcpyAsync(f->d_raw[slot], r->staging[slot], chunk * bps, hipMemcpyHostToDevice, r->copy_stream));
+        if (int rc = frontend_launch(f, r->copy_stream, f->d_raw[slot], fmt, r->d_buf, r->write_pos, r->mask, chunk)) return rc;
+        HIPC(hipEventRecord(r->slot_done[slot], r->copy_stream));
+        r->slot_used[slot] = true;
+        r->write_pos += chunk;
+        if (int rc = ring_enqueue_publish(r)) return rc;
+        src += chunk * bps; n_samples -= chunk;
+    }
     return GM_OK;
 }
 

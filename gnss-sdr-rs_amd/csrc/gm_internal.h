@@ -90,4 +90,21 @@ void launch_trk_persistent(hipStream_t, const TrkDevCfg&, const int8_t* d_codes,
                            unsigned long long* d_xchg, gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost,
                            uint8_t* d_lost_prn, int* d_error, long long* d_stamps);
 
+// ---------------------------------------------------------------- digital front-end (fe_kernels.hip)
+struct FeState { float phase_accumulator; float bias_re[8]; float bias_im[8]; };   // NcoLut.phase_accumulator, DcRemoverSimd.bias_*
+struct FrontendArgs {
+    struct Stream {
+        const void* in;            // n_samples of c32 or int8 IQ (device)
+        void* out;                 // c32 destination: linear buffer (out_mask = ~0) or ring base (out_mask = size-1)
+        uint64_t out_start, out_mask;
+        size_t n_samples;
+        FeState* state;
+    };
+    Stream streams[8];
+    const float* lut;              // [2][2048]: lut_re, lut_im (nco_lut.rs:28-32), built on the host with glibc cosf/sinf
+    float phase_step, alpha, con;
+    int fast_fmod;                 // |phase_step| < 2048: fmodf reduces to one exact conditional add/subtract
+};
+void launch_frontend(hipStream_t, const FrontendArgs&, int n_streams, int fmt);
+
 }  // namespace gm

@@ -224,6 +224,29 @@ int gm_ring_flush(gm_ring *r);
  * sleep until head >= required_idx (wrapping signed comparison) or timeout_ms elapsed; *reached = 1 / 0. */
 int gm_ring_wait_head(gm_ring *r, uint64_t required_idx, uint32_t timeout_ms, int *reached);
 
+/* ------------------------------------------------------------------ Digital front-end
+ * rf::frontend::DigitalFrontend (src/rf/frontend.rs:6-62): DC removal (DcRemoverSimd, src/rf/dc_remove.rs:10-29:
+ * eight one-pole IIR lanes per component, alpha = 0.001) + LUT NCO down-mix (NcoLut, src/rf/nco_lut.rs:17-42: 2048
+ * entries, f32 phase accumulator `% 2048`) + mix_simd (:8-15), bit-exact with the reference's f32 evaluation order.
+ * Only whole chunks of 8 samples are processed (chunks_exact_mut(16), :35); a tail passes through unprocessed. */
+typedef struct gm_frontend gm_frontend;
+int gm_frontend_create(float f_if, float fs_in, float fs_out, gm_frontend **out);     /* ::new :19-30 */
+int gm_frontend_destroy(gm_frontend *f);
+/* NcoLut tables and phase_step (nco_lut.rs:25-34); any pointer may be NULL */
+int gm_frontend_lut(gm_frontend *f, float lut_re[2048], float lut_im[2048], float *phase_step);
+int gm_frontend_get_state(gm_frontend *f, float *phase_accumulator, float bias_re[8], float bias_im[8]);
+int gm_frontend_set_state(gm_frontend *f, float phase_accumulator, const float bias_re[8], const float bias_im[8]);
+/* process_block(&mut [f32]) :33-62 — host buffer of interleaved I/Q, in place (H2D + kernel + D2H, synchronous) */
+int gm_frontend_process_block(gm_frontend *f, float *raw_floats, size_t n_floats);
+/* device-resident form: d_in (GM_FMT_C32 or GM_FMT_I8_IQ) -> d_out (c32; may alias d_in for c32), asynchronous on
+ * `stream` (a hipStream_t, NULL -> the handle's own stream; gm_frontend_synchronize waits for that one) */
+int gm_frontend_process_dev(gm_frontend *f, const void *d_in, int fmt, void *d_out, size_t n_samples, void *stream);
+int gm_frontend_synchronize(gm_frontend *f);
+/* rf_thread's block step (src/rf/rf_thread.rs:43-48: process_block, then shared_ring_buffer.write_samples) fused and
+ * non-blocking: host samples (c32, or int8 IQ: 2 B/sample over PCIe, converted on the GPU) -> pinned staging -> front-end
+ * kernel writing straight into the ring mirror; head advances when the block is in HBM (gm_ring_flush to wait). */
+int gm_frontend_write_ring(gm_frontend *f, gm_ring *ring, const void *samples, size_t n_samples, int fmt);
+
 /* ------------------------------------------------------------------ Tracking
  * The evolving fields of TrackingChannel (src/tracking/do_tracking.rs:88-116). */
 typedef struct {

@@ -794,3 +794,53 @@ int64_t orc_trk_process_channels(orc_trk_channel *ch, int n_channels, const orc_
     return done;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Digital front-end (src/rf/frontend.rs, src/rf/nco_lut.rs, src/rf/dc_remove.rs)
+ * ------------------------------------------------------------------------------------------ */
+void orc_frontend_new(orc_frontend *fe, float f_if, float fs_in, float fs_out) { /* frontend.rs:19-30 */
+    (void)fs_out;                                                  /* stored but unused by the reference (:12-15) */
+    const float pi = 3.14159265358979323846f;                      /* std::f32::consts::PI */
+    for (int i = 0; i < ORC_LUT_SIZE; ++i) {                       /* NcoLut::new nco_lut.rs:28-32 */
+        const float angle = ((2.0f * pi) * (float)i) / (float)ORC_LUT_SIZE;
+        fe->lut_re[i] = cosf(angle);
+        fe->lut_im[i] = -sinf(angle);                              /* "Negative for downconversion" */
+    }
+    fe->phase_step = (f_if / fs_in) * (float)ORC_LUT_SIZE;         /* :34 */
+    fe->phase_accumulator = 0.0f;
+    fe->alpha = 0.001f;                                            /* DcRemoverSimd::new(0.001) frontend.rs:21 */
+    fe->con = 1.0f - fe->alpha;                                    /* dc_remove.rs:12 */
+    for (int j = 0; j < 8; ++j) fe->bias_re[j] = fe->bias_im[j] = 0.0f;
+}
+
+static size_t f32_as_usize(float v) {          /* Rust `as usize`: saturating, NaN -> 0 */
+    if (!(v > 0.0f)) return 0;
+    if (v >= 18446744073709551616.0f) return (size_t)-1;
+    return (size_t)v;
+}
+
+void orc_frontend_process_block(orc_frontend *fe, float *raw, size_t n_floats) { /* frontend.rs:33-62 */
+    for (size_t c = 0; c + 16 <= n_floats; c += 16) {              /* chunks_exact_mut(16) :35 */
+        float *chunk = raw + c;
+        float re[8], im[8];
+        for (int j = 0; j < 8; ++j) { re[j] = chunk[2 * j]; im[j] = chunk[2 * j + 1]; }   /* deinterleave :39 */
+        for (int j = 0; j < 8; ++j) {                              /* DcRemoverSimd::process_block dc_remove.rs:22-28 */
+            fe->bias_re[j] = fe->bias_re[j] * fe->con + re[j] * fe->alpha;
+            fe->bias_im[j] = fe->bias_im[j] * fe->con + im[j] * fe->alpha;
+            re[j] = re[j] - fe->bias_re[j];
+            im[j] = im[j] - fe->bias_im[j];
+        }
+        size_t idx[8];
+        for (int j = 0; j < 8; ++j) {                              /* :47-52 */
+            idx[j] = f32_as_usize(fe->phase_accumulator) % ORC_LUT_SIZE;
+            fe->phase_accumulator = fmodf(fe->phase_accumulator + fe->phase_step, (float)ORC_LUT_SIZE);
+        }
+        for (int j = 0; j < 8; ++j) {                              /* mix_simd nco_lut.rs:8-15 */
+            const float lc = fe->lut_re[idx[j]], ls = fe->lut_im[idx[j]];
+            const float mi = re[j] * lc + im[j] * ls;
+            const float mq = re[j] * ls - im[j] * lc;
+            chunk[2 * j] = mi;                                     /* interleave :59-61 */
+            chunk[2 * j + 1] = mq;
+        }
+    }
+}
+

@@ -186,6 +186,18 @@ void orc_ring_copy_to_slice(const orc_ring *r, uint64_t start, orc_c32 *dest, si
 int orc_trk_update(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float out6[6],
                    uint8_t *msg_prn);
 
+/* ---------------- digital front-end (src/rf/frontend.rs, nco_lut.rs, dc_remove.rs) — SURVEY §8 f2.
+ * The reference has no test for these files: PARITY UNPINNED beyond this line-by-line restatement. */
+#define ORC_LUT_SIZE 2048                       /* nco_lut.rs:4 */
+typedef struct {
+    float lut_re[ORC_LUT_SIZE], lut_im[ORC_LUT_SIZE];   /* NcoLut :17-22 */
+    float phase_accumulator, phase_step;
+    float bias_re[8], bias_im[8], alpha, con;           /* DcRemoverSimd, dc_remove.rs:3-8 (8 SIMD lanes) */
+} orc_frontend;
+void orc_frontend_new(orc_frontend *fe, float f_if, float fs_in, float fs_out);   /* frontend.rs:19-30 */
+/* DigitalFrontend::process_block frontend.rs:33-62: in place over interleaved I/Q f32; only whole chunks of 16 floats */
+void orc_frontend_process_block(orc_frontend *fe, float *raw_floats, size_t n_floats);
+
 /* TrackingManager::process_channels :351-371 (rayon par_iter_mut -> OpenMP), looped like run() :384-415 */
 int64_t orc_trk_process_channels(orc_trk_channel *ch, int n_channels, const orc_ring *ring, orc_c32 *scratch,
                                  size_t scratch_stride, int max_passes, int n_threads);

@@ -388,6 +388,32 @@ def process_channels(channels, ring, max_passes, n_threads=1, native=False):
     return int(done)
 
 
+class FrontendState(C.Structure):
+    _fields_ = [("lut_re", C.c_float * 2048), ("lut_im", C.c_float * 2048), ("phase_accumulator", C.c_float),
+                ("phase_step", C.c_float), ("bias_re", C.c_float * 8), ("bias_im", C.c_float * 8), ("alpha", C.c_float),
+                ("con", C.c_float)]
+
+
+class DigitalFrontend:
+    """rf::frontend::DigitalFrontend (frontend.rs:6-62) with NcoLut (nco_lut.rs:17-42) and DcRemoverSimd (dc_remove.rs)."""
+
+    def __init__(self, f_if, fs_in, fs_out, native=False):
+        self.s = FrontendState()
+        self._native = native
+        L = lib(native)
+        L.orc_frontend_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.orc_frontend_new.restype = None
+        L.orc_frontend_process_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_frontend_process_block.restype = None
+        L.orc_frontend_new(C.byref(self.s), f_if, fs_in, fs_out)
+
+    def process_block(self, raw_floats):
+        """in place on a float32 array of interleaved I/Q"""
+        assert raw_floats.dtype == np.float32 and raw_floats.flags.c_contiguous
+        lib(self._native).orc_frontend_process_block(C.byref(self.s), _p(raw_floats), raw_floats.size)
+        return raw_floats
+
+
 class MulticastRingBuffer:
     """utilities::multicast_ring_buffer::MulticastRingBuffer (multicast_ring_buffer.rs:36-130)"""
 
