@@ -229,6 +229,13 @@ def main():
         except Exception as e:
             out["cfg5_geometry"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ digital front-end, informative
+    if rank == 0 and world == 1:
+        try:
+            out["frontend"] = frontend_leg(torch, dev, not args.no_cpu_baseline)
+        except Exception as e:
+            out["frontend"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc, args.cpu_seconds)
@@ -319,6 +326,40 @@ def cfg5_leg(torch, stream, T):
     return {"workload": "36 ch x 50 Msps, 4092-chip BOC(1,1), 5 arms, 4 ms code periods (no reference code: stand-in codes)",
             "ch_msps": C * fs / 1e6 * (sig_s / dt), "ms_per_code_period": dt / periods * 1e3, "channels_locked": locked,
             "algorithmic_GBs": C * n * 8 * periods / dt / 1e9}
+
+
+def frontend_leg(torch, dev, with_cpu):
+    """DigitalFrontend::process_block (rf/frontend.rs:33-62) on 4 Mi samples of int8 IQ resident in HBM -> c32.  The
+    two f32 recurrences (NCO phase, DC bias) are sequential by construction (bit-exactness), so one stream runs at the
+    speed of the NCO chain on one lane; the requirement is the live sample rate (8-50 Msps)."""
+    from gnss_sdr_rs_amd import frontend as F, _lib
+    n = 1 << 22
+    rng = np.random.default_rng(2)
+    xi = rng.integers(-127, 128, 2 * n).astype(np.int8)
+    d_in = torch.from_numpy(xi).to(dev)
+    d_out = torch.empty(2 * n, dtype=torch.float32, device=dev)
+    fe = F.DigitalFrontend(4.1304e6, 16.3676e6, 16.3676e6)
+    st = torch.cuda.current_stream().cuda_stream
+    fe.process_dev(d_in.data_ptr(), _lib.FMT_I8_IQ, d_out.data_ptr(), n, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fe.process_dev(d_in.data_ptr(), _lib.FMT_I8_IQ, d_out.data_ptr(), n, st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    fe.close()
+    res = {"workload": "DC removal + LUT NCO down-mix, 4 Mi int8 IQ samples -> c32, one stream, bit-exact",
+           "msps": n / dt / 1e6, "ms": dt * 1e3}
+    if with_cpu:
+        from oracle import oracle as O
+        O.build(native=True)
+        ofe = O.DigitalFrontend(4.1304e6, 16.3676e6, 16.3676e6, native=True)
+        xf = xi.astype(np.float32)
+        ofe.process_block(xf[:1 << 16].copy())
+        t0 = time.perf_counter()
+        ofe.process_block(xf)
+        res["cpu_msps_one_thread"] = n / (time.perf_counter() - t0) / 1e6
+    return res
 
 
 def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0):

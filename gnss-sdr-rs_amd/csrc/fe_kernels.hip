@@ -8,7 +8,8 @@
 //   * the NCO phase chain (data-independent) runs on ONE lane of wave 0,
 //   * the 16 DC-bias chains run on 16 lanes of wave 1, concurrently with it,
 //   * everything else (load/convert, LUT gather, complex mix, store) is spread over the workgroup.
-// One workgroup per stream; a segment of 2048 samples costs ~the NCO chain (3 dependent VALU ops per sample).
+// One workgroup per stream; a segment of 2048 samples costs ~the NCO chain (2 dependent VALU ops per sample, measured
+// 9.1 ns: a lone wave issues a DEPENDENT VALU op every ~4.5 ns) + 3.5 us of load/mix: 22 us, 93 Msps per stream.
 // Compiled with -ffp-contract=off: a*b + c*d must round like rustc's (no FMA).
 #include "gm_internal.h"
 
@@ -22,6 +23,7 @@ constexpr int LUT = 2048;
 __device__ __forceinline__ uint32_t as_usize_mod_lut(float p) {   // `phase_accumulator as usize % LUT_SIZE` (:49)
     // Rust's float -> usize cast saturates: negative and NaN -> 0; |p| < 2^24 here on the fast path
     if (!(p > 0.0f)) return 0u;
+    if (p < 4.0e9f) return uint32_t(p) & (LUT - 1);
     if (p >= 1.8446744e19f) return uint32_t(0xFFFFFFFFFFFFFFFFull % LUT);
     return uint32_t(static_cast<unsigned long long>(p) % LUT);
 }
@@ -37,17 +39,30 @@ __device__ __forceinline__ void load_sample(const void* in, size_t i, float& re,
     }
 }
 
+// One segment of the phase chain (frontend.rs:47-52), fast form.  Scaling by 2^-11 commutes with f32 rounding, so the
+// chain is kept in revolutions r = |phase| / 2048 in [0, 1):  r' = fract(fl(r + |step|/2048)) is bit-for-bit
+// |fmodf(fl(phase + step), 2048)| / 2048 when phase and step have the same sign (fmodf keeps the dividend's sign; RNE is
+// symmetric under negation; for r + s in [1, 2) the subtraction of 1 is exact).  Two dependent VALU ops per sample.
+__device__ __forceinline__ void nco_segment_fast(float& r, float s_abs, float* s_ph, int L) {
+#pragma unroll 8
+    for (int k = 0; k < L; ++k) {
+        s_ph[k] = r;
+        r = __builtin_amdgcn_fractf(r + s_abs);
+    }
+}
+
 template <int FMT>
 __global__ __launch_bounds__(FE_T) void frontend_kernel(FrontendArgs a) {
     __shared__ float s_re[FE_SEG], s_im[FE_SEG];
     __shared__ float s_lre[LUT], s_lim[LUT];
-    __shared__ uint16_t s_idx[FE_SEG];
+    __shared__ float s_ph[FE_SEG];                         // phase_accumulator before each sample (x s_scale)
+    __shared__ float s_scale;
     const int tid = threadIdx.x;
     const FrontendArgs::Stream st = a.streams[blockIdx.x];
     for (int i = tid; i < LUT; i += FE_T) { s_lre[i] = a.lut[i]; s_lim[i] = a.lut[LUT + i]; }
 
     const size_t n8 = st.n_samples & ~size_t(7);          // chunks_exact_mut(16 floats) (:35)
-    float phase = 0.0f, bias = 0.0f;
+    float phase = 0.0f, bias = 0.0f, nco_scale = 1.0f;
     const bool nco_lane = tid == 0;
     const bool dc_lane = tid >= 64 && tid < 80;           // wave 1, lanes 0..15: lane j -> re lane j, 8+j -> im lane j
     const int dl = tid - 64;
@@ -61,24 +76,39 @@ __global__ __launch_bounds__(FE_T) void frontend_kernel(FrontendArgs a) {
         for (int i = tid; i < L; i += FE_T) load_sample<FMT>(st.in, seg + i, s_re[i], s_im[i]);
         __syncthreads();
         if (nco_lane) {                                   // frontend.rs:47-52
-            if (fast) {
-                for (int k = 0; k < L; ++k) {
-                    s_idx[k] = uint16_t(phase > 0.0f ? (uint32_t(phase) & (LUT - 1)) : 0u);
-                    float x = phase + step;               // |x| < 4096: fmodf(x, 2048) is one exact conditional step
-                    if (x >= 2048.0f) x -= 2048.0f;
-                    else if (x <= -2048.0f) x = -fabsf(x + 2048.0f);   // fmodf keeps the dividend's sign: -2048 -> -0.0
-                    phase = x;
-                }
+            // fast form: |phase|, |step| < 2048, same sign (or zero), step not so small that r + s could be subnormal
+            const bool neg = step < 0.0f;
+            const bool same_sign = neg ? !(phase > 0.0f) : !(phase < 0.0f);
+            if (fast && fabsf(phase) < 2048.0f && same_sign && (step == 0.0f || fabsf(step) > 1.0e-20f)) {
+                float r = fabsf(phase) * (1.0f / 2048.0f);
+                nco_segment_fast(r, fabsf(step) * (1.0f / 2048.0f), s_ph, L);
+                nco_scale = neg ? -2048.0f : 2048.0f;
+                phase = r * nco_scale;                      // -0.0 for a negative chain that landed on -2048
             } else {
                 for (int k = 0; k < L; ++k) {
-                    s_idx[k] = uint16_t(as_usize_mod_lut(phase));
+                    s_ph[k] = phase;
                     phase = fmodf(phase + step, 2048.0f);
                 }
+                nco_scale = 1.0f;
             }
+            s_scale = nco_scale;
         } else if (dc_lane) {                             // dc_remove.rs:22-28, lane j of the f32x8
             float* buf = dl < 8 ? s_re : s_im;
             const int j = dl & 7;
-            for (int k = j; k < L; k += 8) {
+            int k = j;
+            for (; k + 56 < L; k += 64) {                 // 8 steps per trip: LDS reads issued together, then the chain
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = buf[k + 8 * u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    bias = bias * con + x[u] * alpha;
+                    x[u] = x[u] - bias;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) buf[k + 8 * u] = x[u];
+            }
+            for (; k < L; k += 8) {
                 const float x = buf[k];
                 bias = bias * con + x * alpha;
                 buf[k] = x - bias;
@@ -87,7 +117,8 @@ __global__ __launch_bounds__(FE_T) void frontend_kernel(FrontendArgs a) {
         __syncthreads();
         for (int i = tid; i < L; i += FE_T) {             // mix_simd nco_lut.rs:8-15, interleave :59-61
             const float re = s_re[i], im = s_im[i];
-            const float lc = s_lre[s_idx[i]], ls = s_lim[s_idx[i]];
+            const uint32_t idx = as_usize_mod_lut(s_ph[i] * s_scale);   // `phase_accumulator as usize % LUT_SIZE` (:49)
+            const float lc = s_lre[idx], ls = s_lim[idx];
             float2 o;
             o.x = re * lc + im * ls;
             o.y = re * ls - im * lc;

@@ -189,6 +189,19 @@ public:
     }
 };
 
+// ---- rf::frontend::DigitalFrontend (src/rf/frontend.rs:6-62)
+class DigitalFrontend {
+    gm_frontend* h_ = nullptr;
+public:
+    DigitalFrontend(float f_if, float fs_in, float fs_out) { check(gm_frontend_create(f_if, fs_in, fs_out, &h_), "DigitalFrontend::new"); }   // :19-30
+    ~DigitalFrontend() { gm_frontend_destroy(h_); }
+    DigitalFrontend(const DigitalFrontend&) = delete;
+    void process_block(std::vector<float>& raw_floats) { check(gm_frontend_process_block(h_, raw_floats.data(), raw_floats.size()), "process_block"); }   // :33-62
+    // rf_thread's block step (rf_thread.rs:43-48): process_block + write_samples, fused on the GPU, non-blocking
+    void write_ring(MulticastRingBuffer& ring, const Complex32* block, size_t n) { check(gm_frontend_write_ring(h_, ring.handle(), block, n, GM_FMT_C32), "write_ring"); }
+    void write_ring_i8(MulticastRingBuffer& ring, const int8_t* iq, size_t n) { check(gm_frontend_write_ring(h_, ring.handle(), iq, n, GM_FMT_I8_IQ), "write_ring"); }
+};
+
 // ---- tracking::do_tracking (src/tracking/do_tracking.rs)
 struct LoopFilter {                                            // :52-71
     float tau1 = 0, tau2 = 0;
