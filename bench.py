@@ -206,6 +206,18 @@ def main():
         for _ in range(20):
             eng.search(xi8)
         out["config"]["host_buffer_api_ms_per_dwell"] = (time.perf_counter() - t1) / 20 * 1e3
+        # fine-Doppler refinement of the detections (2^20-point zero-padded FFT per satellite), informative
+        try:
+            r_host = eng.search(xi8)
+            fine = eng.finer_doppler(r_host)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                fine = eng.finer_doppler(r_host)
+            errs = [abs(f["freq_hz"] - (sc["f_if"] + s["doppler_hz"])) for s in sc["sats"] for f in [fine[s["prn"] - 1]] if f]
+            out["fine_doppler"] = {"satellites": len(errs), "fft_size": fine[sc["sats"][0]["prn"] - 1]["fft_size"],
+                                   "ms_per_call": (time.perf_counter() - t1) / 10 * 1e3, "max_abs_error_hz": max(errs)}
+        except Exception as e:
+            out["fine_doppler"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ configs[0] geometry on the GPU (informative)
     if rank == 0 and world == 1:

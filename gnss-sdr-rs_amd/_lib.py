@@ -83,6 +83,7 @@ SIGNATURES = {
     "gm_acq_search_dev": (_i, [_vp, _vp, _i, _vp]),
     "gm_acq_set_prn_mask": (_i, [_vp, _u64]),
     "gm_acq_decide_dev": (_i, [_vp, _vp, _u32, _vp, _u64]),
+    "gm_acq_finer_doppler": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "gm_comm_get_unique_id": (_i, [_vp]),
     "gm_comm_init": (_i, [_i, _i, _vp, _vp]),
     "gm_comm_destroy": (_i, [_vp]),

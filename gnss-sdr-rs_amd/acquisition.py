@@ -138,6 +138,26 @@ class AcquisitionEngine:
         check(st, "gm_acq_search_ring")
         return [res[i].as_dict() if found[i] else None for i in range(self.P)], tail.value
 
+    def finer_doppler(self, results):
+        """Fine-Doppler refinement (finer_doppler, acquisition_bk.rs:215-302) of the found results of the LAST search,
+        on that search's snapshot.  -> list (per worker) of dict(freq_hz, peak_index, peak_mag, fft_size) or None."""
+        n = len(results)
+        res = (AcqResult * n)()
+        found = np.zeros(n, np.uint8)
+        for i, r in enumerate(results):
+            if r:
+                found[i] = 1
+                for k, _ in AcqResult._fields_:
+                    setattr(res[i], k, r[k])
+        f = np.zeros(n, np.float32)
+        idx = np.zeros(n, np.uint64)
+        mag = np.zeros(n, np.float32)
+        size = C.c_uint64(0)
+        check(lib().gm_acq_finer_doppler(self._h, C.cast(res, C.c_void_p), _p(found), n, _p(f), _p(idx), _p(mag),
+                                         C.byref(size)), "gm_acq_finer_doppler")
+        return [dict(freq_hz=float(f[i]), peak_index=int(idx[i]), peak_mag=float(mag[i]), fft_size=size.value)
+                if found[i] else None for i in range(n)]
+
     def metrics(self):
         mx = np.zeros((self.P, self.D), np.float32)
         am = np.zeros((self.P, self.D), np.uint32)

@@ -312,6 +312,134 @@ __global__ __launch_bounds__(PL::T) void fft_batch_kernel(cf* __restrict__ data,
                            [&](int it, int r, cf val) { x[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
 }
 
+// ------------------------------------------------------------------------------------ fine Doppler
+// finer_doppler (acquisition_bk.rs:215-302): X = FFT_{N1*N2}( zero-pad( (s[cp+n] - mean) * chip(n) ) ), peak of |X|.
+// n = N2*n1 + n2, k = k1 + N1*k2:  X[k] = sum_n2 W_N2^{n2 k2} * [ W_N^{n2 k1} * sum_n1 x[N2 n1 + n2] W_N1^{n1 k1} ].
+template <class PL>
+__global__ __launch_bounds__(PL::T) void fine_cols_kernel(FineArgs a) {     // grid (N2, S); PL::N == N1
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    const uint32_t n2 = blockIdx.x, sat = blockIdx.y;
+    load_twiddles<PL>(tw, a.tw1, tid);
+    const uint32_t cp = a.sat_code_phase[sat];
+    const int8_t* chips = a.chips + size_t(a.sat_worker[sat]) * a.code_len;
+    const float mre = a.mean[0], mim = a.mean[1];
+    cf* dst = a.B + (size_t(sat) * a.N2 + n2) * PL::N;
+    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    const float inv_n = 2.0f / float(a.N1 * a.N2);
+    lds_transform<PL, false>(
+        [&](int it, int r) {
+            const uint32_t n1 = uint32_t((tid + it * PL::T) + r * NB0);
+            const uint32_t n = a.N2 * n1 + n2;
+            if (n >= a.size_use) return cf_make(0.0f, 0.0f);                  // zero padding (:255, :273)
+            const cf s = load_sample(a.samples, a.fmt, size_t(cp) + n);
+            const uint32_t ind = uint32_t(floorf((float(n) * a.code_rate) / a.fs)) % a.code_len;   // :241-247
+            const float c = float(chips[ind]);
+            return cf_make((s.x - mre) * c, (s.y - mim) * c);                 // :237, :266-272
+        },
+        [&](int it, int r, cf v) {
+            const uint32_t k1 = uint32_t((tid + it * PL::T) + r * NBL);
+            const uint32_t t = (n2 * k1) & (a.N1 * a.N2 - 1u);                // exact phase index mod N (N <= 2^24)
+            float sn, cs;
+            sincospif(float(t) * inv_n, &sn, &cs);                            // W_N^{n2 k1} = cos - j sin
+            dst[k1] = cf_make(__builtin_fmaf(v.x, cs, v.y * sn), __builtin_fmaf(v.y, cs, -(v.x * sn)));
+        },
+        lds, tw, tid);
+}
+
+template <class PL>
+__global__ __launch_bounds__(PL::T) void fine_rows_kernel(FineArgs a) {     // grid (N1, S); PL::N == N2
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    __shared__ float s_p[PL::T / 64];
+    __shared__ uint32_t s_k[PL::T / 64];
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    const uint32_t k1 = blockIdx.x, sat = blockIdx.y;
+    load_twiddles<PL>(tw, a.tw2, tid);
+    const cf* src = a.B + size_t(sat) * a.N2 * a.N1 + k1;
+    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    float best = -1.0f;
+    uint32_t bestk = 0xFFFFFFFFu;
+    lds_transform<PL, false>(
+        [&](int it, int r) { return src[size_t((tid + it * PL::T) + r * NB0) * a.N1]; },
+        [&](int it, int r, cf v) {
+            const uint32_t k = k1 + a.N1 * uint32_t((tid + it * PL::T) + r * NBL);
+            const float p = __builtin_fmaf(v.x, v.x, v.y * v.y);
+            if (p > best || (p == best && k < bestk)) { best = p; bestk = k; }   // first index of the maximum (:279-282)
+        },
+        lds, tw, tid);
+    for (int off = 32; off > 0; off >>= 1) {
+        const float op = __shfl_xor(best, off);
+        const uint32_t ok = __shfl_xor(bestk, off);
+        if (op > best || (op == best && ok < bestk)) { best = op; bestk = ok; }
+    }
+    if ((tid & 63) == 0) { s_p[tid >> 6] = best; s_k[tid >> 6] = bestk; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < PL::T / 64; ++w)
+            if (s_p[w] > best || (s_p[w] == best && s_k[w] < bestk)) { best = s_p[w]; bestk = s_k[w]; }
+        a.rowmax[size_t(sat) * a.N1 + k1] = best;
+        a.rowarg[size_t(sat) * a.N1 + k1] = bestk;
+    }
+}
+
+__global__ __launch_bounds__(256) void fine_final_kernel(const float* __restrict__ rowmax, const uint32_t* __restrict__ rowarg,
+                                                         uint32_t n_rows, float* __restrict__ peak_pow,
+                                                         uint32_t* __restrict__ peak_idx) {
+    __shared__ float s_p[4];
+    __shared__ uint32_t s_k[4];
+    const int tid = threadIdx.x;
+    const uint32_t sat = blockIdx.x;
+    float best = -1.0f;
+    uint32_t bestk = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < n_rows; i += 256) {
+        const float p = rowmax[size_t(sat) * n_rows + i];
+        const uint32_t k = rowarg[size_t(sat) * n_rows + i];
+        if (p > best || (p == best && k < bestk)) { best = p; bestk = k; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float op = __shfl_xor(best, off);
+        const uint32_t ok = __shfl_xor(bestk, off);
+        if (op > best || (op == best && ok < bestk)) { best = op; bestk = ok; }
+    }
+    if ((tid & 63) == 0) { s_p[tid >> 6] = best; s_k[tid >> 6] = bestk; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (s_p[w] > best || (s_p[w] == best && s_k[w] < bestk)) { best = s_p[w]; bestk = s_k[w]; }
+        peak_pow[sat] = best;
+        peak_idx[sat] = bestk;
+    }
+}
+void launch_fine_final(hipStream_t st, const float* rowmax, const uint32_t* rowarg, uint32_t n_rows, int n_sats,
+                       float* peak_pow, uint32_t* peak_idx) {
+    hipLaunchKernelGGL(fine_final_kernel, dim3(n_sats), dim3(256), 0, st, rowmax, rowarg, n_rows, peak_pow, peak_idx);
+}
+
+// mean of the whole snapshot (:236): per-lane f32 partial sums, tree-combined (the legacy adds sequentially in f32;
+// the difference is far below one part in 1e5 of the mean and the mean itself is ~1e-3 of the signal)
+__global__ __launch_bounds__(1024) void fine_mean_kernel(const void* __restrict__ samples, int fmt, uint32_t n, float* __restrict__ mean) {
+    __shared__ float s_re[16], s_im[16];
+    const int tid = threadIdx.x;
+    float re = 0.0f, im = 0.0f;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const cf v = load_sample(samples, fmt, i);
+        re += v.x; im += v.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) { re += __shfl_xor(re, off); im += __shfl_xor(im, off); }
+    if ((tid & 63) == 0) { s_re[tid >> 6] = re; s_im[tid >> 6] = im; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) { re += s_re[w]; im += s_im[w]; }
+        mean[0] = re / float(n);
+        mean[1] = im / float(n);
+    }
+}
+void launch_fine_mean(hipStream_t st, const void* samples, int fmt, uint32_t n, float* d_mean) {
+    hipLaunchKernelGGL(fine_mean_kernel, dim3(1), dim3(1024), 0, st, samples, fmt, n, d_mean);
+}
+
 // ------------------------------------------------------------------------------------ launchers
 template <class PL> struct Launch {
     static void fill_tw(cf* tw, bool inverse) {
@@ -352,9 +480,17 @@ template <class PL> struct Launch {
         if (inverse) hipLaunchKernelGGL((fft_batch_kernel<PL, true>), dim3(batch), dim3(PL::T), 0, st, data, tw);
         else hipLaunchKernelGGL((fft_batch_kernel<PL, false>), dim3(batch), dim3(PL::T), 0, st, data, tw);
     }
+    static constexpr bool POW2 = (PL::N & (PL::N - 1)) == 0;
+    static void fine_cols(hipStream_t st, const FineArgs& a, int n_sats) {
+        if constexpr (POW2) hipLaunchKernelGGL(fine_cols_kernel<PL>, dim3(a.N2, n_sats), dim3(PL::T), 0, st, a);
+    }
+    static void fine_rows(hipStream_t st, const FineArgs& a, int n_sats) {
+        if constexpr (POW2) hipLaunchKernelGGL(fine_rows_kernel<PL>, dim3(a.N1, n_sats), dim3(PL::T), 0, st, a);
+    }
     static constexpr PlanOps ops() {
         return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL),
-                       &fill_tw, &mix_fft, &corr, &code_fft, &fft_batch};
+                       &fill_tw, &mix_fft, &corr, &code_fft, &fft_batch,
+                       POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr};
     }
 };
 

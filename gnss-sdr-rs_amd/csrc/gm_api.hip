@@ -195,6 +195,19 @@ struct gm_acq {
     uint32_t results_cap = 0;
     const void* last_metrics = nullptr;
     Timing tm;
+    // fine Doppler (gm_acq_finer_doppler): host copy of the chip rows, lazily built device state
+    std::vector<int8_t> chips;             // [P][code_len]
+    uint32_t code_len = 1023;
+    const void* last_samples = nullptr;    // device snapshot of the last search
+    int last_fmt = GM_FMT_C32;
+    struct Fine {
+        const gm::PlanOps *p1 = nullptr, *p2 = nullptr;
+        uint32_t size_use = 0, sats_cap = 0;
+        int8_t* d_chips = nullptr;
+        cf *d_tw1 = nullptr, *d_tw2 = nullptr, *d_B = nullptr;
+        float *d_mean = nullptr, *d_rowmax = nullptr, *d_peak_pow = nullptr;
+        uint32_t *d_rowarg = nullptr, *d_sat_worker = nullptr, *d_sat_cp = nullptr, *d_peak_idx = nullptr;
+    } fine;
 };
 
 static int acq_set_mask(gm_acq* a, uint64_t mask) {
@@ -372,6 +385,10 @@ int gm_rfft_f32(size_t n, const float* in, gm_c32* out) {
 int gm_acq_destroy(gm_acq* a) {
     if (!a) return GM_OK;
     if (a->device >= 0) hipSetDevice(a->device);
+    hipFree(a->fine.d_chips); hipFree(a->fine.d_tw1); hipFree(a->fine.d_tw2); hipFree(a->fine.d_B); hipFree(a->fine.d_mean);
+    hipFree(a->fine.d_rowmax); hipFree(a->fine.d_rowarg); hipFree(a->fine.d_sat_worker); hipFree(a->fine.d_sat_cp);
+    hipFree(a->fine.d_peak_pow); hipFree(a->fine.d_peak_idx);
+    if (a->device >= 0) hipSetDevice(a->device);
     hipFree(a->d_tables); hipFree(a->d_tw_fwd); hipFree(a->d_tw_inv); hipFree(a->d_code_fft);
     hipFree(a->d_spectra); hipFree(a->d_table_freq); hipFree(a->d_code_samples); hipFree(a->d_samples);
     hipFree(a->d_metrics); hipFree(a->d_worker_list); hipFree(a->d_results); hipFree(a->d_found);
@@ -418,9 +435,12 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     }
     // replica samples (AcquisitionWorker::new :132-135)
     std::vector<int8_t> code_samples(P * N);
+    a->code_len = cfg->codes ? cfg->code_len : 1023u;
+    a->chips.resize(P * size_t(a->code_len));
     for (size_t p = 0; p < P; ++p) {
         if (cfg->codes) {
             if (!cfg->code_len) return fail(set_err(GM_ERR_INVALID_ARG, "code_len required with codes"));
+            memcpy(&a->chips[p * a->code_len], cfg->codes + p * cfg->code_len, cfg->code_len);
             rc = resample_code(cfg->codes + p * cfg->code_len, cfg->code_len, true, a->code_rate, cfg->fs, N,
                                &code_samples[p * N]);
         } else {
@@ -429,6 +449,7 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
             // rustfft's process() panics unless the replica length equals fft_size (:135-137)
             if (num_samples_per_code(CA_RATE, cfg->fs, CA_LEN) != N)
                 return fail(set_err(GM_ERR_INVALID_ARG, "fft_size != round(fs / 1 kHz)"));
+            memcpy(&a->chips[p * 1023], ca_table().rows[prn - 1], 1023);
             rc = resample_code(ca_table().rows[prn - 1], 1023, false, CA_RATE, cfg->fs, N, &code_samples[p * N]);
         }
         if (rc) return fail(set_err(rc, "code resampling index out of range"));
@@ -506,6 +527,7 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     if (t) { HIPC(hipEventRecord(ev[2], a->stream)); a->tm.count++; a->tm.decide_valid = false; }
     HIPC(hipGetLastError());
     a->last_metrics = met;
+    a->last_samples = d_samples; a->last_fmt = fmt;
     return GM_OK;
 }
 
@@ -602,6 +624,101 @@ int gm_acq_search_ring(gm_acq* a, gm_ring* ring, uint64_t prn_mask, gm_acq_resul
     if (int rc = gm_acq_decide_dev(a, nullptr, a->P, nullptr, local_tail)) return rc;
     if (local_tail_out) *local_tail_out = local_tail;
     return gm_acq_fetch_results(a, a->P, results, found);
+}
+
+// Fine Doppler: finer_doppler (acquisition_bk.rs:215-302, legacy) for every found result of the last
+// search, on the snapshot that search used (still resident in HBM).  fft_size = 8 * next_pow2((M-1)*N) as N1 x N2.
+int gm_acq_finer_doppler(gm_acq* a, const gm_acq_result* results, const uint8_t* found, uint32_t n_prn, float* fine_freq_hz,
+                         uint64_t* peak_index, float* peak_mag, uint64_t* fft_size_out) {
+    if (!a || !results || !found) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (n_prn > a->P) return set_err(GM_ERR_INVALID_ARG, "n_prn exceeds the handle's workers");
+    if (a->M < 2) return set_err(GM_ERR_INVALID_ARG, "fine Doppler needs num_integrations >= 2 ((M-1)*N samples after the code phase)");
+    if (!a->last_samples) return set_err(GM_ERR_INVALID_ARG, "no search has run on this handle yet");
+    if (int rc = ensure_device(a->device)) return rc;
+    gm_acq::Fine& f = a->fine;
+    const uint32_t size_use = (a->M - 1) * a->N;                         // :240
+    if (!f.p1) {
+        uint64_t p2 = 1;
+        while (p2 < size_use) p2 <<= 1;                                  // next_power_of_two :249
+        const uint64_t n = 8 * p2;
+        if (n > (1ull << 24)) return set_err(GM_ERR_UNSUPPORTED_N, "fine-Doppler FFT longer than 2^24");
+        // N = N1 * N2 with both factors among the power-of-two in-LDS plans, as square as possible
+        int lg = 0;
+        while ((1ull << lg) < n) ++lg;
+        const gm::PlanOps *b1 = nullptr, *b2 = nullptr;
+        for (int l2 = lg / 2; l2 >= 10 && !b1; --l2) {
+            const gm::PlanOps *q1 = gm::find_plan(1 << (lg - l2)), *q2 = gm::find_plan(1 << l2);
+            if (q1 && q2 && q1->fine_cols && q2->fine_rows) { b1 = q1; b2 = q2; }
+        }
+        if (!b1) return set_err(GM_ERR_UNSUPPORTED_N, "no pair of in-LDS plans factors the fine-Doppler FFT size");
+        std::vector<cf> t1(size_t(b1->tw_total) + 1), t2(size_t(b2->tw_total) + 1);
+        b1->fill_tw(t1.data(), false);
+        b2->fill_tw(t2.data(), false);
+        HIPC(hipMalloc(&f.d_tw1, t1.size() * 8));
+        HIPC(hipMalloc(&f.d_tw2, t2.size() * 8));
+        HIPC(hipMemcpy(f.d_tw1, t1.data(), t1.size() * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(f.d_tw2, t2.data(), t2.size() * 8, hipMemcpyHostToDevice));
+        HIPC(hipMalloc(&f.d_chips, a->chips.size()));
+        HIPC(hipMemcpy(f.d_chips, a->chips.data(), a->chips.size(), hipMemcpyHostToDevice));
+        HIPC(hipMalloc(&f.d_mean, 2 * sizeof(float)));
+        f.p1 = b1; f.p2 = b2; f.size_use = size_use;
+    }
+    const uint32_t N1 = uint32_t(f.p1->n), N2 = uint32_t(f.p2->n);
+    std::vector<uint32_t> workers, cps, slot(n_prn, 0xFFFFFFFFu);
+    for (uint32_t p = 0; p < n_prn; ++p) {
+        if (!found[p]) continue;
+        if (results[p].code_phase_samples + size_use > uint64_t(a->M) * a->N)
+            return set_err(GM_ERR_OUT_OF_RANGE, "code_phase + (M-1)*N exceeds the snapshot (:260 would panic)");
+        slot[p] = uint32_t(workers.size());
+        workers.push_back(p);
+        cps.push_back(uint32_t(results[p].code_phase_samples));
+    }
+    const uint32_t S = uint32_t(workers.size());
+    if (fft_size_out) *fft_size_out = uint64_t(N1) * N2;
+    if (!S) return GM_OK;
+    if (S > f.sats_cap) {
+        hipFree(f.d_B); hipFree(f.d_rowmax); hipFree(f.d_rowarg); hipFree(f.d_sat_worker); hipFree(f.d_sat_cp);
+        hipFree(f.d_peak_pow); hipFree(f.d_peak_idx);
+        f.d_B = nullptr; f.sats_cap = 0;
+        HIPC(hipMalloc(&f.d_B, size_t(S) * N1 * N2 * 8));
+        HIPC(hipMalloc(&f.d_rowmax, size_t(S) * N1 * 4));
+        HIPC(hipMalloc(&f.d_rowarg, size_t(S) * N1 * 4));
+        HIPC(hipMalloc(&f.d_sat_worker, S * 4));
+        HIPC(hipMalloc(&f.d_sat_cp, S * 4));
+        HIPC(hipMalloc(&f.d_peak_pow, S * 4));
+        HIPC(hipMalloc(&f.d_peak_idx, S * 4));
+        f.sats_cap = S;
+    }
+    HIPC(hipMemcpyAsync(f.d_sat_worker, workers.data(), S * 4, hipMemcpyHostToDevice, a->stream));
+    HIPC(hipMemcpyAsync(f.d_sat_cp, cps.data(), S * 4, hipMemcpyHostToDevice, a->stream));
+    gm::FineArgs fa{};
+    fa.samples = a->last_samples; fa.fmt = a->last_fmt; fa.mean = f.d_mean;
+    fa.chips = f.d_chips; fa.code_len = a->code_len; fa.code_rate = a->code_rate; fa.fs = a->cfg.fs;
+    fa.sat_worker = f.d_sat_worker; fa.sat_code_phase = f.d_sat_cp;
+    fa.size_use = size_use; fa.N1 = N1; fa.N2 = N2; fa.B = f.d_B; fa.tw1 = f.d_tw1; fa.tw2 = f.d_tw2;
+    fa.rowmax = f.d_rowmax; fa.rowarg = f.d_rowarg;
+    gm::launch_fine_mean(a->stream, a->last_samples, a->last_fmt, a->M * a->N, f.d_mean);
+    f.p1->fine_cols(a->stream, fa, int(S));
+    f.p2->fine_rows(a->stream, fa, int(S));
+    gm::launch_fine_final(a->stream, f.d_rowmax, f.d_rowarg, N1, int(S), f.d_peak_pow, f.d_peak_idx);
+    HIPC(hipGetLastError());
+    std::vector<float> pw(S);
+    std::vector<uint32_t> pi(S);
+    HIPC(hipMemcpyAsync(pw.data(), f.d_peak_pow, S * 4, hipMemcpyDeviceToHost, a->stream));
+    HIPC(hipMemcpyAsync(pi.data(), f.d_peak_idx, S * 4, hipMemcpyDeviceToHost, a->stream));
+    HIPC(hipStreamSynchronize(a->stream));
+    const uint64_t fft_size = uint64_t(N1) * N2;
+    const uint64_t one_side = uint64_t(ceilf((float(fft_size) + 1.0f) / 2.0f));       // :250
+    for (uint32_t p = 0; p < n_prn; ++p) {
+        if (slot[p] == 0xFFFFFFFFu) continue;
+        const uint64_t idx = pi[slot[p]];
+        if (peak_index) peak_index[p] = idx;
+        if (peak_mag) peak_mag[p] = sqrtf(pw[slot[p]]);
+        if (fine_freq_hz)   // :251-253; the upper half is where the legacy indexes out of bounds (:285-288): negative frequency
+            fine_freq_hz[p] = idx > one_side ? -((float(fft_size - idx) * a->cfg.fs) / float(fft_size))
+                                             : (float(idx) * a->cfg.fs) / float(fft_size);
+    }
+    return GM_OK;
 }
 
 int gm_acq_search_c32(gm_acq* a, const gm_c32* s, size_t n, uint64_t tail, uint64_t mask, gm_acq_result* r, uint8_t* f) {

@@ -8,6 +8,21 @@
 
 namespace gm {
 
+// Fine Doppler (finer_doppler, acquisition_bk.rs:215-302): the zero-padded long FFT of the code-stripped
+// snapshot as a four-step N1 x N2 transform built from two in-LDS plans; never materialised: the column pass reads the
+// samples (strip + zero-pad fused), the row pass reduces |X|^2 to {max, first index} per row.
+struct FineArgs {
+    const void* samples; int fmt;          // the snapshot of the last search (M*N samples)
+    const float* mean;                     // device {re, im}
+    const int8_t* chips; uint32_t code_len; float code_rate, fs;   // [P][code_len]
+    const uint32_t* sat_worker;            // [S] worker index of each satellite to refine
+    const uint32_t* sat_code_phase;        // [S]
+    uint32_t size_use, N1, N2;             // fft_size = N1 * N2
+    cf* B;                                 // [S][N2][N1] intermediate (columns transformed, twiddled)
+    const cf *tw1, *tw2;                   // forward base twiddles of plan N1 / plan N2
+    float* rowmax; uint32_t* rowarg;       // [S][N1]
+};
+
 // One entry per shipped transform size: launchers for the kernels instantiated on that plan.
 struct PlanOps {
     int n;             // transform length
@@ -28,7 +43,14 @@ struct PlanOps {
     void (*code_fft)(hipStream_t, const int8_t* code_samples, const cf* tw_fwd, cf* code_fft, int n_codes);
     // FFT<T>::execute (fft.rs:21-25) on `batch` contiguous transforms
     void (*fft_batch)(hipStream_t, cf* data, const cf* tw, int inverse, int batch);
+    // four-step long FFT passes (power-of-two plans only, else null): this plan as N1 (columns) / as N2 (rows)
+    void (*fine_cols)(hipStream_t, const FineArgs&, int n_sats);
+    void (*fine_rows)(hipStream_t, const FineArgs&, int n_sats);
 };
+// mean of the snapshot (finer_doppler :236) and the final per-satellite reduction over the rows
+void launch_fine_mean(hipStream_t, const void* samples, int fmt, uint32_t n, float* d_mean);
+void launch_fine_final(hipStream_t, const float* rowmax, const uint32_t* rowarg, uint32_t n_rows, int n_sats,
+                       float* peak_pow, uint32_t* peak_idx);
 const PlanOps* find_plan(int n);
 int list_plans(uint32_t* sizes, int cap);
 

@@ -148,6 +148,17 @@ typedef struct gm_ring gm_ring;
 int gm_acq_search_ring(gm_acq *a, gm_ring *ring, uint64_t prn_mask, gm_acq_result *results, uint8_t *found,
                        uint64_t *local_tail_out);
 
+/* Fine-Doppler refinement after detection (finer_doppler, src/acquisition/acquisition_bk.rs:215-302 —
+ * a legacy file outside the reference's module tree): for every found[p], the snapshot of the LAST search on this handle
+ * (still in HBM) is code-stripped from results[p].code_phase_samples over (num_integrations-1)*fft_size samples (:240-272),
+ * mean-removed (:236-237), zero-padded to 8*next_pow2 (:249) and transformed; the first index of the maximum |X| (:276-283)
+ * gives fine_freq_hz[p] = (idx*fs)/fft_size (:251-253), i.e. IF + Doppler to fs/fft_size (7.6 Hz at 8 Msps, 10 ms).
+ * Indices above fft_size/2 are reported as negative frequencies (the legacy indexes out of bounds there, :285-288, and
+ * multiplies by (-1)^is_complex, :298-299: neither is reproduced).  Entries of not-found PRNs are left untouched.
+ * Any output pointer may be NULL.  Synchronous.  GM_ERR_UNSUPPORTED_N if the long FFT does not factor into two in-LDS plans. */
+int gm_acq_finer_doppler(gm_acq *a, const gm_acq_result *results, const uint8_t *found, uint32_t n_prn,
+                         float *fine_freq_hz, uint64_t *peak_index, float *peak_mag, uint64_t *fft_size);
+
 /* Device-resident form: samples already in HBM; kernels are enqueued on the handle's stream and the
  * call returns without synchronising.  d_metrics (optional, may be NULL -> internal buffer) receives
  * 3*n_prn*n_bins 32-bit words: max f32 [P][D], argmax u32 [P][D], sum f32 [P][D]. */

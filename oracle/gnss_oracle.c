@@ -844,3 +844,49 @@ void orc_frontend_process_block(orc_frontend *fe, float *raw, size_t n_floats) {
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * finer_doppler (src/acquisition/acquisition_bk.rs:215-302, legacy)
+ * ------------------------------------------------------------------------------------------ */
+int orc_finer_doppler(const orc_c32 *samples, size_t n_samples, size_t code_phase, const int8_t *chips, size_t code_len,
+                      float code_rate, float fs, size_t size_signal_use, uint64_t *peak_index, float *peak_mag,
+                      float *freq_hz, int *upper_half, size_t *fft_size_out) {
+    if (!size_signal_use || code_phase + size_signal_use > n_samples) return -1;   /* slice :260 would panic */
+    float sum_re = 0.0f, sum_im = 0.0f;                                            /* iter().sum::<Complex32>() :236 */
+    for (size_t i = 0; i < n_samples; ++i) { sum_re += samples[i].re; sum_im += samples[i].im; }
+    const float mean_re = sum_re / (float)n_samples, mean_im = sum_im / (float)n_samples;
+    size_t p2 = 1;
+    while (p2 < size_signal_use) p2 <<= 1;                                         /* next_power_of_two :249 */
+    const size_t fft_size = 8 * p2;
+    orc_c32 *x = (orc_c32 *)calloc(fft_size, sizeof(orc_c32));                     /* zero padding :255,273 */
+    if (!x) return -2;
+    for (size_t n = 0; n < size_signal_use; ++n) {
+        const size_t ind = (size_t)floorf(((float)n * code_rate) / fs) % code_len; /* :241-247 */
+        const float c = (float)chips[ind];
+        x[n].re = (samples[code_phase + n].re - mean_re) * c;                      /* :237, :266-272 */
+        x[n].im = (samples[code_phase + n].im - mean_im) * c;
+    }
+    orc_fft_plan *pl = orc_fft_plan_create(fft_size, 0);
+    if (!pl) { free(x); return -2; }
+    orc_fft_exec(pl, x);                                                           /* :275 */
+    orc_fft_plan_destroy(pl);
+    float best = -1.0f;
+    size_t idx = 0;
+    for (size_t k = 0; k < fft_size; ++k) {                                        /* abs() :276, max :278, first equal :279-282 */
+        const float m = hypotf(x[k].re, x[k].im);
+        if (m > best) { best = m; idx = k; }
+    }
+    free(x);
+    const size_t one_side = (size_t)ceilf(((float)fft_size + 1.0f) / 2.0f);        /* :250 */
+    if (peak_index) *peak_index = idx;
+    if (peak_mag) *peak_mag = best;
+    if (fft_size_out) *fft_size_out = fft_size;
+    if (idx > one_side) {                                                          /* :284-297 — the legacy panics here */
+        if (upper_half) *upper_half = 1;
+        if (freq_hz) *freq_hz = -(((float)(fft_size - idx) * fs) / (float)fft_size);
+    } else {
+        if (upper_half) *upper_half = 0;
+        if (freq_hz) *freq_hz = ((float)idx * fs) / (float)fft_size;               /* :251-253 */
+    }
+    return 0;
+}
+

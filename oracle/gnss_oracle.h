@@ -186,6 +186,17 @@ void orc_ring_copy_to_slice(const orc_ring *r, uint64_t start, orc_c32 *dest, si
 int orc_trk_update(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float out6[6],
                    uint8_t *msg_prn);
 
+/* ---------------- fine Doppler (src/acquisition/acquisition_bk.rs:215-302, LEGACY file outside the reference's module
+ * tree, no test) — SURVEY §8 f3.  PARITY UNPINNED.  Restated on the live path's data: `samples` are the c32 snapshot of
+ * do_acquisition.rs:300 (the legacy took i16 pairs, :225-235), size_signal_use = (num_integrations-1)*N (:240), code
+ * chips at floor((x*rate)/fs) % len (:241-247), mean removal (:236-237), fft_size = 8*next_pow2(size) (:249), first
+ * index of the maximum |X| (:277-283).  freq_hz = (idx*fs)/fft_size for idx <= one_side (:250-253,298-299 without the
+ * legacy's (-1)^is_complex factor); for idx > one_side the legacy indexes out of bounds (:285-288: it would panic), here
+ * the negative frequency -((fft_size-idx)*fs)/fft_size is returned with *upper_half = 1. */
+int orc_finer_doppler(const orc_c32 *samples, size_t n_samples, size_t code_phase, const int8_t *chips, size_t code_len,
+                      float code_rate, float fs, size_t size_signal_use, uint64_t *peak_index, float *peak_mag,
+                      float *freq_hz, int *upper_half, size_t *fft_size_out);
+
 /* ---------------- digital front-end (src/rf/frontend.rs, nco_lut.rs, dc_remove.rs) — SURVEY §8 f2.
  * The reference has no test for these files: PARITY UNPINNED beyond this line-by-line restatement. */
 #define ORC_LUT_SIZE 2048                       /* nco_lut.rs:4 */

@@ -388,6 +388,24 @@ def process_channels(channels, ring, max_passes, n_threads=1, native=False):
     return int(done)
 
 
+def finer_doppler(samples, code_phase, chips, fs, size_signal_use, code_rate=1.023e6, native=False):
+    """finer_doppler (acquisition_bk.rs:215-302, legacy) on a c32 snapshot.  Returns dict(peak_index, peak_mag, freq_hz,
+    upper_half, fft_size)."""
+    L = lib(native)
+    L.orc_finer_doppler.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
+                                    C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.orc_finer_doppler.restype = C.c_int
+    s = _c64(samples)
+    ch = np.ascontiguousarray(chips, np.int8)
+    idx, mag, f, up, n = C.c_uint64(0), C.c_float(0), C.c_float(0), C.c_int(0), C.c_size_t(0)
+    rc = L.orc_finer_doppler(_p(s), s.size, int(code_phase), _p(ch), ch.size, code_rate, fs, int(size_signal_use),
+                             C.byref(idx), C.byref(mag), C.byref(f), C.byref(up), C.byref(n))
+    if rc:
+        raise IndexError("finer_doppler: slice out of range (the legacy would panic)")
+    return dict(peak_index=idx.value, peak_mag=mag.value, freq_hz=f.value, upper_half=bool(up.value), fft_size=n.value)
+
+
 class FrontendState(C.Structure):
     _fields_ = [("lut_re", C.c_float * 2048), ("lut_im", C.c_float * 2048), ("phase_accumulator", C.c_float),
                 ("phase_step", C.c_float), ("bias_re", C.c_float * 8), ("bias_im", C.c_float * 8), ("alpha", C.c_float),
