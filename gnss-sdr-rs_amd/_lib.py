@@ -45,6 +45,12 @@ class TrkOut(C.Structure):
     _fields_ = [(k, C.c_float) for k in ("ip", "qp", "ie", "qe", "il", "ql", "ive", "qve", "ivl", "qvl")]
 
 
+class NavStatus(C.Structure):
+    _fields_ = [("flag_bit_sync", C.c_uint8), ("flag_frame_sync", C.c_uint8), ("sync_sw", C.c_uint8), ("bit", C.c_int8),
+                ("polarity", C.c_int8), ("frame_sync_ind", C.c_uint32), ("n_frame_bits", C.c_uint64), ("i_p", C.c_float),
+                ("sf_cnt", C.c_uint64), ("sf_start_biti", C.c_uint64), ("tow_expected_ind", C.c_uint64)]
+
+
 class TrkCfg(C.Structure):
     _fields_ = [("fs", C.c_float), ("n_channels", C.c_uint32), ("n_arms", C.c_uint32),
                 ("early_late_space", C.c_float), ("very_early_late_space", C.c_float),
@@ -110,6 +116,12 @@ SIGNATURES = {
     "gm_ring_write_samples_async": (_i, [_vp, _vp, _sz]),
     "gm_ring_flush": (_i, [_vp]),
     "gm_ring_wait_head": (_i, [_vp, _u64, _u32, _vp]),
+    "gm_nav_sync_create": (_i, [_i, _vp]),
+    "gm_nav_sync_destroy": (_i, [_vp]),
+    "gm_nav_sync_update": (_i, [_vp, _f, _f, _u64, _u64, _vp]),
+    "gm_nav_sync_frame_bits": (_i, [_vp, _vp, _sz, _vp]),
+    "gm_nav_sync_histogram": (_i, [_vp, _vp]),
+    "gm_nav_parity_check": (_i, [_vp, _vp, _vp]),
     "gm_frontend_create": (_i, [_f, _f, _f, _vp]),
     "gm_frontend_destroy": (_i, [_vp]),
     "gm_frontend_lut": (_i, [_vp, _vp, _vp, _vp]),

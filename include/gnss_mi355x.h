@@ -340,6 +340,36 @@ int gm_trk_debug_stamps(gm_trk *t, uint32_t cap, long long *out);
 int gm_trk_enable_timing(gm_trk *t, int on);
 int gm_trk_last_timing(gm_trk *t, float *ms_correlate_total, uint32_t *launches);
 
+/* ------------------------------------------------------------------ Bit sync + nav-bit accumulation
+ * src/decoding.rs:8,40-227 (legacy file outside the reference's module tree): 20-bin histogram of prompt-I sign
+ * changes (check_bit_sync :164-182, threshold 30), 20 ms accumulation into +-1 bits (bit_accumulation :184-214),
+ * 8-bit preamble correlation (check_preamble_syn :216-227).  Host-side integer work, no device needed.
+ * GM_NAV_FAITHFUL keeps the file's bugs (bits only emitted when frame_sync_ind == 0, :203-205; preamble tested only at
+ * exactly 8 collected bits, :131-135); GM_NAV_FIXED wraps the bit boundary modulo 20 and slides the 8-bit window.
+ * The subframe decoding of :147-160,229-257 panics as written (todo!(), indexing an empty Vec) and is not provided. */
+enum { GM_NAV_FAITHFUL = 0, GM_NAV_FIXED = 1 };
+typedef struct gm_nav_sync gm_nav_sync;
+typedef struct {
+    uint8_t flag_bit_sync, flag_frame_sync, sync_sw;   /* sync_sw: this epoch completed a bit */
+    int8_t bit;                                        /* the completed bit (+1/-1), 0 otherwise */
+    int8_t polarity;                                   /* preamble polarity (-1 until frame sync, like ::new :85) */
+    uint32_t frame_sync_ind;                           /* ms offset of the bit edge */
+    uint64_t n_frame_bits;
+    float i_p;                                         /* running 20 ms accumulator */
+    uint64_t sf_cnt, sf_start_biti, tow_expected_ind;
+} gm_nav_status;
+int gm_nav_sync_create(int mode, gm_nav_sync **out);                                       /* NavSyncStatus::new :68-100 */
+int gm_nav_sync_destroy(gm_nav_sync *s);
+/* nav_decoding's per-epoch step (:102-145) for epoch number `cnt` (1 ms each) with the channel's previous and current
+ * prompt I (TrackingResult.old_i_prompt / i_prompt) */
+int gm_nav_sync_update(gm_nav_sync *s, float old_i_prompt, float i_prompt, uint64_t cnt, uint64_t buff_loc,
+                       gm_nav_status *out);
+int gm_nav_sync_frame_bits(gm_nav_sync *s, int8_t *bits, size_t cap, size_t *n);
+int gm_nav_sync_histogram(gm_nav_sync *s, uint64_t hist[20]);
+/* parity_check (:259-352) on 32 symbols in +-1 form [D29*, D30*, d1..d24, D25..D30]: *ok = all six products match;
+ * *ref_sum_zero (may be NULL) = the reference's own criterion, the i8 sum of the six differences is zero (:348-350) */
+int gm_nav_parity_check(const int8_t bits[32], int *ok, int *ref_sum_zero);
+
 #ifdef __cplusplus
 }
 #endif

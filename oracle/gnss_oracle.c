@@ -890,3 +890,102 @@ int orc_finer_doppler(const orc_c32 *samples, size_t n_samples, size_t code_phas
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Bit sync / nav-bit accumulation / preamble (src/decoding.rs, legacy)
+ * ------------------------------------------------------------------------------------------ */
+static const int8_t ORC_GPS_CA_PREAMBLE[8] = {1, -1, -1, -1, 1, -1, 1, 1};   /* gps_property_constants.rs:13 */
+#define ORC_BIT_SYNC_THRESHOLD 30                                              /* decoding.rs:8 */
+
+void orc_nav_sync_new(orc_nav_sync *s, int fixed) { /* :68-100 */
+    memset(s, 0, sizeof(*s));
+    s->fixed = fixed;
+    s->polarity = -1;
+}
+void orc_nav_sync_free(orc_nav_sync *s) { free(s->frame_bits); s->frame_bits = NULL; }
+
+static int orc_check_bit_sync(orc_nav_sync *s, float old_i, float i_p) { /* :164-182 */
+    if (old_i * i_p < 0.0f) {
+        s->bit_sync_buff[s->biti] += 1;
+        size_t i_max = 0;
+        uint64_t v_max = s->bit_sync_buff[0];
+        for (size_t i = 1; i < 20; ++i)                 /* Iterator::max_by keeps the LAST of equal maxima */
+            if (s->bit_sync_buff[i] >= v_max) { v_max = s->bit_sync_buff[i]; i_max = i; }
+        s->frame_sync_ind = i_max;
+        if (v_max == ORC_BIT_SYNC_THRESHOLD) return 1;
+    }
+    return 0;
+}
+
+static void orc_bit_accumulation(orc_nav_sync *s, float i_p, uint64_t loop_ms, uint64_t buff_loc) { /* :184-214 */
+    (void)buff_loc;
+    s->sync_sw = 0;
+    if (s->biti == s->frame_sync_ind) { s->bit_code_cnt = 1; s->i_p = i_p; }
+    else s->i_p += i_p;
+    s->loop_sw = (s->bit_code_cnt % loop_ms) == 0;
+    const uint64_t last = s->fixed ? (s->frame_sync_ind + 19) % 20 : s->frame_sync_ind + 19;   /* :203-205 */
+    if (s->biti == last) {
+        const int8_t bit = s->i_p > 0.0f ? 1 : -1;
+        if (s->n_frame_bits == s->cap_frame_bits) {
+            s->cap_frame_bits = s->cap_frame_bits ? 2 * s->cap_frame_bits : 512;
+            s->frame_bits = (int8_t *)realloc(s->frame_bits, s->cap_frame_bits);
+        }
+        s->frame_bits[s->n_frame_bits++] = bit;
+        s->last_bit = bit;
+        s->sync_sw = 1;
+        if (!s->flag_frame_sync) {                      /* buff_preamble.push_back(bit) :210-212 */
+            if (s->fixed) {
+                memmove(s->buff_preamble, s->buff_preamble + 1, 7);
+                s->buff_preamble[7] = bit;
+                if (s->n_preamble < 8) s->n_preamble++;
+            } else {
+                if (s->n_preamble < 8) s->buff_preamble[s->n_preamble] = bit;
+                s->n_preamble++;
+            }
+        }
+    }
+    s->bit_code_cnt += 1;
+}
+
+static int orc_check_preamble_syn(orc_nav_sync *s) { /* :216-227 */
+    int corr = 0;
+    for (int x = 0; x < 8; ++x) corr += s->buff_preamble[x] * ORC_GPS_CA_PREAMBLE[x % 8];
+    if (abs(corr) == 8) { s->polarity = (int8_t)(corr > 0 ? 1 : -1); return 1; }
+    return 0;
+}
+
+int orc_nav_sync_update(orc_nav_sync *s, float old_i, float i_p, uint64_t cnt, uint64_t buff_loc) { /* :102-162 */
+    s->biti = cnt % 20;                                                        /* :114 */
+    if (!s->flag_bit_sync && cnt > (uint64_t)(1.0f / 1.0e-3f))                 /* :115 */
+        s->flag_bit_sync = orc_check_bit_sync(s, old_i, i_p);
+    if (s->flag_bit_sync) orc_bit_accumulation(s, i_p, 10 /* tracking::LOOP_MS */, buff_loc);
+    if (s->sync_sw) {                                                          /* :129-145 */
+        if (!s->flag_frame_sync && s->n_preamble == 8) s->flag_frame_sync = orc_check_preamble_syn(s);
+        if (s->flag_frame_sync) {
+            s->sf_buffer_loc = buff_loc;
+            s->sf_cnt = cnt;
+            s->sf_start_biti = s->n_frame_bits - 8;
+            s->tow_expected_ind = cnt + 30 * 20;
+        }
+    }
+    return s->sync_sw;
+}
+
+int orc_nav_parity_check(const int8_t b[32], int *ref_sum_zero) { /* :259-352 */
+    static const int8_t idx[6][16] = {
+        {0, 2, 3, 4, 6, 7, 11, 12, 13, 14, 15, 18, 19, 21, 24, -1},
+        {1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22, 25, -1},
+        {0, 2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23, -1},
+        {1, 3, 5, 6, 7, 9, 10, 14, 15, 16, 17, 18, 21, 22, 24, -1},
+        {1, 2, 4, 6, 7, 8, 10, 11, 15, 16, 17, 18, 19, 22, 23, 25},
+        {0, 4, 6, 7, 9, 10, 11, 12, 14, 16, 20, 23, 24, 25, -1, -1}};
+    int all = 1, sum = 0;
+    for (int k = 0; k < 6; ++k) {
+        int p = 1;
+        for (int j = 0; j < 16 && idx[k][j] >= 0; ++j) p *= b[idx[k][j]];
+        if (p != b[26 + k]) all = 0;
+        sum += p - b[26 + k];
+    }
+    if (ref_sum_zero) *ref_sum_zero = ((int8_t)sum) == 0;
+    return all;
+}
+

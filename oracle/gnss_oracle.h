@@ -197,6 +197,32 @@ int orc_finer_doppler(const orc_c32 *samples, size_t n_samples, size_t code_phas
                       float code_rate, float fs, size_t size_signal_use, uint64_t *peak_index, float *peak_mag,
                       float *freq_hz, int *upper_half, size_t *fft_size_out);
 
+/* ---------------- bit sync + nav-bit accumulation (src/decoding.rs:8,40-227, LEGACY file outside the module tree; its
+ * parity/subframe functions :229-352 panic as written) — SURVEY §8 f4.  PARITY UNPINNED (no reference test).
+ * fixed = 0 restates the file line by line, bugs included: bits are only emitted when frame_sync_ind == 0 (:203-205 has
+ * no modulo) and the preamble is tested only when exactly 8 bits have been collected (:131-135, the VecDeque keeps
+ * growing); fixed = 1 wraps the bit boundary modulo 20 and slides an 8-bit window. */
+typedef struct {
+    int fixed;
+    int flag_bit_sync, flag_frame_sync, sync_sw, loop_sw;
+    uint64_t biti, frame_sync_ind, bit_code_cnt, sf_buffer_loc, sf_cnt, sf_start_biti, tow_expected_ind;
+    uint64_t bit_sync_buff[20];
+    float i_p;
+    int8_t polarity;
+    int8_t *frame_bits; size_t n_frame_bits, cap_frame_bits;
+    int8_t buff_preamble[8]; size_t n_preamble;          /* len of the reference's VecDeque (keeps counting past 8) */
+    int8_t last_bit;
+} orc_nav_sync;
+void orc_nav_sync_new(orc_nav_sync *s, int fixed);          /* NavSyncStatus::new :68-100 */
+void orc_nav_sync_free(orc_nav_sync *s);
+/* nav_decoding :102-162 up to frame sync (subframe decoding :147-160 panics in the reference: not restated).
+ * returns 1 when this epoch completed a bit (sync_sw), else 0 */
+int orc_nav_sync_update(orc_nav_sync *s, float old_i_prompt, float i_prompt, uint64_t cnt, uint64_t buff_loc);
+/* the six parity equations of :259-346 on 32 symbols in +-1 form (bits[0..1] = D29*, D30* of the previous word,
+ * bits[2..25] = d1..d24, bits[26..31] = D25..D30); returns 1 when every product equals its parity symbol
+ * (the reference sums the differences, :348-350, so +2 and -2 cancel: *ref_sum_zero reports that form) */
+int orc_nav_parity_check(const int8_t bits[32], int *ref_sum_zero);
+
 /* ---------------- digital front-end (src/rf/frontend.rs, nco_lut.rs, dc_remove.rs) — SURVEY §8 f2.
  * The reference has no test for these files: PARITY UNPINNED beyond this line-by-line restatement. */
 #define ORC_LUT_SIZE 2048                       /* nco_lut.rs:4 */

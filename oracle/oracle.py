@@ -406,6 +406,50 @@ def finer_doppler(samples, code_phase, chips, fs, size_signal_use, code_rate=1.0
     return dict(peak_index=idx.value, peak_mag=mag.value, freq_hz=f.value, upper_half=bool(up.value), fft_size=n.value)
 
 
+class NavSyncState(C.Structure):
+    _fields_ = [("fixed", C.c_int), ("flag_bit_sync", C.c_int), ("flag_frame_sync", C.c_int), ("sync_sw", C.c_int),
+                ("loop_sw", C.c_int), ("biti", C.c_uint64), ("frame_sync_ind", C.c_uint64), ("bit_code_cnt", C.c_uint64),
+                ("sf_buffer_loc", C.c_uint64), ("sf_cnt", C.c_uint64), ("sf_start_biti", C.c_uint64),
+                ("tow_expected_ind", C.c_uint64), ("bit_sync_buff", C.c_uint64 * 20), ("i_p", C.c_float),
+                ("polarity", C.c_int8), ("frame_bits", C.POINTER(C.c_int8)), ("n_frame_bits", C.c_size_t),
+                ("cap_frame_bits", C.c_size_t), ("buff_preamble", C.c_int8 * 8), ("n_preamble", C.c_size_t),
+                ("last_bit", C.c_int8)]
+
+
+class NavSyncStatus:
+    """decoding.rs NavSyncStatus + nav_decoding's per-epoch step (:40-227, legacy)"""
+
+    def __init__(self, fixed=False):
+        self.s = NavSyncState()
+        L = lib()
+        L.orc_nav_sync_new.argtypes = [C.c_void_p, C.c_int]
+        L.orc_nav_sync_new.restype = None
+        L.orc_nav_sync_free.argtypes = [C.c_void_p]
+        L.orc_nav_sync_free.restype = None
+        L.orc_nav_sync_update.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_uint64]
+        L.orc_nav_sync_update.restype = C.c_int
+        L.orc_nav_sync_new(C.byref(self.s), int(fixed))
+
+    def __del__(self):
+        lib().orc_nav_sync_free(C.byref(self.s))
+
+    def update(self, old_i_prompt, i_prompt, cnt, buff_loc=0):
+        return lib().orc_nav_sync_update(C.byref(self.s), old_i_prompt, i_prompt, int(cnt), int(buff_loc))
+
+    def frame_bits(self):
+        return np.array([self.s.frame_bits[i] for i in range(self.s.n_frame_bits)], np.int8)
+
+
+def nav_parity_check(bits32):
+    L = lib()
+    L.orc_nav_parity_check.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.orc_nav_parity_check.restype = C.c_int
+    b = np.ascontiguousarray(bits32, np.int8)
+    ref = C.c_int(0)
+    ok = L.orc_nav_parity_check(_p(b), C.byref(ref))
+    return bool(ok), bool(ref.value)
+
+
 class FrontendState(C.Structure):
     _fields_ = [("lut_re", C.c_float * 2048), ("lut_im", C.c_float * 2048), ("phase_accumulator", C.c_float),
                 ("phase_step", C.c_float), ("bias_re", C.c_float * 8), ("bias_im", C.c_float * 8), ("alpha", C.c_float),
