@@ -62,6 +62,9 @@ def doppler_grid(span_hz=FREQ_SEARCH_ACQUISITION_HZ, step_hz=FREQ_SEARCH_STEP_HZ
     return np.array([np.float32(-span_hz / 2.0) + np.float32(i) * np.float32(step_hz) for i in range(capacity)], np.float32)
 
 
+DECIDE_REFERENCE, DECIDE_BEST_BIN = 0, 1   # gm_decision_mode
+
+
 class AcquisitionEngine:
     """The batched replacement of `workers.par_iter_mut()` (do_acquisition.rs:268-271, 302-313):
     all AcquisitionWorkers of one stage in one handle."""

@@ -26,9 +26,12 @@ using Plan6000 = Plan<6000, 512, 25, 15, 16>;     // 6 Msps
 using Plan8192 = Plan<8192, 512, 16, 32, 16>;     // 8.192 Msps
 using Plan15000 = Plan<15000, 1024, 25, 25, 24>;  // 15 Msps
 using Plan16384 = Plan<16384, 1024, 32, 32, 16>;  // 16.384 Msps
+using Plan512 = Plan<512, 64, 8, 8, 8>;           // factors of the long fine-Doppler FFT (2^16 .. 2^19) at low sample rates
+using Plan256 = Plan<256, 64, 16, 16>;
 }  // namespace gm
 
 #define GM_FOR_EACH_PLAN(X) \
     X(gm::Plan8000) X(gm::Plan16368) X(gm::Plan4096) X(gm::Plan2048) X(gm::Plan1024) \
     X(gm::Plan4000) X(gm::Plan10000) X(gm::Plan12000) X(gm::Plan16000) \
-    X(gm::Plan2000) X(gm::Plan5000) X(gm::Plan6000) X(gm::Plan8192) X(gm::Plan15000) X(gm::Plan16384)
+    X(gm::Plan2000) X(gm::Plan5000) X(gm::Plan6000) X(gm::Plan8192) X(gm::Plan15000) X(gm::Plan16384) \
+    X(gm::Plan512) X(gm::Plan256)

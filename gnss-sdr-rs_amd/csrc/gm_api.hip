@@ -646,7 +646,7 @@ int gm_acq_finer_doppler(gm_acq* a, const gm_acq_result* results, const uint8_t*
         int lg = 0;
         while ((1ull << lg) < n) ++lg;
         const gm::PlanOps *b1 = nullptr, *b2 = nullptr;
-        for (int l2 = lg / 2; l2 >= 10 && !b1; --l2) {
+        for (int l2 = lg / 2; l2 >= 8 && !b1; --l2) {
             const gm::PlanOps *q1 = gm::find_plan(1 << (lg - l2)), *q2 = gm::find_plan(1 << l2);
             if (q1 && q2 && q1->fine_cols && q2->fine_rows) { b1 = q1; b2 = q2; }
         }

@@ -35,6 +35,10 @@ def make_scene(code_table, fs, f_if, n_samples, sats, sigma=16.0, config_id=0, r
         c = code_table[s["prn_row"]][chip].astype(np.float64)
         if bit_flip_at is not None:
             c = np.where(n >= bit_flip_at, -c, c)
+        if s.get("data_bits") is not None:   # 50 bit/s navigation data: bit k covers code periods edge + 20k .. edge + 20k + 19
+            period = np.floor((n - s["code_start"]) * (code_rate / L) / fs).astype(np.int64)
+            k = (period - int(s.get("bit_edge_ms", 0))) // 20
+            c = c * np.asarray(s["data_bits"], np.float64)[k % len(s["data_bits"])]
         ph = 2.0 * np.pi * (f_if + s["doppler_hz"]) * n / fs + s.get("phase", 0.0)
         if real_only:
             x += amp * np.sqrt(2.0) * c * np.cos(ph)

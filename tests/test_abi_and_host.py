@@ -115,3 +115,17 @@ def test_synth_scene_is_deterministic(gm):
     i8 = synth.to_i8_iq(a["x"])
     assert i8.shape == (80000, 2) and np.abs(i8).max() <= 127
     assert hashlib.sha256(i8.tobytes()).hexdigest() == hashlib.sha256(synth.to_i8_iq(b["x"]).tobytes()).hexdigest()
+
+
+def test_fft_core_cpu_emulation_of_every_plan():
+    """tests/cpu/test_fft_core.cpp: the in-LDS FFT header (csrc/fft_core.h) is host/device portable; g++ runs every
+    shipped plan lane by lane, barrier phase by barrier phase, against a float64 DFT (threshold 7e-7 relative L2)."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tempfile.mkdtemp(prefix="gm_fftcore_"), "test_fft_core")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "gnss-sdr-rs_amd", "csrc"),
+                    os.path.join(root, "tests", "cpu", "test_fft_core.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "Plan8000" in r.stdout and "Plan256" in r.stdout and "worst" in r.stdout

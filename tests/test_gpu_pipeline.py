@@ -79,3 +79,65 @@ def test_best_bin_decision_mode(gpu, oracle):
     # the reference mode stops earlier on this strong signal (a sinc sidelobe already passes peak/mean > 7)
     assert r_ref[0]["doppler_bin"] < b and r_ref[0]["code_phase_samples"] == 321
     ref.close(); best.close()
+
+
+def test_full_chain_frontend_to_nav_bits(gpu, oracle):
+    """SURVEY §8 f1-f4 chained around the path: int8 IF samples -> DigitalFrontend (DC removal + NCO down-mix, f2) ->
+    device ring -> acquisition on a ring snapshot -> fine Doppler (f3) -> TrackingChannel::start -> 3 s of
+    process_channels -> bit sync / nav bits / preamble on the prompt I (f4).  Checked against the simulated truth."""
+    from gnss_sdr_rs_amd import acquisition as A, decoding as Dm, frontend as F, tracking as T, synth
+    t = oracle.ca_code_table()
+    fs, N, M, f_if = 2_048_000.0, 2048, 10, 256_000.0        # f_if / fs * 2048 = 256: the LUT NCO is exact at this IF
+    n_ms = 3100
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 2, 160) * 2 - 1
+    for at in (20, 60, 100, 130):
+        data[at:at + 8] = Dm.GPS_CA_PREAMBLE
+    sat = dict(prn=9, prn_row=8, cn0_dbhz=50.0, doppler_hz=1337.0, code_start=700, phase=0.4, data_bits=data, bit_edge_ms=13)
+    # mix_simd with the negated sine table (nco_lut.rs:8-15,31) computes conj(x) * exp(-j theta): it brings a spectrally
+    # INVERTED IF stream (carrier at -(f_if + doppler)) to baseband at +doppler.  That is the stream fed here.
+    x = np.conj(synth.make_scene(t, fs, f_if, n_ms * N, [sat], config_id=77))
+    x = x + (6.0 - 4.0j)                                       # a DC offset for the front-end to remove
+    xi8 = synth.to_i8_iq(np.clip(x.real, -127, 127) + 1j * np.clip(x.imag, -127, 127))
+
+    ring = T.MulticastRingBuffer(1 << 23)
+    fe = F.DigitalFrontend(f_if, fs, fs)
+    for off in range(0, n_ms * N, 1 << 18):                    # rf_thread's block pump (larger blocks, same arithmetic)
+        fe.write_ring(ring, xi8[off:off + (1 << 18)])
+    ring.flush()
+    assert ring.get_head() == n_ms * N
+    _, br, bi = fe.state()
+    assert abs(br.mean() - 6.0) < 1.0 and abs(bi.mean() + 4.0) < 1.0      # the IIR settled on the injected offset
+
+    dop = np.arange(-2500.0, 2500.1, 250.0, dtype=np.float32)
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, n_integrations=M, decision_mode=A.DECIDE_BEST_BIN)
+    snap = ring.copy_to_slice(0, 12 * N)
+    res = eng.search(snap[:M * N])
+    found = {r["prn"]: r for r in res if r}
+    assert set(found) == {9}
+    r = found[9]
+    assert r["code_phase_samples"] == 700
+    fine = eng.finer_doppler(res)[8]
+    assert abs(fine["freq_hz"] - 1337.0) < 60.0             # nav-bit edges inside the 9 ms window cost some accuracy
+    mgr = T.TrackingManager(fs, n_channels=2, code_index_mode=T.CODE_INDEX_FIXED)
+    mgr.channels[0].start(dict(r, carrier_freq=fine["freq_hz"]))
+    outs, proc, lost, done = mgr.update_all(ring, 3090)
+    n_run = int(proc[:, 0].sum())
+    assert n_run >= 3080 and not lost.any()
+    s = mgr.channels[0].state
+    assert s.active and abs(s.carrier_freq - 1337.0) < 15.0
+
+    nav = Dm.NavSyncStatus(Dm.NAV_FIXED)
+    ip = outs[:n_run, 0, 0]
+    old, st = 0.0, None
+    for e in range(n_run):
+        st = nav.update(float(old), float(ip[e]), e)
+        old = ip[e]
+    assert st["flag_bit_sync"] and st["frame_sync_ind"] == 13   # the bit edge of the simulated data
+    assert st["flag_frame_sync"]
+    bits = nav.frame_bits()
+    assert bits.size > 30
+    # the decoded bits are the transmitted ones up to the PLL's 180 degree ambiguity, which the preamble polarity resolves
+    start = next(k for k in range(data.size - bits.size + 1) if (data[k:k + bits.size] == st["polarity"] * bits).all())
+    assert start > 50
+    mgr.close(); eng.close(); fe.close(); ring.close()
