@@ -1,0 +1,65 @@
+"""Turn gpurun_out/prof (tools/profile_round.sh) into the committed summaries under profiles/ for round RR:
+   rRR_bench_line.json, rRR_bench_kernel_stats.csv, rRR_pmc_fetch_write.json, traffic.json."""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rr = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(root, "gpurun_out", "prof")
+dst = os.path.join(root, "profiles")
+shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, f"{rr}_bench_line.json"))
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+shutil.copy(stats[0], os.path.join(dst, f"{rr}_bench_kernel_stats.csv"))
+
+
+def short(name):
+    m = re.search(r"gm::(?:\(anonymous namespace\)::)?(\w+)", name)
+    if not m:
+        return name.split("(")[0][:60]
+    k = "gm::" + m.group(1)
+    pl = re.search(r"Plan<(\d+)", name)          # one entry per transform size: the bench workload is N = 8000
+    if pl and pl.group(1) != "8000":
+        k += f"<N={pl.group(1)}>"
+    arms = re.search(r"trk_persistent_kernel<(\d+)", name)
+    if arms and arms.group(1) != "3":
+        k += f"<arms={arms.group(1)}>"
+    return k
+
+
+out = {}
+for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    files = glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True)
+    acc = {}
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != ctr:
+                continue
+            k = short(row["Kernel_Name"])
+            a = acc.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += float(row["Counter_Value"])
+    out[ctr] = {k: {"launches": n, "avg_counter_KB": v / n} for k, (n, v) in acc.items() if k.startswith("gm::")}
+json.dump(out, open(os.path.join(dst, f"{rr}_pmc_fetch_write.json"), "w"), indent=1)
+
+
+def kb(ctr, k):
+    return out[ctr].get(k, {}).get("avg_counter_KB", 0.0)
+
+
+# MI355X_MICROARCH.md §HBM: FETCH_SIZE under-reports coalesced streaming reads by 2x on gfx950 (64 B per 128-B request);
+# WRITE_SIZE is exact.  Units: KB.
+traffic = {
+    "source": f"profiles/{rr}_pmc_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py workload)",
+    "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE exact; KB -> bytes x1024",
+    "acq_corr_kernel_hbm_bytes_per_launch": int((2 * kb("FETCH_SIZE", "gm::acq_corr_kernel") + kb("WRITE_SIZE", "gm::acq_corr_kernel")) * 1024),
+    "acq_mix_fft_kernel_hbm_bytes_per_launch": int((2 * kb("FETCH_SIZE", "gm::acq_mix_fft_kernel") + kb("WRITE_SIZE", "gm::acq_mix_fft_kernel")) * 1024),
+    "trk_persistent_kernel_hbm_bytes_per_launch": int((2 * kb("FETCH_SIZE", "gm::trk_persistent_kernel") + kb("WRITE_SIZE", "gm::trk_persistent_kernel")) * 1024),
+    "note": "fabric (L2 memory-side) bytes; Infinity-Cache hits are counted, so true HBM traffic is at most this",
+}
+json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
