@@ -314,3 +314,28 @@ def test_finer_doppler_small_and_errors(gpu, oracle):
         n_ok += 1
     assert n_ok >= 3
     eng.close()
+
+
+def test_search_ring_snapshot_wraps_and_empty_mask(gpu, oracle):
+    """Edge cases of run()'s snapshot (do_acquisition.rs:297-313): the M*N samples before head straddle the physical end
+    of the ring (copy_to_slice's two-part copy, multicast_ring_buffer.rs:117-127); a zero PRN mask searches nothing
+    (every `(mask >> (prn-1)) & 1` test fails, :305-311)."""
+    from gnss_sdr_rs_amd import acquisition as A, tracking as T, synth
+    t = oracle.ca_code_table()
+    fs, N, M = 2.048e6, 2048, 3
+    dop = np.array([-500.0, 0.0, 500.0], np.float32)
+    sats = [dict(prn_row=6, cn0_dbhz=52.0, doppler_hz=120.0, code_start=900)]
+    x = synth.to_c32(synth.make_scene(t, fs, 0.0, 11 * N, sats, config_id=41))
+    ring = T.MulticastRingBuffer(1 << 13)                    # 8192 samples = 4 code periods: the 3-period snapshot wraps
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=[7, 19], n_integrations=M)
+    ring.write_samples(x[:4 * N])
+    ring.write_samples(x[4 * N:6 * N + 700])                 # head = 12988: snapshot = [6844, 12988) -> physical wrap
+    res, tail = eng.search_ring(ring)
+    assert tail == 6 * N + 700 - M * N and (tail & 8191) + M * N > 8192
+    assert res == eng.search(x[tail:tail + M * N], local_tail=tail)
+    assert res[0] is not None and res[0]["prn"] == 7 and res[1] is None
+    assert (res[0]["code_phase_samples"] + tail - 900) % N == 0
+    none, _ = eng.search_ring(ring, prn_mask=0)
+    assert none == [None, None]
+    assert eng.search(x[:M * N], prn_mask=0) == [None, None]
+    eng.close(); ring.close()

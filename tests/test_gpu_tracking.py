@@ -228,3 +228,52 @@ def test_ring_async_writer_and_condvar(gpu):
     assert woke["ok"] and woke["dt"] < 2.0
     a.close()
     b.close()
+
+
+def test_more_channels_than_resident_workgroups(gpu, oracle):
+    """Maximum sizes: 600 channels (> the 512 workgroup slots of the persistent kernel, so one workgroup per channel and
+    several rounds) give, channel by channel, exactly what a 3-channel manager gives for the same three satellites."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    fs, n = 2_048_000.0, 2048
+    t = oracle.ca_code_table()
+    sc = synth.tracking_scene(t, fs, 0.0, [5, 12, 30], 12, config_id=29, cn0=50.0)
+    x = synth.to_c32(sc["x"])
+    ring = T.MulticastRingBuffer(1 << 15)
+    ring.write_samples(x[:11 * n])
+    big, small = T.TrackingManager(fs, n_channels=600, code_index_mode=1), T.TrackingManager(fs, n_channels=3, code_index_mode=1)
+    for i in range(600):
+        s = sc["sats"][i % 3]
+        r = _acq_result(s["prn"], s["doppler_hz"] + 25.0, 0.0, fs, idx=s["code_start"])
+        big.channels[i].start(r)
+        if i < 3:
+            small.channels[i].start(r)
+    ob, pb, lb, db = big.update_all(ring, 12)
+    os_, ps, ls, ds = small.update_all(ring, 12)
+    assert db == ds == 10 and not lb.any()
+    for i in range(600):
+        assert (pb[:, i] == ps[:, i % 3]).all()
+        # different slice counts per channel (G = 1 vs G = 32) change the summation tree, not the value
+        env = np.hypot(os_[:, i % 3, 0], os_[:, i % 3, 1]).max()
+        assert np.abs(ob[:, i] - os_[:, i % 3]).max() <= 5 * REL * env
+        assert big.channels[i].state.next_sample_index == small.channels[i % 3].state.next_sample_index
+    big.close(); small.close(); ring.close()
+
+
+def test_more_epochs_than_one_persistent_launch(gpu, oracle):
+    """4095 passes per persistent launch (the epoch index lives in 12 bits of the exchange tag): 4200 passes are split
+    into two launches and equal 4200 single-pass calls' bookkeeping; noise-only input, so channels lose lock after 20
+    epochs and are reset exactly like do_tracking.rs:196-203."""
+    from gnss_sdr_rs_amd import tracking as T
+    fs, n = 1_024_000.0, 1024
+    rng = np.random.default_rng(11)
+    x = (0.01 * (rng.standard_normal(40 * n) + 1j * rng.standard_normal(40 * n))).astype(np.complex64)   # |P|^2 << 15
+    ring = T.MulticastRingBuffer(1 << 16)
+    ring.write_samples(x)
+    mgr = T.TrackingManager(fs, n_channels=2, code_index_mode=1)
+    mgr.channels[0].start(_acq_result(4, 500.0, 0.0, fs, idx=0))
+    outs, proc, lost, done = mgr.update_all(ring, 4200)
+    assert proc.shape == (4200, 2) and done == 20            # 20 unlocked epochs, then reset (:196-203): nothing runs after
+    assert proc[:20, 0].all() and not proc[20:, 0].any() and not proc[:, 1].any()
+    assert lost[19, 0] and lost.sum() == 1
+    assert not mgr.channels[0].is_active()
+    mgr.close(); ring.close()
