@@ -234,6 +234,14 @@ def main():
         except Exception as e:   # the headline number stands on its own
             out["tracking"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ the same kernel with 256 channels (informative)
+    if rank == 0 and world == 1 and not args.no_tracking:
+        try:
+            t256 = tracking_leg(torch, dev, stream, ca, T, synth, 1, dist, 0.0, C=256)
+            out["tracking_256ch"] = {k: t256[k] for k in ("value", "unit", "channels_per_gpu", "ms_per_epoch", "channels_locked", "roofline")}
+        except Exception as e:
+            out["tracking_256ch"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ configs[4] geometry (informative, no reference code)
     if rank == 0 and world == 1 and not args.no_tracking:
         try:
@@ -374,10 +382,11 @@ def frontend_leg(torch, dev, with_cpu):
     return res
 
 
-def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0):
-    """32 channels x 25 Msps, 1 ms E/P/L correlators + DLL/PLL on-device, FIXED code indexing
-    (FAITHFUL cannot run PRN 32: the reference indexes GPS_CA_CODE_32_PRN[32])."""
-    fs, C, epochs, reps = 25.0e6, 32, 40, 5
+def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0, C=32):
+    """C channels x 25 Msps, 1 ms E/P/L correlators + DLL/PLL on-device, FIXED code indexing
+    (FAITHFUL cannot run PRN 32: the reference indexes GPS_CA_CODE_32_PRN[32]).  C = 32 is BASELINE configs[2];
+    larger C (channels beyond 32 re-track the same 32 satellites) shows the kernel away from the per-epoch latency floor."""
+    fs, epochs, reps = 25.0e6, 40, 5
     n = 25000
     prns = list(range(1, 33))
     sc = synth.tracking_scene(ca, fs, 0.0, prns, epochs + 2, config_id=3, cn0=47.0)
@@ -387,7 +396,8 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0)
     mgr.set_stream(stream)
 
     def restart():
-        for i, s in enumerate(sc["sats"]):
+        for i in range(C):
+            s = sc["sats"][i % 32]
             mgr.channels[i].start(dict(prn=s["prn"], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=s["doppler_hz"] + 20.0,
                                        fs=fs, mag_relative=1.0, sample_global_index=s["code_start"], doppler_bin=0))
             mgr.channels[i].set_state(code_rate=1.023e6, num_samples_per_code=n, carrier_phase=0.0, code_error=0.0,
@@ -395,7 +405,7 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0)
     restart()
     mgr.update_all_dev(ring, epochs)
     mgr.synchronize()
-    locked = sum(1 for c in mgr.channels if c.is_active() and abs(c.carrier_freq - sc["sats"][c.id]["doppler_hz"]) < 25.0)
+    locked = sum(1 for c in mgr.channels if c.is_active() and abs(c.carrier_freq - sc["sats"][c.id % 32]["doppler_hz"]) < 25.0)
     times = []
     for _ in range(reps):
         restart()
@@ -413,7 +423,7 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0)
     mgr.close()
     ring.close()
     trk_cpu = None
-    if world == 1 and cpu_seconds > 0:
+    if world == 1 and cpu_seconds > 0 and C == 32:
         trk_cpu = tracking_cpu_baseline(sc, fs, n, cpu_seconds)
     return {"metric": "tracking ch×Msps", "cpu_baseline": trk_cpu, "value": ch_msps * world, "unit": "ch*Msps", "channels_per_gpu": C,
             "fs_msps": 25.0, "epochs": epochs, "ms_per_epoch": dt / epochs * 1e3, "channels_locked": locked,
