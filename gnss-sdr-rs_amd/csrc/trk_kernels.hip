@@ -56,8 +56,12 @@ __device__ __forceinline__ void sincos_f32_via_f64(float x, float& s, float& c) 
 // (-len, len) and i*step in [0, 2*len), so t lies in (-len, 3*len) and each branch below is exact
 // (Sterbenz) and equals fmodf(t, len): sign of the dividend, magnitude < len.  !FAST: plain fmodf.
 template <bool FAST> __device__ __forceinline__ float fmod_code(float t, float len) {
-    if constexpr (FAST) return t < len ? t : (t < 2.0f * len ? t - len : t - 2.0f * len);
-    else return fmodf(t, len);
+    if constexpr (FAST) {   // both differences first, then two selects: straight-line code (the nested ternary became branches)
+        const float two = 2.0f * len, a = t - len, b = t - two;
+        float r = t >= len ? a : t;
+        r = t >= two ? b : r;
+        return r;
+    } else return fmodf(t, len);
 }
 
 // get_ca_chip's index (:275): `(phase.floor() as usize) % 1023` — the cast saturates, so a negative
@@ -98,7 +102,7 @@ __device__ __forceinline__ void reset_state(gm_trk_state& s) {
 
 // per-epoch constants of one channel, derived from its state exactly once per epoch
 struct EpochConsts {
-    float carrier_phase, two_pi_f, code_phase, step, fs, lenf, el, vel;
+    float carrier_phase, two_pi_f, code_phase, step, fs, inv_fs, lenf, el, vel;
     int len, mode, boc11;
 };
 __device__ __forceinline__ EpochConsts epoch_consts(const TrkDevCfg& cfg, const gm_trk_state& st) {
@@ -107,14 +111,40 @@ __device__ __forceinline__ EpochConsts epoch_consts(const TrkDevCfg& cfg, const 
     c.two_pi_f = 2.0f * GM_PI_F * st.carrier_freq;      // (2.0*PI)*carrier_freq
     c.code_phase = st.code_phase;
     c.step = __fdiv_rn(st.code_rate, cfg.fs);           // self.code_rate / self.fs
+    c.inv_fs = __fdiv_rn(1.0f, cfg.fs);                 // correctly rounded reciprocal for div_by_fs()
     c.fs = cfg.fs; c.lenf = cfg.code_len_f; c.len = cfg.code_len; c.mode = cfg.code_index_mode;
     c.boc11 = cfg.boc11; c.el = cfg.el_space; c.vel = cfg.vel_space;
     return c;
 }
 
-// once per epoch: may the exact fast path of fmod_code be used for samples 0..n-1 ?
+// once per epoch: may the exact fast forms be used for samples 0..n-1 ?
+//  * fmod_code: code_phase in [0, len), 0 <= step, n*step < 1.99 len -> one conditional subtraction, result in [0, len);
+//  * chip look-ups: with the chip phase in [0, len) and arm spacings in (0, 1] every arm's floor lies in [-1, len], so one
+//    select per arm replaces the general modulo (chip_index_arm);
+//  * x / fs: q0 = x*r, q = fma(fma(-q0, fs, x), r, q0) with r = RN(1/fs) is the correctly rounded quotient (Markstein)
+//    unless fs's significand is all ones or the quotient leaves the normal range — excluded here.  Checked against IEEE
+//    division on 1.3e9 operands for 21 sample rates (tools/ubench note in DESIGN.md); only the sign of a zero quotient can
+//    differ, which cannot change a sample's products.
 __device__ __forceinline__ bool fast_code_range(const EpochConsts& c, uint64_t n) {
-    return c.code_phase > -c.lenf && c.code_phase < c.lenf && c.step >= 0.0f && float(n) * c.step < 1.99f * c.lenf;
+    const bool code_ok = c.code_phase >= 0.0f && c.code_phase < c.lenf && c.step >= 0.0f && float(n) * c.step < 1.99f * c.lenf;
+    const bool arms_ok = c.el > 0.0f && c.el <= 1.0f && c.vel > 0.0f && c.vel <= 1.0f;
+    const bool div_ok = (__float_as_uint(c.fs) & 0x7fffffu) != 0x7fffffu && c.fs > 1.0f && c.fs < 1.0e12f &&
+                        (c.two_pi_f == 0.0f || (fabsf(c.two_pi_f) > 1.0e-12f && fabsf(c.two_pi_f) < 1.0e12f));
+    return code_ok && arms_ok && div_ok;
+}
+
+// x / fs, correctly rounded (see fast_code_range)
+__device__ __forceinline__ float div_by_fs(float x, float fs, float inv_fs) {
+    const float q0 = x * inv_fs;
+    return __builtin_fmaf(__builtin_fmaf(-q0, fs, x), inv_fs, q0);
+}
+
+// get_ca_chip's index (:275) for phase = chip_idx +- spacing when floor(phase) is known to lie in [-1, len]:
+// len -> 0 (`% len`), -1 -> 0 in FAITHFUL mode (`as usize` saturates) or len-1 in FIXED mode (wrap)
+__device__ __forceinline__ int chip_index_arm(float phase, int len, int mode) {
+    const int i = int(floorf(phase));
+    if (mode == GM_CODE_INDEX_FAITHFUL) return i >= len ? 0 : (i < 0 ? 0 : i);
+    return i >= len ? 0 : (i < 0 ? len - 1 : i);
 }
 
 // one sample: carrier wipe-off fused with the replica multiplies (early_late_correlation :231-263)
@@ -126,16 +156,24 @@ __device__ __forceinline__ void correlate_sample(const EpochConsts& c, const int
     const int mode = MODE_T >= 0 ? MODE_T : c.mode;
     const bool boc = BOC_T >= 0 ? (BOC_T != 0) : (c.boc11 != 0);
     const float fi = float(i);
-    const float phase = c.carrier_phase + __fdiv_rn(c.two_pi_f * fi, c.fs);
+    const float w = c.two_pi_f * fi;
+    const float phase = c.carrier_phase + (FAST ? div_by_fs(w, c.fs, c.inv_fs) : __fdiv_rn(w, c.fs));
     float sn, cs;
     sincos_f32_via_f64(phase, sn, cs);
     const float wc = cs, ws = -sn;                          // Complex32::new(cos_p, -sin)
     const float xr = d.x * wc - d.y * ws;                   // num-complex Mul
     const float xi = d.x * ws + d.y * wc;
     const float chip_idx = fmod_code<FAST>(c.code_phase + fi * c.step, c.lenf);
-    float pc = float(chips[chip_index(chip_idx, c.len, mode)]);
-    float ec = float(chips[chip_index(chip_idx + c.el, c.len, mode)]);
-    float lc = float(chips[chip_index(chip_idx - c.el, c.len, mode)]);
+    float pc, ec, lc;
+    if (FAST) {   // chip_idx in [0, len): the prompt index needs no reduction, the arms one select each
+        pc = float(chips[int(floorf(chip_idx))]);
+        ec = float(chips[chip_index_arm(chip_idx + c.el, c.len, mode)]);
+        lc = float(chips[chip_index_arm(chip_idx - c.el, c.len, mode)]);
+    } else {
+        pc = float(chips[chip_index(chip_idx, c.len, mode)]);
+        ec = float(chips[chip_index(chip_idx + c.el, c.len, mode)]);
+        lc = float(chips[chip_index(chip_idx - c.el, c.len, mode)]);
+    }
     if (boc) {   // BOC(1,1): sub-carrier sign = +1 on the first half chip, -1 on the second
         const float a = chip_idx, b = chip_idx + c.el, e = chip_idx - c.el;
         pc = (a - floorf(a)) < 0.5f ? pc : -pc;
@@ -148,8 +186,8 @@ __device__ __forceinline__ void correlate_sample(const EpochConsts& c, const int
     acc[4] = __builtin_fmaf(xr, lc, acc[4]); acc[5] = __builtin_fmaf(xi, lc, acc[5]);
     if constexpr (ARMS == 5) {
         const float ve = chip_idx + c.vel, vl = chip_idx - c.vel;
-        float vec = float(chips[chip_index(ve, c.len, mode)]);
-        float vlc = float(chips[chip_index(vl, c.len, mode)]);
+        float vec = float(chips[FAST ? chip_index_arm(ve, c.len, mode) : chip_index(ve, c.len, mode)]);
+        float vlc = float(chips[FAST ? chip_index_arm(vl, c.len, mode) : chip_index(vl, c.len, mode)]);
         if (boc) {
             vec = (ve - floorf(ve)) < 0.5f ? vec : -vec;
             vlc = (vl - floorf(vl)) < 0.5f ? vlc : -vlc;
@@ -406,8 +444,8 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
     const bool leader = (g == 0 && tid == 0);
     int e = 0;
     bool timed_out = false;
-    gm_trk_state s = s0;
-    if (s0.active && row >= 0 && row < cfg.n_codes) {
+    const bool ran = s0.active && row >= 0 && row < cfg.n_codes;
+    if (ran) {
         const int8_t* crow = a.codes + size_t(row) * cfg.code_len;
         for (int i = tid; i < cfg.code_len; i += T) chips[i] = crow[i];
         if (tid == 0) { ctl = 0; sh.s = s0; prepare_epoch(cfg, a.head, sh); }
@@ -418,9 +456,13 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
         const uint32_t i0 = uint32_t(g) * per;
         // software prefetch: the first KPF strided samples of the NEXT epoch are requested while this
         // epoch's partial sums travel between workgroups (its window start is known: next + n)
-        cf pf[KPF];
-#pragma unroll
-        for (int j = 0; j < KPF; ++j) pf[j] = a.ring[(s0.next_sample_index + i0 + tid + j * T) & a.mask];
+        // (four named values, not an array: hipcc kept `cf pf[4]` in scratch memory, and the scratch store behind
+        // each prefetch made every wave wait for its loads right there instead of at first use)
+        static_assert(KPF == 4, "prefetch depth is spelled out below");
+        cf pf0 = a.ring[(s0.next_sample_index + i0 + tid) & a.mask];
+        cf pf1 = a.ring[(s0.next_sample_index + i0 + tid + T) & a.mask];
+        cf pf2 = a.ring[(s0.next_sample_index + i0 + tid + 2 * T) & a.mask];
+        cf pf3 = a.ring[(s0.next_sample_index + i0 + tid + 3 * T) & a.mask];
 
         for (; e < a.epochs; ++e) {
             const uint32_t n = sh.n;
@@ -441,16 +483,16 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
                 // samples (division, f64 reduction, LDS look-ups are long dependent chains)
                 const uint32_t b0 = i0 + tid;
                 if (full >= 2) {
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[0], b0, acc);
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[1], b0 + T, acc2);
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf0, b0, acc);
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf1, b0 + T, acc2);
                 } else if (full == 1) {
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[0], b0, acc);
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf0, b0, acc);
                 }
                 if (full >= 4) {
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[2], b0 + 2 * T, acc);
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[3], b0 + 3 * T, acc2);
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf2, b0 + 2 * T, acc);
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf3, b0 + 3 * T, acc2);
                 } else if (full == 3) {
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf[2], b0 + 2 * T, acc);
+                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf2, b0 + 2 * T, acc);
                 }
                 uint32_t j = KPF;
                 for (; j + 1 < full; j += 2) {
@@ -462,7 +504,9 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
                 // ragged last pass
                 const uint32_t it = b0 + full * T;
                 if (it < i1) {
-                    cf d = full == 0 ? pf[0] : (full == 1 ? pf[1] : (full == 2 ? pf[2] : pf[3]));
+                    // component-wise selects: a ternary over the structs is a select of ADDRESSES and pins all four in scratch
+                    cf d = cf_make(full == 0 ? pf0.x : (full == 1 ? pf1.x : (full == 2 ? pf2.x : pf3.x)),
+                                   full == 0 ? pf0.y : (full == 1 ? pf1.y : (full == 2 ? pf2.y : pf3.y)));
                     if (full >= uint32_t(KPF)) d = a.ring[(win + it) & a.mask];
                     correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d, it, acc2);
                 }
@@ -474,8 +518,10 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
             if (a.stamps && blockIdx.x == 0 && lane == 0) stp[8 + wave] = stamp_now();        // per-wave compute end
             {   // request the next epoch's samples now; they land during the exchange below
                 const uint64_t nb = win + n;
-#pragma unroll
-                for (int j = 0; j < KPF; ++j) pf[j] = a.ring[(nb + i0 + tid + j * T) & a.mask];
+                pf0 = a.ring[(nb + i0 + tid) & a.mask];
+                pf1 = a.ring[(nb + i0 + tid + T) & a.mask];
+                pf2 = a.ring[(nb + i0 + tid + 2 * T) & a.mask];
+                pf3 = a.ring[(nb + i0 + tid + 3 * T) & a.mask];
             }
 #pragma unroll
             for (int k = 0; k < NV; ++k) acc[k] = wave_sum_dpp(acc[k] + acc2[k]);
@@ -562,10 +608,9 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
             if (st_on) stp[7] = stamp_now();
         }
         if (tid == 0 && timed_out) *a.error_flag = 1;
-        s = sh.s;
     }
     if (leader) {
-        a.states[ch] = s;
+        if (ran) a.states[ch] = sh.s;       // an idle channel's state is left as it was
         gm_trk_out z;
         z.ip = z.qp = z.ie = z.qe = z.il = z.ql = z.ive = z.qve = z.ivl = z.qvl = 0.0f;
         for (int r = e; r < a.epochs; ++r) {   // passes in which this channel did not run
