@@ -1098,6 +1098,7 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
     d.pll_dt = cfg->pll_dt > 0 ? cfg->pll_dt : 0.001f;
     d.dll_dt = cfg->dll_dt > 0 ? cfg->dll_dt : 0.001f;
     d.nominal_code_rate = cfg->nominal_code_rate > 0 ? cfg->nominal_code_rate : CA_RATE;
+    gm::fill_trk_derived(d);
     if (cfg->codes) t->h_codes.assign(cfg->codes, cfg->codes + size_t(cfg->n_codes) * cfg->code_len);
     else t->h_codes.assign(&ca_table().rows[0][0], &ca_table().rows[0][0] + 32 * 1023);
 

@@ -89,7 +89,20 @@ struct TrkDevCfg {
     float lock_threshold; uint32_t max_lost_epochs;
     float pll_tau1, pll_tau2, dll_tau1, dll_tau2, pll_dt, dll_dt;
     float nominal_code_rate;
+    // per-launch constants of the scalar epilogue, computed once on the host with IEEE f32 / f64 division
+    // (fill_trk_derived): quotients of configuration constants and correctly rounded reciprocals for the
+    // constant-divisor divisions
+    float inv_fs, inv_len;
+    float pll_dt_tau1, pll_tau2_tau1, dll_dt_tau1, dll_tau2_tau1;   // dt/tau1, tau2/tau1 (LoopFilter::update :68-70)
+    int div_fs_ok;            // fs significand not all ones: div_const(x, fs) is the correctly rounded quotient
 };
+inline void fill_trk_derived(TrkDevCfg& d) {
+    d.inv_fs = 1.0f / d.fs; d.inv_len = 1.0f / d.code_len_f;
+    d.pll_dt_tau1 = d.pll_dt / d.pll_tau1; d.pll_tau2_tau1 = d.pll_tau2 / d.pll_tau1;
+    d.dll_dt_tau1 = d.dll_dt / d.dll_tau1; d.dll_tau2_tau1 = d.dll_tau2 / d.dll_tau1;
+    uint32_t bits; __builtin_memcpy(&bits, &d.fs, 4);
+    d.div_fs_ok = ((bits & 0x7fffffu) != 0x7fffffu && d.fs > 1.0f && d.fs < 1.0e12f) ? 1 : 0;
+}
 enum { TRK_MODE_CORRELATE = 0, TRK_MODE_DO_WORK = 1 };
 // sample source: ring (mask = size-1, absolute index = next_sample_index + i) or linear (mask = ~0, base 0)
 struct TrkSrc {

@@ -81,14 +81,28 @@ __device__ __forceinline__ int chip_index(float phase, int len, int mode) {
     return i >= len ? i - len : i;
 }
 
-// LoopFilter::update (:68-70)
-__device__ __forceinline__ float loop_filter_update(float tau1, float tau2, float d_err, float err, float dt) {
-    return d_err * __fdiv_rn(dt, tau1) + (d_err - err) * __fdiv_rn(tau2, tau1);
+// LoopFilter::update (:68-70): d_err * (dt / tau1) + (d_err - err) * (tau2 / tau1); the two quotients are
+// configuration constants, divided once on the host (TrkDevCfg::*_tau1, same IEEE f32 quotients)
+__device__ __forceinline__ float loop_filter_update(float dt_over_tau1, float tau2_over_tau1, float d_err, float err) {
+    return d_err * dt_over_tau1 + (d_err - err) * tau2_over_tau1;
+}
+
+// x / y for a divisor whose correctly rounded reciprocal inv = RN(1/y) is known: q0 = x*inv,
+// q = fma(fma(-q0, y, x), inv, q0) is the correctly rounded quotient (Markstein) while the quotient stays in the normal
+// range and y's significand is not all ones — checked against IEEE division on 3.6e8 operands per divisor (code
+// lengths, 21 sample rates).  Used only where the dividend is a sample count or a code rate (0 or ~1e3..1e8).
+__device__ __forceinline__ float div_const(float x, float y, float inv) {
+    const float q0 = x * inv;
+    return __builtin_fmaf(__builtin_fmaf(-q0, y, x), inv, q0);
 }
 
 // generate_ca_code_samples(..).len() = round(fs / (code_rate / len))  (ca_code.rs:13-16)
 __device__ __forceinline__ uint64_t samples_per_code(float fs, float code_rate, float lenf) {
     const float v = roundf(__fdiv_rn(fs, __fdiv_rn(code_rate, lenf)));
+    return v > 0.0f ? uint64_t(v) : 0;
+}
+__device__ __forceinline__ uint64_t samples_per_code(const TrkDevCfg& cfg, float code_rate) {   // same value, one true division
+    const float v = roundf(__fdiv_rn(cfg.fs, div_const(code_rate, cfg.code_len_f, cfg.inv_len)));
     return v > 0.0f ? uint64_t(v) : 0;
 }
 
@@ -110,8 +124,8 @@ __device__ __forceinline__ EpochConsts epoch_consts(const TrkDevCfg& cfg, const 
     c.carrier_phase = st.carrier_phase;
     c.two_pi_f = 2.0f * GM_PI_F * st.carrier_freq;      // (2.0*PI)*carrier_freq
     c.code_phase = st.code_phase;
-    c.step = __fdiv_rn(st.code_rate, cfg.fs);           // self.code_rate / self.fs
-    c.inv_fs = __fdiv_rn(1.0f, cfg.fs);                 // correctly rounded reciprocal for div_by_fs()
+    c.step = cfg.div_fs_ok ? div_const(st.code_rate, cfg.fs, cfg.inv_fs) : __fdiv_rn(st.code_rate, cfg.fs);   // code_rate / fs
+    c.inv_fs = cfg.inv_fs;                              // correctly rounded reciprocal for div_by_fs()
     c.fs = cfg.fs; c.lenf = cfg.code_len_f; c.len = cfg.code_len; c.mode = cfg.code_index_mode;
     c.boc11 = cfg.boc11; c.el = cfg.el_space; c.vel = cfg.vel_space;
     return c;
@@ -275,11 +289,14 @@ template <int ARMS>
 __device__ __forceinline__ void epoch_epilogue(const TrkDevCfg& cfg, gm_trk_state& s, const float (&v)[2 * ARMS],
                                                uint64_t n, int mode, uint8_t& lst, uint8_t& lprn) {
     const float nf = float(n);
+    const bool dk = cfg.div_fs_ok != 0;
     // carrier_phase = (carrier_phase + 2*PI*carrier_freq*(n as f32 / fs)) % (2*PI)      (:240-242)
-    s.carrier_phase = fmodf(s.carrier_phase + 2.0f * GM_PI_F * s.carrier_freq * __fdiv_rn(nf, cfg.fs),
+    s.carrier_phase = fmodf(s.carrier_phase + 2.0f * GM_PI_F * s.carrier_freq *
+                                (dk ? div_const(nf, cfg.fs, cfg.inv_fs) : __fdiv_rn(nf, cfg.fs)),
                             2.0f * GM_PI_F);
     // code_phase = (code_phase + (code_rate/fs) * n as f32) % 1023.0                     (:265-267)
-    s.code_phase = fmodf(s.code_phase + __fdiv_rn(s.code_rate, cfg.fs) * nf, cfg.code_len_f);
+    s.code_phase = fmodf(s.code_phase + (dk ? div_const(s.code_rate, cfg.fs, cfg.inv_fs) : __fdiv_rn(s.code_rate, cfg.fs)) * nf,
+                         cfg.code_len_f);
     s.i_prompt = v[0]; s.q_prompt = v[1];
     lst = 0; lprn = 0;
     if (mode != TRK_MODE_DO_WORK) return;
@@ -289,13 +306,13 @@ __device__ __forceinline__ void epoch_epilogue(const TrkDevCfg& cfg, gm_trk_stat
         s.lost_counter = 0;
         // run_loop_filters (:279-302)
         const float pll_err = __fdiv_rn(atanf(__fdiv_rn(v[1], v[0])), 2.0f * GM_PI_F);
-        s.carrier_nco = loop_filter_update(cfg.pll_tau1, cfg.pll_tau2, pll_err, s.carrier_error, cfg.pll_dt);
+        s.carrier_nco = loop_filter_update(cfg.pll_dt_tau1, cfg.pll_tau2_tau1, pll_err, s.carrier_error);
         s.carrier_error = pll_err;
         s.carrier_freq += s.carrier_nco;
         const float pow_e = __fsqrt_rn(v[2] * v[2] + v[3] * v[3]);
         const float pow_l = __fsqrt_rn(v[4] * v[4] + v[5] * v[5]);
         const float dll_err = ((pow_e + pow_l) != 0.0f) ? __fdiv_rn(pow_e - pow_l, pow_e + pow_l) : 0.0f;
-        s.code_nco = loop_filter_update(cfg.dll_tau1, cfg.dll_tau2, dll_err, s.code_error, cfg.dll_dt);
+        s.code_nco = loop_filter_update(cfg.dll_dt_tau1, cfg.dll_tau2_tau1, dll_err, s.code_error);
         s.code_error = dll_err;
         s.code_rate += s.code_nco;
     } else {
@@ -308,7 +325,7 @@ __device__ __forceinline__ void epoch_epilogue(const TrkDevCfg& cfg, gm_trk_stat
     }
     if (advance) {
         s.next_sample_index += n;                    // (:192 / :203)
-        s.num_samples_per_code = samples_per_code(cfg.fs, s.code_rate, cfg.code_len_f);
+        s.num_samples_per_code = samples_per_code(cfg, s.code_rate);
     }
 }
 
@@ -416,9 +433,10 @@ struct EpochShared {
     EpochConsts ec;
 };
 
-__device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t head, EpochShared& sh) {
+// n_known: the epilogue has just stored round(fs/(code_rate/len)) for the CURRENT code_rate in num_samples_per_code
+__device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t head, EpochShared& sh, bool n_known = false) {
     const gm_trk_state& s = sh.s;
-    const uint64_t n = samples_per_code(cfg.fs, s.code_rate, cfg.code_len_f);     // update() :165-166
+    const uint64_t n = n_known ? s.num_samples_per_code : samples_per_code(cfg, s.code_rate);     // update() :165-166
     bool run = s.active && n > 0 && n < (1ull << 31);
     if (run) run = (int64_t)(head - (s.next_sample_index + n)) >= 0;              // :170-172
     sh.n = run ? uint32_t(n) : 0u;
@@ -590,7 +608,7 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
                 if (st_on) stp[6] = stamp_now();
                 if (lane == 0) {
                     sh.s = sn;
-                    prepare_epoch(cfg, a.head, sh);              // n / constants / gate of the NEXT epoch, once
+                    prepare_epoch(cfg, a.head, sh, !to);            // n / constants / gate of the NEXT epoch, once
                     ctl = to ? 1 : 0;
                     if (g == 0 && !to) {
                         const size_t o = size_t(e) * C + ch;
