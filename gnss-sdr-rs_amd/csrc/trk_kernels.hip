@@ -559,7 +559,7 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
                     for (int w = 1; w < NW; ++w) p += wsum[w][lane];
                     const unsigned long long gran =
                         (unsigned long long)__float_as_uint(p) | ((unsigned long long)tag << 32);
-                    __hip_atomic_store(&slot[g * NV + lane], gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&slot[lane * a.G + g], gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // arm-major: [k][g]
                 }
                 if (st_on) stp[3] = stamp_now();
                 // gather the G partials: lane l polls granules l, l+64, ... (G*NV <= 256)
@@ -567,39 +567,73 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
                 float val[4] = {0.f, 0.f, 0.f, 0.f};
                 const long long t0 = wall_clock64();
                 bool to = false;
+                // first sweep: every granule this lane is responsible for is requested before any is examined, so the
+                // common case (all partners already published) costs ONE memory round trip, not one per slot
+                unsigned long long gr[4] = {0ull, 0ull, 0ull, 0ull};
+                bool pending[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int idx = lane + q * 64;
-                    if (idx < ng) {
-                        unsigned long long gr;
-                        for (;;) {
-                            gr = __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (uint32_t(gr >> 32) == tag) break;
-                            if (wall_clock64() - t0 > 20000000ll) { to = true; break; }   // 0.2 s at 100 MHz
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        val[q] = __uint_as_float(uint32_t(gr));
-                    }
+                    pending[q] = lane + q * 64 < ng;
+                    if (pending[q]) gr[q] = __hip_atomic_load(&slot[lane + q * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (pending[q] && uint32_t(gr[q] >> 32) == tag) pending[q] = false;
+                // stragglers: re-poll only what is still missing; the wall clock (bounded wait) is read every 64th round
+                uint32_t rounds = 0;
+                while ((pending[0] | pending[1] | pending[2] | pending[3]) && !to) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (pending[q]) gr[q] = __hip_atomic_load(&slot[lane + q * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (pending[q] && uint32_t(gr[q] >> 32) == tag) pending[q] = false;
+                    if ((++rounds & 63u) == 0u && wall_clock64() - t0 > 20000000ll) to = true;   // 0.2 s at 100 MHz
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (lane + q * 64 < ng) val[q] = __uint_as_float(uint32_t(gr[q]));
                 to = __any(to);
                 if (st_on) stp[4] = stamp_now();
-                // totals: the polled values are staged in LDS (this wave only: DS operations of one wave complete in
-                // order), lane k adds the G partials of arm k in workgroup order, and the NV totals are broadcast
-                // as scalars, so every lane (and every workgroup of the channel) holds the same v[]
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int idx = lane + q * 64;
-                    if (idx < ng) gathered[idx] = val[q];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                float tk = 0.0f;
-                if (lane < NV)
-                    for (int gg = 0; gg < a.G; ++gg) tk += gathered[gg * NV + lane];
+                // totals of the G partials of every arm, identical in all lanes and in all workgroups of the channel.
+                // Granules are arm-major ([k][g]).  G == 16: arm k's partials sit in one DPP row of 16 lanes (arms 0-3 in
+                // the first sweep's registers, 4.. in the next), so four row_shr adds leave the arm total in the row's last
+                // lane and a readlane broadcasts it — no LDS, no fences.  Other G: staged in LDS (DS operations of one wave
+                // complete in order) and added by lane k in workgroup order.
                 float v[NV];
+                if (a.G == 16) {
+                    float r[4];
 #pragma unroll
-                for (int k = 0; k < NV; ++k) v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tk), k));
+                    for (int q = 0; q < 4; ++q) r[q] = val[q];
+#pragma unroll
+                    for (int q = 0; q < (NV + 3) / 4; ++q) {
+                        int x = __float_as_int(r[q]);
+                        r[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));   // row_shr:1
+                        x = __float_as_int(r[q]);
+                        r[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));   // row_shr:2
+                        x = __float_as_int(r[q]);
+                        r[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true));   // row_shr:4
+                        x = __float_as_int(r[q]);
+                        r[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true));   // row_shr:8
+                    }
+#pragma unroll
+                    for (int k = 0; k < NV; ++k)
+                        v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r[k / 4]), (k % 4) * 16 + 15));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int idx = lane + q * 64;
+                        if (idx < ng) gathered[idx] = val[q];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    float tk = 0.0f;
+                    if (lane < NV)
+                        for (int gg = 0; gg < a.G; ++gg) tk += gathered[lane * a.G + gg];
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tk), k));
+                }
                 if (st_on) stp[5] = stamp_now();
                 gm_trk_state sn = sh.s;
                 sn.num_samples_per_code = n;                     // update() stores the length it used (:166)
