@@ -619,6 +619,27 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
 #pragma unroll
                     for (int k = 0; k < NV; ++k)
                         v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r[k / 4]), (k % 4) * 16 + 15));
+                } else if (a.G == 32 && NV <= 8) {   // arm k = two rows of sweep k/2: row totals by row_shr, pair added as scalars
+                    float r[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r[q] = val[q];
+#pragma unroll
+                    for (int q = 0; q < (NV + 1) / 2; ++q) {
+                        int x = __float_as_int(r[q]);
+                        r[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));
+                        x = __float_as_int(r[q]);
+                        r[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));
+                        x = __float_as_int(r[q]);
+                        r[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true));
+                        x = __float_as_int(r[q]);
+                        r[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true));
+                    }
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        const uint32_t u = __float_as_uint(r[k / 2]);
+                        v[k] = __uint_as_float(__builtin_amdgcn_readlane(u, (k % 2) * 32 + 15)) +
+                               __uint_as_float(__builtin_amdgcn_readlane(u, (k % 2) * 32 + 31));
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
