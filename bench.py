@@ -219,6 +219,13 @@ def main():
         except Exception as e:
             out["fine_doppler"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ three dwells in flight (informative, never `value`)
+    if rank == 0 and world == 1:
+        try:
+            out["config"]["three_dwells_in_flight"] = pipelined_leg(torch, dev, sc, A, d_samples, P, D, N, M)
+        except Exception as e:
+            out["config"]["three_dwells_in_flight"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ configs[0] geometry on the GPU (informative)
     if rank == 0 and world == 1:
         try:
@@ -266,6 +273,36 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pipelined_leg(torch, dev, sc, A, d_samples, P, D, N, M):
+    """Three independent dwells kept in flight on three engines / streams: what the chip does when the grid tail of one
+    dwell (1312 workgroups on 512 slots = 2.56 rounds) and the short stage-F / decision kernels are filled by the next
+    dwell's work.  Per-kernel durations double under co-execution, so this is reported beside `value`, not as it."""
+    engs, mets, streams = [], [], []
+    for _ in range(3):
+        e = A.AcquisitionEngine(sc["fs"], sc["f_if"], N, doppler_hz=sc["doppler_hz"], n_integrations=M)
+        streams.append(torch.cuda.Stream(device=dev))      # kept alive until the engines are closed
+        e.set_stream(streams[-1].cuda_stream)
+        engs.append(e)
+        mets.append(torch.zeros(3 * P * D, dtype=torch.int32, device=dev))
+
+    def step(i):
+        engs[i % 3].search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, mets[i % 3].data_ptr())
+        engs[i % 3].decide_dev(mets[i % 3].data_ptr())
+    for i in range(6):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 60
+    for i in range(K):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = sorted(r["prn"] for r in engs[0].fetch_results(P) if r) == sorted(s["prn"] for s in sc["sats"])
+    for e in engs:
+        e.close()
+    return {"cells_per_s": P * D * N * K / dt, "ms_per_dwell": dt / K * 1e3, "detections_ok": bool(ok)}
 
 
 def cfg1_leg(torch, dev, stream, ca, A, synth):
