@@ -226,6 +226,13 @@ def main():
         except Exception as e:
             out["config"]["three_dwells_in_flight"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ configs[3]'s Galileo part (informative, no reference code)
+    if rank == 0 and world == 1:
+        try:
+            out["cfg4_galileo_geometry"] = cfg4_leg(torch, dev, A, synth)
+        except Exception as e:
+            out["cfg4_galileo_geometry"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ configs[0] geometry on the GPU (informative)
     if rank == 0 and world == 1:
         try:
@@ -273,6 +280,40 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cfg4_leg(torch, dev, A, synth):
+    """The Galileo E1 share of BASELINE configs[3] on one GPU: 36 codes of 4092 chips (4 ms) x 41 bins x 32 000 phases at
+    8 Msps, two code periods.  N = 32000 exceeds one LDS buffer: the composite path (2 x the 16000-point in-LDS plan,
+    intermediates through HBM / L2).  Stand-in random codes; no reference code exists for this constellation."""
+    fs, L, rate, N, M, P = 8.0e6, 4092, 1.023e6, 32000, 2, 36
+    rng = np.random.default_rng(4)
+    codes = np.where(rng.integers(0, 2, (P, L)) > 0, 1, -1).astype(np.int8)
+    dop = np.arange(-5000.0, 5000.1, 250.0, dtype=np.float32)
+    sats = [dict(prn_row=r, cn0_dbhz=48.0, doppler_hz=float(rng.uniform(-4500, 4500)), code_start=int(rng.integers(0, N)))
+            for r in (1, 7, 19, 30)]
+    x = synth.to_i8_iq(synth.make_scene(codes, fs, 0.0, M * N, sats, config_id=44, code_rate=rate))
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=np.arange(1, P + 1), n_integrations=M, codes=codes,
+                              code_rate=rate, decision_mode=A.DECIDE_BEST_BIN)
+    d_x = torch.from_numpy(x).to(dev)
+    d_met = torch.zeros(3 * P * dop.size, dtype=torch.int32, device=dev)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        eng.search_dev(d_x.data_ptr(), A.FMT_I8_IQ, d_met.data_ptr())
+        eng.decide_dev(d_met.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 5
+    for _ in range(K):
+        eng.search_dev(d_x.data_ptr(), A.FMT_I8_IQ, d_met.data_ptr())
+        eng.decide_dev(d_met.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    res = eng.fetch_results(P)
+    ok = all(res[s["prn_row"]] and res[s["prn_row"]]["code_phase_samples"] == s["code_start"] for s in sats)
+    eng.close()
+    return {"workload": "36 codes x 41 bins x 32000 phases (4092-chip code, 4 ms), 2 periods, 8 Msps int8; N = 2 x 16000 composite",
+            "cells_per_s": P * dop.size * N / dt, "ms_per_dwell": dt * 1e3, "simulated_found_at_true_phase": bool(ok)}
 
 
 def pipelined_leg(torch, dev, sc, A, d_samples, P, D, N, M):

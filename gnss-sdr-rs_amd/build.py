@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgnss_mi355x.so")
-SOURCES = ["acq_kernels.hip", "trk_kernels.hip", "fe_kernels.hip", "nav_host.hip", "gm_api.hip"]
+SOURCES = ["acq_kernels.hip", "acq_composite.hip", "trk_kernels.hip", "fe_kernels.hip", "nav_host.hip", "gm_api.hip"]
 HEADERS = ["fft_core.h", "fft_plans.h", "gm_internal.h", os.path.join("..", "..", "include", "gnss_mi355x.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
          "-Wall", "-Wno-unused-function"]
@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
         if r.returncode:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout)
         return r.stdout
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s + ".o") for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

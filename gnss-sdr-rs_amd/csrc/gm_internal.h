@@ -57,6 +57,15 @@ int list_plans(uint32_t* sizes, int cap);
 // diagnostic: device buffer [n_int][8 waves][8 phases] of s_memtime stamps written by workgroup 0 of acq_corr_kernel
 void set_corr_stamps(long long* d_ptr);
 
+// composite transform sizes N = Q * Nb (acq_composite.hip)
+bool comp_q_supported(uint32_t Q);
+void launch_comp_pre(hipStream_t, const void* in, int fmt, const cf* tables, cf* out, uint32_t Q, uint32_t Nb,
+                     uint32_t n_int, uint32_t n_items, const int8_t* code_samples);
+void launch_comp_mul(hipStream_t, const cf* spectra, const cf* code_fft, cf* y, const uint32_t* worker_list, uint32_t N,
+                     uint32_t n_dm, uint32_t n_workers);
+void launch_comp_post(hipStream_t, const cf* z, uint32_t Q, uint32_t Nb, uint32_t n_int, uint32_t n_bins,
+                      const uint32_t* worker_list, uint32_t n_workers, float* mmax, uint32_t* margmax, float* msum);
+
 // elementwise apply_doppler_shift (doppler_shift.rs:25-58)
 void launch_apply_doppler(hipStream_t, const cf* s, const cf* t, cf* out, size_t n);
 // |X|^2 (fft.rs:27-29)

@@ -169,3 +169,55 @@ def test_five_arm_boc_persistent_kernel_first_epoch(gpu, oracle):
         o = outs[ep, 2]
         assert np.hypot(o[0], o[1]) > np.hypot(o[6], o[7]) and np.hypot(o[0], o[1]) > np.hypot(o[8], o[9])
     mgr.close(); ring.close()
+
+
+@pytest.mark.parametrize("fs,code_len,code_rate,N,Q", [(8.0e6, 4092, 1.023e6, 32000, 2),      # Galileo-E1-like, configs[3]
+                                                       (10.0e6, 4092, 1.023e6, 40000, 4),
+                                                       (25.0e6, 1023, 1.023e6, 25000, 5)])    # GPS C/A at configs[2]'s rate
+def test_acquisition_beyond_one_lds_buffer(gpu, oracle, fs, code_len, code_rate, N, Q):
+    """Transform sizes above 16384 (one code period of a 4 ms code at 8-10 Msps, or GPS at 25 Msps): N = Q x an in-LDS
+    plan (acq_composite.hip).  Same checks as every other acquisition parity test: per-(worker, bin) max / first argmax /
+    sum against the generalised oracle (its FFT handles any N), identical decisions."""
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    M = 2
+    dop = np.array([-500.0, 0.0, 500.0], np.float32)
+    rng = np.random.default_rng(N)
+    if code_len == 1023:
+        codes, prn_ids = None, [3, 9, 21]
+        table = oracle.ca_code_table()
+        rows = [2, 8, 20]
+    else:
+        codes = np.where(rng.integers(0, 2, (3, code_len)) > 0, 1, -1).astype(np.int8)
+        prn_ids, table, rows = [1, 2, 3], codes, [0, 1, 2]
+    sats = [dict(prn_row=rows[0], cn0_dbhz=50.0, doppler_hz=180.0, code_start=N - 77),
+            dict(prn_row=rows[2], cn0_dbhz=48.0, doppler_hz=-390.0, code_start=12345)]
+    x = synth.to_i8_iq(synth.make_scene(table, fs, 0.0, M * N, sats, config_id=70 + Q, code_rate=code_rate))
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=prn_ids, n_integrations=M, codes=codes, code_rate=code_rate)
+    got = eng.search(x)
+    mx, am, sm = eng.metrics()
+    tables = [oracle.DopplerShiftTable(0.0, float(d), fs, N) for d in dop]
+    xc = (x[:, 0] + 1j * x[:, 1]).astype(np.complex64)
+    n_found = 0
+    for w in range(3):
+        ow = oracle.AcquisitionWorker(prn_ids[w], N, fs, code=(codes[w] if codes is not None else None), code_rate=code_rate)
+        assert np.linalg.norm(eng.code_fft(w) - ow.ca_code_samples_fft) / np.linalg.norm(ow.ca_code_samples_fft) < 2e-6
+        exp, (bmax, barg, bsum, _) = ow.search_satellite(xc, tables, 0, M, want_planes=True, no_early_exit=True)
+        assert np.allclose(mx[w], bmax, rtol=REL) and np.allclose(sm[w], bsum, rtol=REL)
+        assert (am[w] == barg).all(), (w, am[w], barg)
+        assert (got[w] is None) == (exp is None)
+        if exp:
+            n_found += 1
+            for k in ("prn", "code_phase_samples", "doppler_bin", "carrier_freq"):
+                assert got[w][k] == exp[k]
+    # (the reference's peak / mean > 7 test false-alarms on a noise-only plane of >= 25 000 cells with two integrations —
+    # the GPU and the oracle agree on that too — so only the two simulated satellites are pinned here)
+    # and, like the reference, the decision stops at the FIRST bin that passes, which may be such a false alarm; the truth
+    # is checked on the strongest bin of each simulated satellite's plane
+    assert n_found >= 2
+    assert am[0][int(np.argmax(mx[0]))] == N - 77 and am[2][int(np.argmax(mx[2]))] == 12345
+    assert abs(float(dop[int(np.argmax(mx[0]))]) - 180.0) <= 250.0 and abs(float(dop[int(np.argmax(mx[2]))]) + 390.0) <= 250.0
+    # the refinement works on the same snapshot (its own long FFT does not depend on the acquisition size)
+    r0 = dict(got[0], code_phase_samples=N - 77)
+    fine = eng.finer_doppler([r0, None, None])
+    assert abs(fine[0]["freq_hz"] - 180.0) < 60.0
+    eng.close()
