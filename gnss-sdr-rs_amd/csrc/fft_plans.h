@@ -12,7 +12,7 @@
 
 namespace gm {
 using Plan8000 = Plan<8000, 512, 25, 20, 16>;
-using Plan16368 = Plan<16368, 576, 33, 31, 16>;   // last pass: 1023 butterflies -> 2 per thread
+using Plan16368 = Plan<16368, 768, 33, 31, 16>;   // 12 waves = 3 per SIMD (576 lanes = 9 waves loaded the SIMDs 3/2/2/2); last pass 2 butterflies per thread
 using Plan4096 = Plan<4096, 256, 16, 16, 16>;
 using Plan2048 = Plan<2048, 256, 8, 16, 16>;
 using Plan1024 = Plan<1024, 128, 8, 8, 16>;
