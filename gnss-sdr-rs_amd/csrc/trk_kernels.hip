@@ -551,6 +551,9 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
             lds_barrier();    // NOT __syncthreads(): its fence would wait for the prefetch loads (vmcnt(0))
             if (st_on) stp[2] = stamp_now();
             if (wave == 0) {
+                // the serial section is a chain of dependent instructions of ONE wave; the other workgroup of this CU is
+                // usually correlating on the same SIMD: raise this wave's issue priority so the chain is not queued behind it
+                __builtin_amdgcn_s_setprio(3);
                 // this workgroup's partial (waves added in a fixed order), published as {value, tag} granules
                 const uint32_t tag = a.tag_base + uint32_t(e) + 1u;
                 unsigned long long* slot = a.xchg + (size_t(e & 1) * C + ch) * a.G * NV;
@@ -673,6 +676,7 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
                         if (a.lost_prn) a.lost_prn[o] = lprn;
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
             }
             lds_barrier();
             if (ctl) { timed_out = true; break; }
