@@ -552,34 +552,50 @@ __global__ __launch_bounds__(64) void decide_kernel(DecideArgs a) {
         smax[d] = a.mmax[o]; ssum[d] = a.msum[o]; sarg[d] = a.margmax[o];
     }
     __syncthreads();
-    if (lane != 0) return;
-    gm_acq_result r;
-    r.prn = a.prn_ids[p]; r.code_phase_samples = 0; r.code_phase_chips = 0.f; r.carrier_freq = 0.f;
-    r.fs = 0.f; r.mag_relative = 0.f; r.sample_global_index = 0; r.doppler_bin = -1;   // AcquisitionResult::new
-    uint8_t found = 0;
+    // The reference scans the bins in ascending order keeping a running best plane (first strict maximum, :195-202) and
+    // stops at the first bin where that running best passes max/avg > threshold (:204-223).  Here lane d holds the running
+    // best THROUGH bin d (its own scan of smax[0..d], same comparisons), evaluates the test for it with the same two IEEE
+    // divisions, and the lowest passing lane is the reference's exit point: 41 dependent iterations become one.
     const bool searched = (p >= 64) || ((a.mask_lo >> p) & 1ull);
-    if (searched) {
-        float gmax = 0.0f, bsum = 0.0f;                    // best plane starts all-zero (:168)
-        uint32_t bphase = 0;
-        int bbin = -1;
-        const float nm1 = float(a.fft_size - 1);
-        for (int d = 0; d < D; ++d) {                      // ascending Doppler (:171)
-            const float lm = smax[d];
-            if (lm > gmax) { gmax = lm; bphase = sarg[d]; bsum = ssum[d]; bbin = d; }
-            if (a.best_bin_mode && d + 1 < D) continue;      // strongest-bin mode: test once, after the last bin
-            const float avg = __fdiv_rn(bsum - gmax, nm1);  // (sum - max) / (N-1)  (:236)
-            if (__fdiv_rn(gmax, avg) > a.threshold) {       // max/avg > 7.0       (:237)
+    float gmax = 0.0f, bsum = 0.0f;                        // best plane starts all-zero (:168)
+    uint32_t bphase = 0;
+    int bbin = -1;
+    bool pass = false;
+    for (int d0 = 0; d0 < D; d0 += 64) {                   // D <= 64 in practice: one trip
+        const int d = d0 + lane;
+        if (d0 > 0) { gmax = 0.0f; bsum = 0.0f; bphase = 0; bbin = -1; }
+        if (d < D && searched) {
+            for (int q = 0; q <= d; ++q) {
+                const float lm = smax[q];
+                if (lm > gmax) { gmax = lm; bphase = sarg[q]; bsum = ssum[q]; bbin = q; }
+            }
+            if (!a.best_bin_mode || d + 1 == D) {          // strongest-bin mode: test once, after the last bin
+                const float avg = __fdiv_rn(bsum - gmax, float(a.fft_size - 1));   // (sum - max) / (N-1)  (:236)
+                pass = __fdiv_rn(gmax, avg) > a.threshold;                          // max/avg > 7.0       (:237)
+            }
+        }
+        const unsigned long long votes = __ballot(pass);
+        if (votes) {
+            if (lane == __ffsll((long long)votes) - 1) {       // the first bin that passes: early exit (:211-222)
+                gm_acq_result r;
+                r.prn = a.prn_ids[p];
                 r.code_phase_samples = bphase;
                 r.code_phase_chips = __fdiv_rn(float(bphase) * a.code_rate, a.fs);   // (:215-216)
                 r.carrier_freq = a.table_freq[bbin]; r.fs = a.fs; r.mag_relative = gmax;
                 r.sample_global_index = a.local_tail + bphase; r.doppler_bin = bbin;
-                found = 1;
-                break;                                       // early exit (:211-222)
+                a.results[p] = r;
+                a.found[p] = 1;
             }
+            return;
         }
     }
-    a.results[p] = r;
-    a.found[p] = found;
+    if (lane == 0) {
+        gm_acq_result r;
+        r.prn = a.prn_ids[p]; r.code_phase_samples = 0; r.code_phase_chips = 0.f; r.carrier_freq = 0.f;
+        r.fs = 0.f; r.mag_relative = 0.f; r.sample_global_index = 0; r.doppler_bin = -1;   // AcquisitionResult::new
+        a.results[p] = r;
+        a.found[p] = 0;
+    }
 }
 void launch_decide(hipStream_t st, const DecideArgs& a) {
     if (a.n_prn <= 0) return;
