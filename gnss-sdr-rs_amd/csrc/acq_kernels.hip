@@ -142,12 +142,25 @@ template <class PL, bool KEEP_CODE, bool STAMPS>
 __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ tw_inv,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
-    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int map_mode) {
+    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int map_mode,
+    int split_from, int split_k, int split_items, float* __restrict__ split_scratch, uint32_t* __restrict__ split_counter) {
     // XCD-aware tile map: blocks b and b+8 share an XCD (round-robin dispatch, speed only).  The (bin, worker)
     // items are numbered bin-major and every XCD takes one contiguous, EQUAL share of them: the workers of a
     // Doppler bin stay on one XCD (at most two), so that bin's M spectra (M*8N bytes) are served by that XCD's L2,
     // and no XCD gets a whole extra bin (41 bins over 8 XCDs used to give XCD 0 a full third round).
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    // Grid tail: the items of an XCD beyond its last FULL round of resident workgroups (slot >= split_from) are cut into
+    // split_k parts of n_int / split_k integrations each, so the last round is made of short workgroups (1312 items on
+    // 512 slots are 2.56 rounds: whole items would take 3, fifths take 2.6).  The parts of an item meet through HBM: each
+    // stores its partial power plane write-through, the one whose ticket comes last adds the split_k planes in part order
+    // and does the reduction.  Placement is for speed only: correctness does not depend on where the parts run.
+    const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3;
+    int slot = wslot, part = 0, parts = 1;
+    if (wslot >= split_from) {
+        const int h = wslot - split_from;
+        slot = split_from + h / split_k;
+        part = h % split_k;
+        parts = split_k;
+    }
     int d, p;
     if (map_mode == 0) {          // equal contiguous share of the bin-major item list per XCD
         const int items = n_bins * n_workers, share = (items + 7) >> 3;
@@ -207,7 +220,8 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     long long* stbase = nullptr;
     if constexpr (STAMPS) stbase = (blockIdx.x == 0 && (tid & 63) == 0 && PL::T / 64 <= 8) ? g_corr_stamps : nullptr;
     const int wv = tid >> 6;
-    for (int m = 0; m < n_int; ++m) {
+    const int m_per = n_int / parts, m_begin = part * m_per, m_end = m_begin + m_per;
+    for (int m = m_begin; m < m_end; ++m) {
         auto in = [&](int it, int r) {
             const int voff = (tid + it * PL::T) * 8;
             const cf a = buf_load_cf(xrs, voff, (m * PL::N + r * NB0) * 8);
@@ -237,6 +251,51 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
             cf vl[PL::ITL][PL::RL];
             Fft<PL, true>::last_stage1(vl, lds, tw, tid);
             Fft<PL, true>::last_stage2(vl, out, tid);
+        }
+    }
+
+    if constexpr (PL::RL % 4 == 0 && !STAMPS) {
+        if (parts > 1) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int SLAB = PL::ITL * PL::RL * PL::T;                        // floats per partial plane, register order
+            const size_t item_slab = (size_t(xcd) * split_items + (slot - split_from)) * parts;
+            const __amdgpu_buffer_rsrc_t srs =
+                make_rsrc(split_scratch + item_slab * SLAB, unsigned(parts) * SLAB * 4u);
+#pragma unroll
+            for (int it = 0; it < PL::ITL; ++it)
+#pragma unroll
+                for (int r4 = 0; r4 < PL::RL / 4; ++r4) {
+                    u32x4 v;
+                    v.x = __float_as_uint(acc[it][4 * r4 + 0]); v.y = __float_as_uint(acc[it][4 * r4 + 1]);
+                    v.z = __float_as_uint(acc[it][4 * r4 + 2]); v.w = __float_as_uint(acc[it][4 * r4 + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, srs, tid * 16, (part * SLAB + (it * (PL::RL / 4) + r4) * PL::T * 4) * 4, 16);   // sc1: write-through
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left
+            __syncthreads();                                         // ... and every wave's
+            __shared__ int s_last;
+            if (tid == 0) {
+                uint32_t* cnt = split_counter + size_t(xcd) * split_items + (slot - split_from);
+                const uint32_t old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (old == uint32_t(parts - 1)) ? 1 : 0;
+                if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            __syncthreads();
+            if (!s_last) return;
+            // the last arriver: planes added in part order (the same order whoever comes last), sc1 loads bypass this CU's L1
+#pragma unroll
+            for (int it = 0; it < PL::ITL; ++it)
+#pragma unroll
+                for (int r = 0; r < PL::RL; ++r) acc[it][r] = 0.0f;
+            for (int q = 0; q < parts; ++q) {
+#pragma unroll
+                for (int it = 0; it < PL::ITL; ++it)
+#pragma unroll
+                    for (int r4 = 0; r4 < PL::RL / 4; ++r4) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srs, tid * 16, (q * SLAB + (it * (PL::RL / 4) + r4) * PL::T * 4) * 4, 16);
+                        acc[it][4 * r4 + 0] += __uint_as_float(v.x); acc[it][4 * r4 + 1] += __uint_as_float(v.y);
+                        acc[it][4 * r4 + 2] += __uint_as_float(v.z); acc[it][4 * r4 + 3] += __uint_as_float(v.w);
+                    }
+            }
         }
     }
 
@@ -450,9 +509,10 @@ template <class PL> struct Launch {
         hipLaunchKernelGGL(acq_mix_fft_kernel<PL>, dim3(n_bins * n_int), dim3(PL::T), 0, st, samples, fmt,
                            tables, tw_fwd, spectra, n_int);
     }
+    static constexpr int SPLIT_SLAB = (PL::RL % 4 == 0) ? PL::ITL * PL::RL * PL::T : 0;   // floats per partial plane
     static void corr(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
-                     int n_int) {
+                     int n_int, float* split_scratch, uint32_t* split_counter) {
         if (n_workers <= 0) return;
         // Tile map: whole Doppler bins per XCD (best L2 locality) unless that costs an XCD an extra round of
         // workgroups (2 x 32 resident per XCD) compared with equal shares of the item list.  Measured on configs[1]
@@ -466,12 +526,36 @@ template <class PL> struct Launch {
         if (map_mode == 1 && per_xcd_mixed < per_xcd_bins) map_mode = 2;   // same locality, balanced leftovers
         if (forced >= 0) map_mode = forced;
         const int share = map_mode == 0 ? per_xcd_even : (map_mode == 1 ? per_xcd_bins : per_xcd_mixed);
+        // Grid tail.  When the queue of an XCD runs dry its resident workgroups finish one by one, and the launch ends a
+        // whole workgroup duration (M transforms, ~45 us alone on a CU) after the last one started: about half a duration
+        // of idle slots.  The LAST items of every XCD are therefore cut into k parts of n_int / k integrations (k = the
+        // largest divisor of n_int up to 5), enough of them that every resident slot ends on a short workgroup
+        // (items * k ~ slots).  Measured at configs[1]: 0.229 -> 0.206 ms per launch; k and the item count barely matter
+        // between (2, 4) and (10, 8).  GM_CORR_SPLIT = 0 / k and GM_CORR_SPLIT_ITEMS override for diagnostics.
+        static const int split_env = getenv("GM_CORR_SPLIT") ? atoi(getenv("GM_CORR_SPLIT")) : -1;
+        static const int items_env = getenv("GM_CORR_SPLIT_ITEMS") ? atoi(getenv("GM_CORR_SPLIT_ITEMS")) : -1;
+        int split_from = share, split_k = 1, split_items = 0;
+        if (SPLIT_SLAB && split_scratch && split_counter && split_env != 0 && !g_corr_stamps_armed && share > slots) {
+            for (int k = 2; k <= GM_CORR_SPLIT_MAX_K; ++k)
+                if (n_int % k == 0) split_k = k;
+            if (split_env > 1 && split_env <= GM_CORR_SPLIT_MAX_K && n_int % split_env == 0) split_k = split_env;
+            if (split_k > 1) {
+                split_items = items_env > 0 ? items_env : (slots + split_k - 1) / split_k;
+                if (split_items > share) split_items = share;
+                if (split_items > GM_CORR_SPLIT_MAX_ITEMS / 8) split_items = GM_CORR_SPLIT_MAX_ITEMS / 8;
+                if (split_items * split_k > GM_CORR_SPLIT_MAX_SLABS / 8) split_items = GM_CORR_SPLIT_MAX_SLABS / 8 / split_k;
+                split_from = share - split_items;
+            }
+        }
+        const int grid = 8 * (split_from + split_items * split_k);
         if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
-            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, true>), dim3(8 * share), dim3(PL::T), 0, st,
-                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode);
+            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, true>), dim3(grid), dim3(PL::T), 0, st,
+                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
+                               split_from, split_k, split_items, split_scratch, split_counter);
         else
-            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, false>), dim3(8 * share), dim3(PL::T), 0, st,
-                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode);
+            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, false>), dim3(grid), dim3(PL::T), 0, st,
+                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
+                               split_from, split_k, split_items, split_scratch, split_counter);
     }
     static void code_fft(hipStream_t st, const int8_t* code_samples, const cf* tw_fwd, cf* out, int n_codes) {
         hipLaunchKernelGGL(acq_code_fft_kernel<PL>, dim3(n_codes), dim3(PL::T), 0, st, code_samples, tw_fwd, out);
@@ -488,7 +572,7 @@ template <class PL> struct Launch {
         if constexpr (POW2) hipLaunchKernelGGL(fine_rows_kernel<PL>, dim3(a.N1, n_sats), dim3(PL::T), 0, st, a);
     }
     static constexpr PlanOps ops() {
-        return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL),
+        return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL), SPLIT_SLAB,
                        &fill_tw, &mix_fft, &corr, &code_fft, &fft_batch,
                        POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr};
     }

@@ -196,6 +196,8 @@ struct gm_acq {
     const void* last_metrics = nullptr;
     Timing tm;
     // composite transform size N = Q * plan->n (acq_composite.hip); Q == 1: the fused single-LDS-buffer kernels
+    float* d_split_scratch = nullptr;      // partial power planes of the correlation grid's tail split
+    uint32_t* d_split_counter = nullptr;   // arrival tickets, one per split item, zero between launches
     uint32_t Q = 1, Nb = 0;
     cf* d_comp_y = nullptr;                // [workers][D][M][N] products / inverse transforms
     size_t comp_y_elems = 0;
@@ -389,7 +391,7 @@ int gm_rfft_f32(size_t n, const float* in, gm_c32* out) {
 int gm_acq_destroy(gm_acq* a) {
     if (!a) return GM_OK;
     if (a->device >= 0) hipSetDevice(a->device);
-    hipFree(a->d_comp_y);
+    hipFree(a->d_comp_y); hipFree(a->d_split_scratch); hipFree(a->d_split_counter);
     hipFree(a->fine.d_chips); hipFree(a->fine.d_tw1); hipFree(a->fine.d_tw2); hipFree(a->fine.d_B); hipFree(a->fine.d_mean);
     hipFree(a->fine.d_rowmax); hipFree(a->fine.d_rowarg); hipFree(a->fine.d_sat_worker); hipFree(a->fine.d_sat_cp);
     hipFree(a->fine.d_peak_pow); hipFree(a->fine.d_peak_idx);
@@ -491,6 +493,11 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     HIPA(hipMalloc(&a->d_metrics, 3 * P * D * 4));
     HIPA(hipMemset(a->d_metrics, 0, 3 * P * D * 4));
     HIPA(hipMalloc(&a->d_worker_list, P * 4));
+    if (a->Q == 1 && pl->split_slab && M >= 2) {
+        HIPA(hipMalloc(&a->d_split_scratch, size_t(gm::GM_CORR_SPLIT_MAX_SLABS) * pl->split_slab * sizeof(float)));
+        HIPA(hipMalloc(&a->d_split_counter, gm::GM_CORR_SPLIT_MAX_ITEMS * sizeof(uint32_t)));
+        HIPA(hipMemset(a->d_split_counter, 0, gm::GM_CORR_SPLIT_MAX_ITEMS * sizeof(uint32_t)));
+    }
     HIPA(hipMemcpy(a->d_tables, tables.data(), D * N * 8, hipMemcpyHostToDevice));
     HIPA(hipMemcpy(a->d_table_freq, a->table_freq.data(), D * 4, hipMemcpyHostToDevice));
     HIPA(hipMemcpy(a->d_tw_fwd, twf.data(), twf.size() * 8, hipMemcpyHostToDevice));
@@ -557,7 +564,8 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     if (t) HIPC(hipEventRecord(ev[1], a->stream));
     if (a->Q == 1) {
         a->plan->corr(a->stream, a->d_spectra, a->d_code_fft, a->d_tw_inv, reinterpret_cast<float*>(met), met + PD,
-                      reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M));
+                      reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M),
+                      a->d_split_scratch, a->d_split_counter);
     } else if (a->n_workers) {
         const uint32_t n_dm = a->D * a->M;
         gm::launch_comp_mul(a->stream, a->d_spectra, a->d_code_fft, a->d_comp_y, a->d_worker_list, a->N, n_dm, a->n_workers);

@@ -29,6 +29,7 @@ struct PlanOps {
     int threads;       // workgroup size
     int tw_total;      // base-twiddle table entries (per direction)
     int lds_bytes;     // static LDS per workgroup of the correlation kernel
+    int split_slab;    // floats of one partial power plane of the tail split (0: this plan cannot split)
     void (*fill_tw)(cf* tw, bool inverse);
     // stage F: carrier mix (apply_doppler_shift, doppler_shift.rs:25-58) fused into the forward FFT
     // (do_acquisition.rs:177-182).  One workgroup per (doppler bin, ms block); shared by all PRNs.
@@ -38,7 +39,7 @@ struct PlanOps {
     // {max, first argmax, sum} per (worker, bin)  (do_acquisition.rs:184-202, 229-235)
     void (*corr)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                  uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
-                 int n_int);
+                 int n_int, float* split_scratch, uint32_t* split_counter);
     // AcquisitionWorker::new's replica spectrum (do_acquisition.rs:132-138)
     void (*code_fft)(hipStream_t, const int8_t* code_samples, const cf* tw_fwd, cf* code_fft, int n_codes);
     // FFT<T>::execute (fft.rs:21-25) on `batch` contiguous transforms
@@ -51,6 +52,11 @@ struct PlanOps {
 void launch_fine_mean(hipStream_t, const void* samples, int fmt, uint32_t n, float* d_mean);
 void launch_fine_final(hipStream_t, const float* rowmax, const uint32_t* rowarg, uint32_t n_rows, int n_sats,
                        float* peak_pow, uint32_t* peak_idx);
+// tail split of the correlation grid: per XCD about one resident round of slots (64) worth of parts, at most
+// GM_CORR_SPLIT_MAX_K parts per item; the scratch holds GM_CORR_SPLIT_MAX_SLABS partial planes, one ticket per item
+constexpr int GM_CORR_SPLIT_MAX_K = 5;
+constexpr int GM_CORR_SPLIT_MAX_SLABS = 8 * 80;
+constexpr int GM_CORR_SPLIT_MAX_ITEMS = 8 * 40;
 const PlanOps* find_plan(int n);
 int list_plans(uint32_t* sizes, int cap);
 

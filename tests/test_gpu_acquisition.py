@@ -144,7 +144,12 @@ def test_cfg2_full_i8(gpu, oracle):
     mask = (1 << 1) | (1 << 5) | (1 << 30)
     res_m = eng.search(xi8, prn_mask=mask)
     for i, r in enumerate(res_m):
-        assert r == (res[i] if (mask >> i) & 1 else None)
+        exp = res[i] if (mask >> i) & 1 else None
+        assert (r is None) == (exp is None)
+        if r:   # a different worker count changes the grid's tail split, i.e. the order in which the ten |.|^2 planes of
+            # some items are added: FFT tolerance on the power, everything else identical
+            assert {k: v for k, v in r.items() if k != "mag_relative"} == {k: v for k, v in exp.items() if k != "mag_relative"}
+            assert abs(r["mag_relative"] - exp["mag_relative"]) <= REL * exp["mag_relative"]
     eng.close()
 
 
