@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")
+    ap.add_argument("--three-dwells", action="store_true",
+                    help="also time three dwells in flight on three streams (informative; off by default because the "
+                         "co-executing launches would pollute the per-kernel averages of a rocprofv3 --stats run)")
     args = ap.parse_args()
 
     import torch
@@ -220,7 +223,7 @@ def main():
             out["fine_doppler"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ three dwells in flight (informative, never `value`)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.three_dwells:
         try:
             out["config"]["three_dwells_in_flight"] = pipelined_leg(torch, dev, sc, A, d_samples, P, D, N, M)
         except Exception as e:
