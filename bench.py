@@ -113,36 +113,60 @@ def main():
         d_gather = torch.zeros(world * 3 * P * D, dtype=torch.int32, device=dev)
         ids_all = np.tile(np.arange(1, 33, dtype=np.uint8), world)
 
-    def step():
-        eng.search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, d_metrics.data_ptr())
-        if native_comm:      # all-gather + regroup inside the library, on the handle's stream
-            native_comm.allgather_metrics(eng, d_gather.data_ptr(), d_metrics.data_ptr())
-            eng.decide_dev(d_gather.data_ptr(), n_prn=world * P, prn_ids=ids_all)
-            return None
-        if world > 1:
-            if debug_gloo:   # rehearsal only: exchange through host memory
-                h = [torch.empty(3 * P * D, dtype=torch.int32) for _ in range(world)]
-                dist.all_gather(h, d_metrics.cpu())
-                d_gather.copy_(torch.cat(h))
-            else:
-                dist.all_gather_into_tensor(d_gather, d_metrics)    # the path's one exchange step
-            g = d_gather.view(world, 3, P * D).permute(1, 0, 2).contiguous()   # -> [3][world*P][D]
-            eng.decide_dev(g.data_ptr(), n_prn=world * P, prn_ids=ids_all)
-            return g
-        eng.decide_dev(d_metrics.data_ptr())
-        return None
+    # N > 1: the exchange of dwell i (RCCL, on torch.distributed's own stream) overlaps the search of dwell i + 1 — the
+    # all-gather is issued asynchronously right behind search(i), and regroup + decision of dwell i are enqueued after
+    # search(i + 1).  Metrics / gather buffers alternate.  Every timed step is still issued AND finished inside the region.
+    if world > 1 and not native_comm:
+        met2 = [d_metrics, torch.zeros_like(d_metrics)]
+        gat2 = [d_gather, torch.zeros_like(d_gather)]
 
-    keep = None
-    for _ in range(args.warmup):
-        keep = step()
+    def issue(i):
+        k = i & 1
+        eng.search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, met2[k].data_ptr())
+        if debug_gloo:       # rehearsal only: exchange through host memory (synchronous)
+            h = [torch.empty(3 * P * D, dtype=torch.int32) for _ in range(world)]
+            dist.all_gather(h, met2[k].cpu())
+            gat2[k].copy_(torch.cat(h))
+            return None, k
+        return dist.all_gather_into_tensor(gat2[k], met2[k], async_op=True), k    # the path's one exchange step
+
+    def finish(pending):
+        work, k = pending
+        if work is not None:
+            work.wait()      # the current stream waits for the collective; the host does not
+        g = gat2[k].view(world, 3, P * D).permute(1, 0, 2).contiguous()            # -> [3][world*P][D]
+        eng.decide_dev(g.data_ptr(), n_prn=world * P, prn_ids=ids_all)
+        return g
+
+    def run(n_steps):
+        keep = None
+        if world > 1 and not native_comm:
+            prev = None
+            for i in range(n_steps):
+                cur = issue(i)
+                if prev is not None:
+                    keep = finish(prev)
+                prev = cur
+            if prev is not None:
+                keep = finish(prev)
+            return keep
+        for _ in range(n_steps):
+            eng.search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, d_metrics.data_ptr())
+            if native_comm:      # all-gather + regroup inside the library, on the handle's stream
+                native_comm.allgather_metrics(eng, d_gather.data_ptr(), d_metrics.data_ptr())
+                eng.decide_dev(d_gather.data_ptr(), n_prn=world * P, prn_ids=ids_all)
+            else:
+                eng.decide_dev(d_metrics.data_ptr())
+        return keep
+
+    keep = run(args.warmup)
     torch.cuda.synchronize()
     eng.enable_timing(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        keep = step()
+    keep = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,7 +205,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (DEBUG gloo rehearsal, one GPU shared)" if debug_gloo else ""),
         "config": {"workload": "GPS L1 C/A 32-PRN x +-5 kHz/250 Hz (41 bins) acquisition, 8 Msps complex int8, "
-                               "N=8000, 10 x 1 ms non-coherent, per GPU" + ("; all-gather of {max,argmax,sum}[P][D]" if world > 1 else ""),
+                               "N=8000, 10 x 1 ms non-coherent, per GPU" + ("; all-gather of {max,argmax,sum}[P][D] overlapped with the next dwell's search" if world > 1 else ""),
                    "prns_per_gpu": P, "doppler_bins": D, "fft_size": N, "integrations": M,
                    "cells_per_step": cells_per_step, "cell_integrations_per_s": value * M,
                    "parallelism": f"prn-shard x{world}", "exchange": ("gm_comm (RCCL via the C ABI)" if native_comm else "torch.distributed nccl" if world > 1 else None), "detections_ok": bool(detections_ok)},
