@@ -8,12 +8,12 @@
 //   forward   X[Q k2 + k1] = sum_n2 W_Nb^{n2 k2} * ( W_N^{n2 k1} * sum_n1 x[n1 Nb + n2] W_Q^{n1 k1} )
 //             comp_pre_kernel (the Q-point DFTs across the Q blocks + twiddle, the carrier mix fused in) ->
 //             the batched in-LDS transform of size Nb (fft_batch_kernel) -> spectrum in "decimated" order [k1][k2]
-//   product   elementwise in that order (the code spectra are produced by the same two steps)      comp_mul_kernel
+//   product   elementwise in that order (the code spectra are produced by the same two steps), fused into the loads of
 //   inverse   y[n1 Nb + n2] = sum_k1 W_Q^{-n1 k1} * ( W_N^{-n2 k1} * IFFT_Nb(Y[Q k2 + k1])[n2] )
-//             batched inverse transforms, then comp_post_kernel: twiddle + Q-point inverse DFTs, |y|^2 accumulated over
+//             the batched inverse transforms (comp_corr_fft_kernel in acq_kernels.hip), then comp_post_kernel: twiddle + Q-point inverse DFTs, |y|^2 accumulated over
 //             the integrations in registers, reduced to {max, first argmax, sum} per (worker, bin): no plane is stored.
 //
-// Intermediates travel through HBM / L2 (about six passes over P*D*M*N*8 bytes): a first, correct version of the
+// Intermediates travel through HBM / L2 (about four passes over P*D*M*N*8 bytes): a first, correct version of the
 // large-N case; the fused single-LDS-buffer kernels remain the path for N <= 16384.
 #include "gm_internal.h"
 
@@ -74,20 +74,6 @@ __global__ __launch_bounds__(CT) void comp_pre_kernel(const void* __restrict__ i
         const cf w = unit_root(uint32_t((uint64_t(n2) * k1) % N), N, false);
         out[(size_t(item) * Q + k1) * Nb + n2] = cmulf(acc, w);
     }
-}
-
-// Y[w][d][m][:] = X[d][m][:] * conj(C[worker][:])  (num-complex order, no FMA: do_acquisition.rs:184-186)
-__global__ __launch_bounds__(CT) void comp_mul_kernel(const cf* __restrict__ spectra, const cf* __restrict__ code_fft,
-                                                      cf* __restrict__ y, const uint32_t* __restrict__ worker_list,
-                                                      uint32_t N, uint32_t n_dm) {
-    const uint32_t k = blockIdx.x * CT + threadIdx.x;
-    if (k >= N) return;
-    const uint32_t dm = blockIdx.y, w = blockIdx.z;
-    const cf a = spectra[size_t(dm) * N + k];
-    const cf c = code_fft[size_t(worker_list[w]) * N + k];
-    // (a + bi)(c - di) = (ac + bd) + (bc - ad)i, written like num-complex's Mul on conj(): re = a*c - b*(-d), im = a*(-d) + b*c
-    const float nd = -c.y;
-    y[(size_t(w) * n_dm + dm) * N + k] = cf_make(a.x * c.x - a.y * nd, a.x * nd + a.y * c.x);
 }
 
 // inverse post-pass + power accumulation + reduction.  One workgroup per (w, d); z[w][d][m][k1][n2].
@@ -166,11 +152,6 @@ void launch_comp_pre(hipStream_t st, const void* in, int fmt, const cf* tables, 
                      uint32_t n_int, uint32_t n_items, const int8_t* code_samples) {
     GM_COMP_Q_SWITCH(Q, hipLaunchKernelGGL(comp_pre_kernel<QQ>, dim3((Nb + CT - 1) / CT, n_items), dim3(CT), 0, st, in, fmt,
                                            tables, out, Nb, n_int, code_samples))
-}
-void launch_comp_mul(hipStream_t st, const cf* spectra, const cf* code_fft, cf* y, const uint32_t* worker_list,
-                     uint32_t N, uint32_t n_dm, uint32_t n_workers) {
-    hipLaunchKernelGGL(comp_mul_kernel, dim3((N + CT - 1) / CT, n_dm, n_workers), dim3(CT), 0, st, spectra, code_fft, y,
-                       worker_list, N, n_dm);
 }
 void launch_comp_post(hipStream_t st, const cf* z, uint32_t Q, uint32_t Nb, uint32_t n_int, uint32_t n_bins,
                       const uint32_t* worker_list, uint32_t n_workers, float* mmax, uint32_t* margmax, float* msum) {

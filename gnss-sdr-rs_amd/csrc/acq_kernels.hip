@@ -356,6 +356,34 @@ __global__ __launch_bounds__(PL::T) void acq_code_fft_kernel(const int8_t* __res
                              [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
 }
 
+// ------------------------------------------------------------------------------------ composite sizes: product + inverse
+// One length-Nb inverse transform of the composite path (acq_composite.hip) with the x conj(code spectrum) product
+// (:184-186, num-complex order, no FMA) fused into its pass-0 loads.  grid = workers * n_dm * Q transforms;
+// spectra [n_dm][Q][Nb], code spectra [P][Q][Nb] (decimated order), z [w][n_dm][Q][Nb].
+template <class PL>
+__global__ __launch_bounds__(PL::T) void comp_corr_fft_kernel(const cf* __restrict__ spectra, const cf* __restrict__ code_fft,
+                                                             const cf* __restrict__ tw_inv, cf* __restrict__ z,
+                                                             const uint32_t* __restrict__ worker_list, uint32_t Q,
+                                                             uint32_t n_dm) {
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    load_twiddles<PL>(tw, tw_inv, tid);
+    const uint32_t k1 = blockIdx.x % Q, dm = (blockIdx.x / Q) % n_dm, w = blockIdx.x / (Q * n_dm);
+    const cf* x = spectra + (size_t(dm) * Q + k1) * PL::N;
+    const cf* c = code_fft + (size_t(worker_list[w]) * Q + k1) * PL::N;
+    cf* dst = z + size_t(blockIdx.x) * PL::N;
+    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    lds_transform<PL, true>(
+        [&](int it, int r) {
+            const int idx = (tid + it * PL::T) + r * NB0;
+            const cf a = x[idx], g = c[idx];
+            const float nd = -g.y;
+            return cf_make(a.x * g.x - a.y * nd, a.x * nd + a.y * g.x);
+        },
+        [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
+}
+
 // ------------------------------------------------------------------------------------ plain batched FFT
 template <class PL, bool INV>
 __global__ __launch_bounds__(PL::T) void fft_batch_kernel(cf* __restrict__ data, const cf* __restrict__ tw_g) {
@@ -560,6 +588,11 @@ template <class PL> struct Launch {
     static void code_fft(hipStream_t st, const int8_t* code_samples, const cf* tw_fwd, cf* out, int n_codes) {
         hipLaunchKernelGGL(acq_code_fft_kernel<PL>, dim3(n_codes), dim3(PL::T), 0, st, code_samples, tw_fwd, out);
     }
+    static void comp_corr_fft(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, cf* z,
+                              const uint32_t* worker_list, uint32_t Q, uint32_t n_dm, uint32_t n_workers) {
+        hipLaunchKernelGGL(comp_corr_fft_kernel<PL>, dim3(n_workers * n_dm * Q), dim3(PL::T), 0, st, spectra, code_fft, tw_inv,
+                           z, worker_list, Q, n_dm);
+    }
     static void fft_batch(hipStream_t st, cf* data, const cf* tw, int inverse, int batch) {
         if (inverse) hipLaunchKernelGGL((fft_batch_kernel<PL, true>), dim3(batch), dim3(PL::T), 0, st, data, tw);
         else hipLaunchKernelGGL((fft_batch_kernel<PL, false>), dim3(batch), dim3(PL::T), 0, st, data, tw);
@@ -573,7 +606,7 @@ template <class PL> struct Launch {
     }
     static constexpr PlanOps ops() {
         return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL), SPLIT_SLAB,
-                       &fill_tw, &mix_fft, &corr, &code_fft, &fft_batch,
+                       &fill_tw, &mix_fft, &corr, &code_fft, &fft_batch, &comp_corr_fft,
                        POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr};
     }
 };

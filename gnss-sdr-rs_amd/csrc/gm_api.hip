@@ -568,13 +568,8 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
                       a->d_split_scratch, a->d_split_counter);
     } else if (a->n_workers) {
         const uint32_t n_dm = a->D * a->M;
-        gm::launch_comp_mul(a->stream, a->d_spectra, a->d_code_fft, a->d_comp_y, a->d_worker_list, a->N, n_dm, a->n_workers);
-        // batches of at most 2^16 transforms per launch (grid.x)
-        const size_t total = size_t(a->n_workers) * n_dm * a->Q;
-        for (size_t b0 = 0; b0 < total; b0 += 32768) {
-            const size_t nb = total - b0 < 32768 ? total - b0 : 32768;
-            a->plan->fft_batch(a->stream, a->d_comp_y + b0 * a->Nb, a->d_tw_inv, 1, int(nb));
-        }
+        a->plan->comp_corr_fft(a->stream, a->d_spectra, a->d_code_fft, a->d_tw_inv, a->d_comp_y, a->d_worker_list, a->Q, n_dm,
+                               a->n_workers);
         gm::launch_comp_post(a->stream, a->d_comp_y, a->Q, a->Nb, a->M, a->D, a->d_worker_list, a->n_workers,
                              reinterpret_cast<float*>(met), met + PD, reinterpret_cast<float*>(met + 2 * PD));
     }

@@ -44,6 +44,9 @@ struct PlanOps {
     void (*code_fft)(hipStream_t, const int8_t* code_samples, const cf* tw_fwd, cf* code_fft, int n_codes);
     // FFT<T>::execute (fft.rs:21-25) on `batch` contiguous transforms
     void (*fft_batch)(hipStream_t, cf* data, const cf* tw, int inverse, int batch);
+    // composite sizes (N = Q * n): inverse transforms with the x conj(code spectrum) product fused into their loads
+    void (*comp_corr_fft)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, cf* z,
+                          const uint32_t* worker_list, uint32_t Q, uint32_t n_dm, uint32_t n_workers);
     // four-step long FFT passes (power-of-two plans only, else null): this plan as N1 (columns) / as N2 (rows)
     void (*fine_cols)(hipStream_t, const FineArgs&, int n_sats);
     void (*fine_rows)(hipStream_t, const FineArgs&, int n_sats);
@@ -67,8 +70,6 @@ void set_corr_stamps(long long* d_ptr);
 bool comp_q_supported(uint32_t Q);
 void launch_comp_pre(hipStream_t, const void* in, int fmt, const cf* tables, cf* out, uint32_t Q, uint32_t Nb,
                      uint32_t n_int, uint32_t n_items, const int8_t* code_samples);
-void launch_comp_mul(hipStream_t, const cf* spectra, const cf* code_fft, cf* y, const uint32_t* worker_list, uint32_t N,
-                     uint32_t n_dm, uint32_t n_workers);
 void launch_comp_post(hipStream_t, const cf* z, uint32_t Q, uint32_t Nb, uint32_t n_int, uint32_t n_bins,
                       const uint32_t* worker_list, uint32_t n_workers, float* mmax, uint32_t* margmax, float* msum);
 
