@@ -344,3 +344,24 @@ def test_search_ring_snapshot_wraps_and_empty_mask(gpu, oracle):
     assert none == [None, None]
     assert eng.search(x[:M * N], prn_mask=0) == [None, None]
     eng.close(); ring.close()
+
+
+@pytest.mark.parametrize("M,n_bins,plan", [(3, 21, 1024), (4, 19, 2048), (6, 17, 1024), (7, 20, 1024), (2, 25, 4000)])
+def test_grid_tail_split_parity(gpu, oracle, M, n_bins, plan):
+    """The correlation grid's tail split (last items of every XCD cut into k parts of M / k integrations, k = 3, 4, 3, 1
+    (7 is prime: no split), 2) against the oracle: 32 workers x 17..25 bins put more than 64 items on every XCD, so the
+    split is active; planes (max / first argmax / sum) and decisions as in every other acquisition parity test."""
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    t = oracle.ca_code_table()
+    N = plan
+    fs = float(N) * 1000.0
+    dop = (np.arange(n_bins, dtype=np.float32) - n_bins // 2) * np.float32(250.0)
+    sats = [dict(prn_row=3, cn0_dbhz=52.0, doppler_hz=610.0, code_start=N - 3),
+            dict(prn_row=17, cn0_dbhz=50.0, doppler_hz=-1130.0, code_start=5),
+            dict(prn_row=31, cn0_dbhz=49.0, doppler_hz=90.0, code_start=N // 2)]
+    x = synth.to_i8_iq(synth.make_scene(t, fs, 0.0, M * N, sats, config_id=100 + M))
+    prns = list(range(1, 33))
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=prns, n_integrations=M)
+    tables = _tables(oracle, 0.0, dop, fs, N)
+    assert _compare_search(eng, oracle, x, tables, prns, N, fs, M) >= 3
+    eng.close()
