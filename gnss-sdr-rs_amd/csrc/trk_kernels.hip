@@ -285,48 +285,103 @@ __global__ __launch_bounds__(256) void trk_correlate_kernel(TrkDevCfg cfg, const
 // The reference's scalar epilogue of one epoch: early_late_correlation's phase advances (:240-242,
 // :265-270) and, in DO_WORK mode, do_work + run_loop_filters (:183-210, :279-302).
 // v = the 2*ARMS correlator sums; n = samples of this epoch.
+// The scalar work between two epochs, in two independent halves so that two waves can run them side by side in the
+// persistent kernel (a lone wave issues about one instruction per five cycles whatever their dependencies: the section's
+// length is its instruction count).  Each half reads the OLD state and produces only the fields it owns:
+//   carrier half: prn, active, lost_counter, next_sample_index, carrier_{freq,phase,error,nco}, i/q_prompt, messages
+//   code half   : code_{phase,error,nco,rate}, num_samples_per_code
+// Both evaluate the lock test and the give-up rule (:183-210) from the same inputs, so they agree.
+struct CarrierHalf {
+    uint8_t prn, active, lst, lprn;
+    uint32_t lost_counter;
+    uint64_t next_sample_index;
+    float carrier_freq, carrier_phase, carrier_error, carrier_nco, i_prompt, q_prompt;
+};
+struct CodeHalf {
+    uint64_t num_samples_per_code;
+    float code_phase, code_error, code_nco, code_rate;
+};
+__device__ __forceinline__ bool trk_locked(const TrkDevCfg& cfg, float ip, float qp) { return ip * ip + qp * qp > cfg.lock_threshold; }
+__device__ __forceinline__ bool trk_give_up(const TrkDevCfg& cfg, const gm_trk_state& s, bool locked) {
+    return !locked && s.lost_counter + 1u >= cfg.max_lost_epochs;
+}
+
 template <int ARMS>
-__device__ __forceinline__ void epoch_epilogue(const TrkDevCfg& cfg, gm_trk_state& s, const float (&v)[2 * ARMS],
-                                               uint64_t n, int mode, uint8_t& lst, uint8_t& lprn) {
+__device__ __forceinline__ CarrierHalf carrier_half(const TrkDevCfg& cfg, const gm_trk_state& s, const float (&v)[2 * ARMS],
+                                                    uint64_t n, int mode) {
+    CarrierHalf o;
+    o.prn = s.prn; o.active = s.active; o.lst = 0; o.lprn = 0; o.lost_counter = s.lost_counter;
+    o.next_sample_index = s.next_sample_index;
+    o.carrier_freq = s.carrier_freq; o.carrier_error = s.carrier_error; o.carrier_nco = s.carrier_nco;
     const float nf = float(n);
-    const bool dk = cfg.div_fs_ok != 0;
     // carrier_phase = (carrier_phase + 2*PI*carrier_freq*(n as f32 / fs)) % (2*PI)      (:240-242)
-    s.carrier_phase = fmodf(s.carrier_phase + 2.0f * GM_PI_F * s.carrier_freq *
-                                (dk ? div_const(nf, cfg.fs, cfg.inv_fs) : __fdiv_rn(nf, cfg.fs)),
+    o.carrier_phase = fmodf(s.carrier_phase + 2.0f * GM_PI_F * s.carrier_freq *
+                                (cfg.div_fs_ok ? div_const(nf, cfg.fs, cfg.inv_fs) : __fdiv_rn(nf, cfg.fs)),
                             2.0f * GM_PI_F);
-    // code_phase = (code_phase + (code_rate/fs) * n as f32) % 1023.0                     (:265-267)
-    s.code_phase = fmodf(s.code_phase + (dk ? div_const(s.code_rate, cfg.fs, cfg.inv_fs) : __fdiv_rn(s.code_rate, cfg.fs)) * nf,
-                         cfg.code_len_f);
-    s.i_prompt = v[0]; s.q_prompt = v[1];
-    lst = 0; lprn = 0;
-    if (mode != TRK_MODE_DO_WORK) return;
-    const float power = v[0] * v[0] + v[1] * v[1];       // do_work (:183-210)
-    bool advance = true;
-    if (power > cfg.lock_threshold) {
-        s.lost_counter = 0;
-        // run_loop_filters (:279-302)
+    o.i_prompt = v[0]; o.q_prompt = v[1];
+    if (mode != TRK_MODE_DO_WORK) return o;
+    const bool locked = trk_locked(cfg, v[0], v[1]);     // do_work (:183-210)
+    if (locked) {
+        o.lost_counter = 0;
+        // run_loop_filters (:279-302), carrier part
         const float pll_err = __fdiv_rn(atanf(__fdiv_rn(v[1], v[0])), 2.0f * GM_PI_F);
-        s.carrier_nco = loop_filter_update(cfg.pll_dt_tau1, cfg.pll_tau2_tau1, pll_err, s.carrier_error);
-        s.carrier_error = pll_err;
-        s.carrier_freq += s.carrier_nco;
+        o.carrier_nco = loop_filter_update(cfg.pll_dt_tau1, cfg.pll_tau2_tau1, pll_err, s.carrier_error);
+        o.carrier_error = pll_err;
+        o.carrier_freq = s.carrier_freq + o.carrier_nco;
+    } else if (trk_give_up(cfg, s, locked)) {
+        // reset() first, so the message carries prn 0 (:199-201)
+        o.prn = 0; o.active = 0; o.lost_counter = 0; o.next_sample_index = 0;
+        o.carrier_freq = 0.f; o.carrier_phase = 0.f; o.carrier_error = 0.f; o.carrier_nco = 0.f;
+        o.i_prompt = 0.f; o.q_prompt = 0.f;
+        o.lst = 1; o.lprn = 0;
+        return o;
+    } else {
+        o.lost_counter = s.lost_counter + 1u;
+    }
+    o.next_sample_index = s.next_sample_index + n;       // (:192 / :203)
+    return o;
+}
+
+template <int ARMS>
+__device__ __forceinline__ CodeHalf code_half(const TrkDevCfg& cfg, const gm_trk_state& s, const float (&v)[2 * ARMS], uint64_t n,
+                                              uint64_t n_stored, int mode) {
+    CodeHalf o;
+    o.num_samples_per_code = n_stored; o.code_error = s.code_error; o.code_nco = s.code_nco; o.code_rate = s.code_rate;
+    const float nf = float(n);
+    // code_phase = (code_phase + (code_rate/fs) * n as f32) % 1023.0                     (:265-267)
+    o.code_phase = fmodf(s.code_phase + (cfg.div_fs_ok ? div_const(s.code_rate, cfg.fs, cfg.inv_fs) : __fdiv_rn(s.code_rate, cfg.fs)) * nf,
+                         cfg.code_len_f);
+    if (mode != TRK_MODE_DO_WORK) return o;
+    const bool locked = trk_locked(cfg, v[0], v[1]);
+    if (locked) {                                        // run_loop_filters (:279-302), code part
         const float pow_e = __fsqrt_rn(v[2] * v[2] + v[3] * v[3]);
         const float pow_l = __fsqrt_rn(v[4] * v[4] + v[5] * v[5]);
         const float dll_err = ((pow_e + pow_l) != 0.0f) ? __fdiv_rn(pow_e - pow_l, pow_e + pow_l) : 0.0f;
-        s.code_nco = loop_filter_update(cfg.dll_dt_tau1, cfg.dll_tau2_tau1, dll_err, s.code_error);
-        s.code_error = dll_err;
-        s.code_rate += s.code_nco;
-    } else {
-        s.lost_counter += 1;
-        if (s.lost_counter >= cfg.max_lost_epochs) {
-            reset_state(s);                          // reset() first ...
-            lst = 1; lprn = s.prn;                   // ... so the message carries prn 0 (:199-201)
-            advance = false;
-        }
+        o.code_nco = loop_filter_update(cfg.dll_dt_tau1, cfg.dll_tau2_tau1, dll_err, s.code_error);
+        o.code_error = dll_err;
+        o.code_rate = s.code_rate + o.code_nco;
+    } else if (trk_give_up(cfg, s, locked)) {            // reset(): num_samples_per_code keeps the stored length
+        o.code_phase = 0.f; o.code_error = 0.f; o.code_nco = 0.f; o.code_rate = 0.f;
+        return o;
     }
-    if (advance) {
-        s.next_sample_index += n;                    // (:192 / :203)
-        s.num_samples_per_code = samples_per_code(cfg, s.code_rate);
-    }
+    o.num_samples_per_code = samples_per_code(cfg, o.code_rate);
+    return o;
+}
+
+// Per-epoch scalar state update of one channel: phase advances of early_late_correlation (:240-242, :265-270) and, in
+// DO_WORK mode, do_work + run_loop_filters (:183-210, :279-302).  v = the 2*ARMS correlator sums; n = samples of this
+// epoch; s.num_samples_per_code already holds the length update() stored (:166).
+template <int ARMS>
+__device__ __forceinline__ void epoch_epilogue(const TrkDevCfg& cfg, gm_trk_state& s, const float (&v)[2 * ARMS],
+                                               uint64_t n, int mode, uint8_t& lst, uint8_t& lprn) {
+    const CarrierHalf a = carrier_half<ARMS>(cfg, s, v, n, mode);
+    const CodeHalf b = code_half<ARMS>(cfg, s, v, n, s.num_samples_per_code, mode);
+    s.prn = a.prn; s.active = a.active; s.lost_counter = a.lost_counter; s.next_sample_index = a.next_sample_index;
+    s.carrier_freq = a.carrier_freq; s.carrier_phase = a.carrier_phase; s.carrier_error = a.carrier_error;
+    s.carrier_nco = a.carrier_nco; s.i_prompt = a.i_prompt; s.q_prompt = a.q_prompt;
+    s.num_samples_per_code = b.num_samples_per_code; s.code_phase = b.code_phase; s.code_error = b.code_error;
+    s.code_nco = b.code_nco; s.code_rate = b.code_rate;
+    lst = a.lst; lprn = a.lprn;
 }
 
 template <int ARMS> __device__ __forceinline__ gm_trk_out make_out(const float (&v)[2 * ARMS]) {
