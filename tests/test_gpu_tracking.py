@@ -277,3 +277,45 @@ def test_more_epochs_than_one_persistent_launch(gpu, oracle):
     assert lost[19, 0] and lost.sum() == 1
     assert not mgr.channels[0].is_active()
     mgr.close(); ring.close()
+
+
+@pytest.mark.parametrize("fs,f_if", [(2_048_000.0, 0.0), (8.0e6, 0.0), (16_367_600.0, 4_130_400.0), (25.0e6, 0.0), (5.0e6, 1.25e6)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_persistent_kernel_sweep_over_sample_rates(gpu, oracle, fs, f_if, mode):
+    """The persistent kernel's exact shortcuts (constant-divisor division by fs, one-select chip indices, branch-free
+    code-phase wrap, host-side loop-filter quotients) against the oracle's plain IEEE arithmetic, at five sample rates /
+    IFs and both code-index modes: 10 free-running epochs of 3 channels, I/Q within 5e-5 of the prompt envelope at every
+    epoch (the loop feeds back), bookkeeping exact."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    n = int(round(fs / 1000.0))
+    t = oracle.ca_code_table()
+    prns = [4, 15, 29]
+    rows = [p if mode == 0 else p - 1 for p in prns]          # FAITHFUL correlates PRN p against row p: put that code in the air
+    sc = synth.tracking_scene(t, fs, f_if, prns, 12, config_id=int(fs) % 97, cn0=50.0, code_rows=rows)
+    x = synth.to_c32(sc["x"])
+    ring, oring = T.MulticastRingBuffer(1 << 19), oracle.MulticastRingBuffer(1 << 19)
+    ring.write_samples(x[:11 * n])
+    oring.write_samples(x[:11 * n])
+    mgr = T.TrackingManager(fs, n_channels=3, code_index_mode=mode)
+    ocs = []
+    for i, s in enumerate(sc["sats"]):
+        r = _acq_result(s["prn"], f_if + s["doppler_hz"] + 20.0, 0.0, fs, idx=s["code_start"])
+        mgr.channels[i].start(r)
+        oc = oracle.TrackingChannel(i, fs, code_index_mode=mode)
+        oc.start(r)
+        ocs.append(oc)
+    outs, proc, lost, done = mgr.update_all(ring, 12)
+    assert done == 10 and not lost.any()
+    for i, oc in enumerate(ocs):
+        for ep in range(12):
+            rc, exp, msg = oc.update(oring)
+            assert (rc != 0) == bool(proc[ep, i]), (i, ep)
+            if rc:
+                env = float(np.hypot(exp[0], exp[1]))
+                assert np.max(np.abs(outs[ep, i] - exp)) <= 5 * REL * env, (fs, i, ep)
+        s = mgr.channels[i].state
+        assert s.next_sample_index == oc.c.next_sample_index and s.num_samples_per_code == oc.c.num_samples_per_code
+        assert s.lost_counter == oc.c.lost_counter
+        assert s.carrier_freq == pytest.approx(oc.c.carrier_freq, abs=2e-2)
+        assert s.code_rate == pytest.approx(oc.c.code_rate, abs=2e-2)
+    mgr.close(); ring.close()
