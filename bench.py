@@ -487,6 +487,21 @@ def frontend_leg(torch, dev, with_cpu):
     fe.close()
     res = {"workload": "DC removal + LUT NCO down-mix, 4 Mi int8 IQ samples -> c32, one stream, bit-exact",
            "msps": n / dt / 1e6, "ms": dt * 1e3}
+    # 64 independent streams (antennas / bands) in one launch, one workgroup per stream (gm_frontend_process_dev_batch)
+    S, nb = 64, 1 << 20
+    fes = [F.DigitalFrontend(4.1304e6 + 1000.0 * i, 16.3676e6, 16.3676e6) for i in range(S)]
+    outs = torch.empty((S, 2 * nb), dtype=torch.float32, device=dev)
+    ins = [d_in.data_ptr()] * S
+    ops = [outs[i].data_ptr() for i in range(S)]
+    F.process_dev_batch(fes, ins, _lib.FMT_I8_IQ, ops, nb, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    F.process_dev_batch(fes, ins, _lib.FMT_I8_IQ, ops, nb, st)
+    torch.cuda.synchronize()
+    dtb = time.perf_counter() - t0
+    for f_ in fes:
+        f_.close()
+    res["aggregate_msps_64_streams"] = S * nb / dtb / 1e6
     if with_cpu:
         from oracle import oracle as O
         O.build(native=True)

@@ -129,6 +129,7 @@ SIGNATURES = {
     "gm_frontend_set_state": (_i, [_vp, _f, _vp, _vp]),
     "gm_frontend_process_block": (_i, [_vp, _vp, _sz]),
     "gm_frontend_process_dev": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
+    "gm_frontend_process_dev_batch": (_i, [_vp, _u32, _vp, _i, _vp, _sz, _vp]),
     "gm_frontend_synchronize": (_i, [_vp]),
     "gm_frontend_write_ring": (_i, [_vp, _vp, _vp, _sz, _i]),
     "gm_trk_create": (_i, [C.POINTER(TrkCfg), C.POINTER(_vp)]),

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(FE_T) void frontend_kernel(FrontendArgs a) {
     __shared__ float s_ph[FE_SEG];                         // phase_accumulator before each sample (x s_scale)
     __shared__ float s_scale;
     const int tid = threadIdx.x;
-    const FrontendArgs::Stream st = a.streams[blockIdx.x];
+    const FrontendArgs::Stream st = a.streams ? a.streams[blockIdx.x] : a.one;
     for (int i = tid; i < LUT; i += FE_T) { s_lre[i] = a.lut[i]; s_lim[i] = a.lut[LUT + i]; }
 
     const size_t n8 = st.n_samples & ~size_t(7);          // chunks_exact_mut(16 floats) (:35)
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(FE_T) void frontend_kernel(FrontendArgs a) {
     const int dl = tid - 64;
     if (nco_lane) phase = st.state->phase_accumulator;
     if (dc_lane) bias = dl < 8 ? st.state->bias_re[dl] : st.state->bias_im[dl - 8];
-    const float step = a.phase_step, alpha = a.alpha, con = a.con;
-    const bool fast = a.fast_fmod != 0;
+    const float step = st.phase_step, alpha = a.alpha, con = a.con;
+    const bool fast = st.fast_fmod != 0;
 
     for (size_t seg = 0; seg < n8; seg += FE_SEG) {
         const int L = int(n8 - seg < size_t(FE_SEG) ? n8 - seg : size_t(FE_SEG));

@@ -1440,14 +1440,25 @@ struct gm_frontend {
     void* d_io = nullptr;                   // scratch for the host-buffer entry
     size_t io_cap = 0;
     void* d_raw[gm_ring::SLOTS] = {nullptr, nullptr, nullptr, nullptr};   // raw-format landing zones of the ring writer
+    gm::FrontendArgs::Stream* d_batch = nullptr;   // stream descriptors of gm_frontend_process_dev_batch
+    uint32_t batch_cap = 0;
 };
+
+static gm::FrontendArgs::Stream frontend_stream(gm_frontend* f, const void* d_in, void* d_out, uint64_t out_start,
+                                                 uint64_t out_mask, size_t n) {
+    gm::FrontendArgs::Stream s{};
+    s.in = d_in; s.out = d_out; s.out_start = out_start; s.out_mask = out_mask; s.n_samples = n; s.state = f->d_state;
+    s.phase_step = f->phase_step;
+    s.fast_fmod = fabsf(f->phase_step) < 2048.0f ? 1 : 0;     // false for NaN too
+    return s;
+}
 
 static int frontend_launch(gm_frontend* f, hipStream_t st, const void* d_in, int fmt, void* d_out, uint64_t out_start,
                            uint64_t out_mask, size_t n) {
     gm::FrontendArgs a{};
-    a.streams[0] = {d_in, d_out, out_start, out_mask, n, f->d_state};
-    a.lut = f->d_lut; a.phase_step = f->phase_step; a.alpha = f->alpha; a.con = f->con;
-    a.fast_fmod = fabsf(f->phase_step) < 2048.0f ? 1 : 0;     // false for NaN too
+    a.streams = nullptr;
+    a.one = frontend_stream(f, d_in, d_out, out_start, out_mask, n);
+    a.lut = f->d_lut; a.alpha = f->alpha; a.con = f->con;
     gm::launch_frontend(st, a, 1, fmt);
     HIPC(hipGetLastError());
     return GM_OK;
@@ -1484,7 +1495,7 @@ int gm_frontend_destroy(gm_frontend* f) {
     if (!f) return GM_OK;
     hipSetDevice(f->device);
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
-    hipFree(f->d_lut); hipFree(f->d_state); hipFree(f->d_io);
+    hipFree(f->d_lut); hipFree(f->d_state); hipFree(f->d_io); hipFree(f->d_batch);
     for (void* p : f->d_raw) hipFree(p);
     delete f;
     return GM_OK;
@@ -1546,6 +1557,38 @@ int gm_frontend_process_dev(gm_frontend* f, const void* d_in, int fmt, void* d_o
     if (fmt != GM_FMT_C32 && fmt != GM_FMT_I8_IQ) return set_err(GM_ERR_INVALID_ARG, "front-end input is c32 or int8 IQ");
     if (int rc = ensure_device(f->device)) return rc;
     return frontend_launch(f, stream ? static_cast<hipStream_t>(stream) : f->stream, d_in, fmt, d_out, 0, ~0ull, n_samples);
+}
+
+// Many independent streams (antennas, bands) in ONE launch: one workgroup per stream, each with its own front-end state
+// and NCO step.  Descriptors travel in a small device array owned by fes[0]; asynchronous on `stream` (NULL: fes[0]'s).
+int gm_frontend_process_dev_batch(gm_frontend* const* fes, uint32_t n_streams, const void* const* d_in, int fmt,
+                                  void* const* d_out, size_t n_samples, void* stream) {
+    if (!fes || !d_in || !d_out || !n_streams) return set_err(GM_ERR_INVALID_ARG, "null pointer / no streams");
+    if (fmt != GM_FMT_C32 && fmt != GM_FMT_I8_IQ) return set_err(GM_ERR_INVALID_ARG, "front-end input is c32 or int8 IQ");
+    gm_frontend* f0 = fes[0];
+    if (!f0) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (int rc = ensure_device(f0->device)) return rc;
+    std::vector<gm::FrontendArgs::Stream> h(n_streams);
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (!fes[i] || !d_in[i] || !d_out[i] || fes[i]->device != f0->device) return set_err(GM_ERR_INVALID_ARG, "bad stream entry");
+        for (uint32_t j = 0; j < i; ++j)
+            if (fes[j] == fes[i]) return set_err(GM_ERR_INVALID_ARG, "a front-end may appear once per batch (its state is sequential)");
+        h[i] = frontend_stream(fes[i], d_in[i], d_out[i], 0, ~0ull, n_samples);
+    }
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : f0->stream;
+    if (f0->batch_cap < n_streams) {
+        HIPC(hipStreamSynchronize(st));
+        hipFree(f0->d_batch); f0->d_batch = nullptr; f0->batch_cap = 0;
+        HIPC(hipMalloc(&f0->d_batch, n_streams * sizeof(gm::FrontendArgs::Stream)));
+        f0->batch_cap = n_streams;
+    }
+    HIPC(hipMemcpyAsync(f0->d_batch, h.data(), n_streams * sizeof(gm::FrontendArgs::Stream), hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));     // the descriptors were read from pageable host memory
+    gm::FrontendArgs a{};
+    a.streams = f0->d_batch; a.lut = f0->d_lut; a.alpha = f0->alpha; a.con = f0->con;
+    gm::launch_frontend(st, a, int(n_streams), fmt);
+    HIPC(hipGetLastError());
+    return GM_OK;
 }
 
 int gm_frontend_synchronize(gm_frontend* f) {

@@ -150,11 +150,13 @@ struct FrontendArgs {
         uint64_t out_start, out_mask;
         size_t n_samples;
         FeState* state;
+        float phase_step;          // NcoLut.phase_step of this stream's front-end
+        int fast_fmod;             // |phase_step| < 2048: fmodf reduces to one exact conditional add/subtract
     };
-    Stream streams[8];
+    const Stream* streams;         // device array, one entry (and one workgroup) per stream
+    Stream one;                    // used when streams == nullptr (single-stream launches need no upload)
     const float* lut;              // [2][2048]: lut_re, lut_im (nco_lut.rs:28-32), built on the host with glibc cosf/sinf
-    float phase_step, alpha, con;
-    int fast_fmod;                 // |phase_step| < 2048: fmodf reduces to one exact conditional add/subtract
+    float alpha, con;
 };
 void launch_frontend(hipStream_t, const FrontendArgs&, int n_streams, int fmt);
 

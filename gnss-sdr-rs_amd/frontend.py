@@ -64,3 +64,13 @@ class DigitalFrontend:
             s = np.ascontiguousarray(s, np.complex64)
             n, fmt = s.size, FMT_C32
         check(lib().gm_frontend_write_ring(self._h, ring._h, _p(s), n, fmt), "gm_frontend_write_ring")
+
+
+def process_dev_batch(frontends, d_in_ptrs, fmt, d_out_ptrs, n_samples, stream=None):
+    """n independent streams in one launch (gm_frontend_process_dev_batch): frontends[i]: d_in_ptrs[i] -> d_out_ptrs[i]."""
+    n = len(frontends)
+    H = (C.c_void_p * n)(*[f._h for f in frontends])
+    I = (C.c_void_p * n)(*d_in_ptrs)
+    O = (C.c_void_p * n)(*d_out_ptrs)
+    check(lib().gm_frontend_process_dev_batch(C.cast(H, C.c_void_p), n, C.cast(I, C.c_void_p), fmt, C.cast(O, C.c_void_p),
+                                              n_samples, stream), "gm_frontend_process_dev_batch")

@@ -254,6 +254,11 @@ int gm_frontend_process_block(gm_frontend *f, float *raw_floats, size_t n_floats
 /* device-resident form: d_in (GM_FMT_C32 or GM_FMT_I8_IQ) -> d_out (c32; may alias d_in for c32), asynchronous on
  * `stream` (a hipStream_t, NULL -> the handle's own stream; gm_frontend_synchronize waits for that one) */
 int gm_frontend_process_dev(gm_frontend *f, const void *d_in, int fmt, void *d_out, size_t n_samples, void *stream);
+/* n_streams independent streams (antennas, bands) in one launch, one workgroup each: fes[i] processes d_in[i] -> d_out[i]
+ * (n_samples each); every front-end keeps its own state and NCO step; a handle may appear once per call.
+ * Asynchronous on `stream` (NULL -> fes[0]'s own). */
+int gm_frontend_process_dev_batch(gm_frontend *const *fes, uint32_t n_streams, const void *const *d_in, int fmt,
+                                  void *const *d_out, size_t n_samples, void *stream);
 int gm_frontend_synchronize(gm_frontend *f);
 /* rf_thread's block step (src/rf/rf_thread.rs:43-48: process_block, then shared_ring_buffer.write_samples) fused and
  * non-blocking: host samples (c32, or int8 IQ: 2 B/sample over PCIe, converted on the GPU) -> pinned staging -> front-end

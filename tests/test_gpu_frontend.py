@@ -81,3 +81,29 @@ def test_write_ring_equals_process_then_write(gpu, oracle):
         _same_state(fe, ofe)
         fe.close()
         ring.close()
+
+
+def test_batch_of_streams_equals_single_stream_calls(gpu, oracle, hipbuf):
+    """gm_frontend_process_dev_batch: 5 front-ends with different IFs in one launch, two consecutive calls (state
+    continuity) — every stream bit-equal to the oracle run on its own."""
+    from gnss_sdr_rs_amd import frontend as F, _lib
+    rng = np.random.default_rng(12)
+    n = 6000
+    ifs = [0.0, 1.0e6, 2.5e6, -0.4e6, 3.999e6]
+    fes = [F.DigitalFrontend(f, 8.0e6, 8.0e6) for f in ifs]
+    ofes = [oracle.DigitalFrontend(f, 8.0e6, 8.0e6) for f in ifs]
+    for call in range(2):
+        xs = [rng.integers(-127, 128, 2 * n).astype(np.int8) for _ in ifs]
+        d_in = [hipbuf.upload(x) for x in xs]
+        d_out = [hipbuf.alloc(n * 8) for _ in ifs]
+        F.process_dev_batch(fes, d_in, _lib.FMT_I8_IQ, d_out, n)
+        fes[0].synchronize()
+        for i in range(len(ifs)):
+            want = ofes[i].process_block(xs[i].astype(np.float32))
+            got = hipbuf.download(d_out[i], n * 8, np.float32)
+            assert (_bits(got) == _bits(want)).all(), (call, i)
+            _same_state(fes[i], ofes[i])
+    with pytest.raises(_lib.GmError):
+        F.process_dev_batch([fes[0], fes[0]], d_in[:2], _lib.FMT_I8_IQ, d_out[:2], n)
+    for f in fes:
+        f.close()
