@@ -173,7 +173,8 @@ def main():
 
     keep = run(args.warmup)
     torch.cuda.synchronize()
-    eng.enable_timing(True)
+    # every 5th dwell carries HIP events (four records cost ~8 us of stream time per dwell when all are timed)
+    eng.enable_timing(0 if os.environ.get("GM_BENCH_NO_EVENTS") == "1" else 5)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -184,7 +185,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    tsum = eng.timing_summary()
+    try:
+        tsum = eng.timing_summary()
+    except Exception:      # GM_BENCH_NO_EVENTS=1 (diagnostic): no per-kernel timing
+        tsum = {"avg_corr_ms": 0.0, "avg_mix_fft_ms": 0.0, "launches": 0}
     eng.enable_timing(False)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)

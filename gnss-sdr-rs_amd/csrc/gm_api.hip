@@ -106,6 +106,9 @@ struct Timing {
     static constexpr int CAP = 512;
     std::vector<hipEvent_t> ev;   // CAP * 4 events, created on first enable
     bool on = false;
+    int stride = 1;               // record every stride-th search (an event record costs ~2 us of stream time)
+    int calls = 0;                // searches since enable
+    bool this_call = false;       // the search in flight is a recorded one (its decision event follows)
     int count = 0;                // calls recorded since enable (only the last CAP are kept)
     bool decide_valid = false;
 };
@@ -543,7 +546,8 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     if (int rc = ensure_device(a->device)) return rc;
     uint32_t* met = d_metrics ? static_cast<uint32_t*>(d_metrics) : a->d_metrics;
     const size_t PD = size_t(a->P) * a->D;
-    const bool t = a->tm.on;
+    const bool t = a->tm.on && (a->tm.calls++ % a->tm.stride == 0);
+    a->tm.this_call = t;
     hipEvent_t* ev = t ? &a->tm.ev[size_t(a->tm.count % Timing::CAP) * 4] : nullptr;
     if (a->Q > 1 && a->n_workers) {    // grow the product buffer before anything is enqueued
         const size_t need = size_t(a->n_workers) * a->D * a->M * a->N;
@@ -606,7 +610,8 @@ int gm_acq_decide_dev(gm_acq* a, const void* d_metrics, uint32_t n_prn, const ui
     da.local_tail = local_tail;
     da.results = a->d_results; da.found = a->d_found;
     gm::launch_decide(a->stream, da);
-    if (a->tm.on && a->tm.count > 0) {
+    if (a->tm.on && a->tm.this_call && a->tm.count > 0) {
+        a->tm.this_call = false;
         HIPC(hipEventRecord(a->tm.ev[size_t((a->tm.count - 1) % Timing::CAP) * 4 + 3], a->stream));
         a->tm.decide_valid = true;
     }
@@ -820,6 +825,9 @@ int gm_acq_enable_timing(gm_acq* a, int on) {
         for (auto& e : a->tm.ev) HIPC(hipEventCreate(&e));
     }
     a->tm.on = on != 0;
+    a->tm.stride = on > 1 ? on : 1;      // on = k > 1: every k-th search is timed
+    a->tm.calls = 0;
+    a->tm.this_call = false;
     a->tm.count = 0;
     a->tm.decide_valid = false;
     return GM_OK;

@@ -207,7 +207,8 @@ int gm_acq_code_fft(gm_acq *a, uint32_t worker, gm_c32 *out);
 /* The table list in use: [n_bins][fft_size] and [n_bins] (either may be NULL). */
 int gm_acq_tables(gm_acq *a, gm_c32 *tables, float *table_freq);
 /* Kernel timing of the last gm_acq_search*_dev call, measured with HIP events on the handle's
- * stream: ms_mix_fft (stage F), ms_corr (stage C, the dominant kernel), ms_decide.  Enable first. */
+ * stream: ms_mix_fft (stage F), ms_corr (stage C, the dominant kernel), ms_decide.  Enable first: on = 1 times every
+ * search, on = k > 1 every k-th (an event record costs about 2 us of stream time; four per timed search), 0 disables. */
 int gm_acq_enable_timing(gm_acq *a, int on);
 int gm_acq_last_timing(gm_acq *a, float *ms_mix_fft, float *ms_corr, float *ms_decide);
 /* Averages over every gm_acq_search_dev call since timing was enabled (the last 512 at most). */
