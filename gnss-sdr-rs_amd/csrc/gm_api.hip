@@ -1089,7 +1089,7 @@ struct gm_trk {
     // persistent multi-epoch kernel: G workgroups per channel, granule exchange buffer, launch counter
     int G = 1;
     unsigned long long* d_xchg = nullptr;
-    int* d_error = nullptr;
+    int* d_error = nullptr;             // host-pinned, device-visible: written by the kernel only when an exchange times out
     uint32_t launch_seq = 0;
     long long* d_stamps = nullptr; uint32_t stamps_cap = 0;   // diagnostic phase stamps (gm_trk_debug_stamps)
 };
@@ -1121,7 +1121,7 @@ int gm_trk_destroy(gm_trk* t) {
     if (t->device >= 0) hipSetDevice(t->device);
     hipFree(t->d_codes); hipFree(t->d_states); hipFree(t->d_partials); hipFree(t->d_ready); hipFree(t->d_scratch);
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
-    hipFree(t->d_xchg); hipFree(t->d_error); hipFree(t->d_stamps);
+    hipFree(t->d_xchg); if (t->d_error) hipHostFree(t->d_error); hipFree(t->d_stamps);
     if (t->ev0) hipEventDestroy(t->ev0);
     if (t->ev1) hipEventDestroy(t->ev1);
     if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
@@ -1210,8 +1210,8 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
         const size_t xb = size_t(2) * t->C * g * nv * sizeof(unsigned long long);
         HIPT(hipMalloc(&t->d_xchg, xb));
         HIPT(hipMemset(t->d_xchg, 0, xb));
-        HIPT(hipMalloc(&t->d_error, sizeof(int)));
-        HIPT(hipMemset(t->d_error, 0, sizeof(int)));
+        HIPT(hipHostMalloc(reinterpret_cast<void**>(&t->d_error), sizeof(int), hipHostMallocDefault));   // read on the host after a stream sync: no copy
+        *t->d_error = 0;
     }
     if (int rc = trk_reserve_epochs(t, 1)) return fail(rc);
 #undef HIPT
@@ -1386,10 +1386,9 @@ int gm_trk_update_all(gm_trk* t, gm_ring* ring, uint32_t max_epochs, gm_trk_out*
 }
 
 static int trk_check_error(gm_trk* t) {
-    int err = 0;
-    HIPC(hipMemcpy(&err, t->d_error, sizeof(int), hipMemcpyDeviceToHost));
+    const int err = *static_cast<volatile int*>(t->d_error);      // the stream has been synchronised by the caller
     if (err) {
-        HIPC(hipMemset(t->d_error, 0, sizeof(int)));
+        *t->d_error = 0;
         return set_err(GM_ERR_HIP, "tracking: inter-workgroup exchange timed out (workgroups of a channel not co-resident?)");
     }
     return GM_OK;
