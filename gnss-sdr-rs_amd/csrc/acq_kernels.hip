@@ -435,27 +435,52 @@ __global__ __launch_bounds__(PL::T) void fine_cols_kernel(FineArgs a) {     // g
         lds, tw, tid);
 }
 
+// RT adjacent rows per workgroup: B is [n2][k1], so a row's elements are N1*8 bytes apart; one lane's loads for RT rows are
+// RT*8 contiguous bytes (a whole 64-byte line at RT = 8) instead of eight strided 8-byte reads of eight workgroups.
+template <class PL> struct FineRows {
+    static constexpr int PER = PL::IT0 * PL::R0;                       // pass-0 elements a lane owns
+    static constexpr int RT = PL::T >= 1024 ? 1 : (PER <= 8 ? 8 : (PER <= 16 ? 4 : (PER <= 32 ? 2 : 1)));   // 1024 lanes: 128-VGPR cap
+};
+
 template <class PL>
-__global__ __launch_bounds__(PL::T) void fine_rows_kernel(FineArgs a) {     // grid (N1, S); PL::N == N2
+__global__ __launch_bounds__(PL::T) void fine_rows_kernel(FineArgs a) {     // grid (N1 / RT, S); PL::N == N2
+    constexpr int RT = FineRows<PL>::RT;
     __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
     __shared__ float s_p[PL::T / 64];
     __shared__ uint32_t s_k[PL::T / 64];
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
-    const uint32_t k1 = blockIdx.x, sat = blockIdx.y;
+    const uint32_t k1_0 = blockIdx.x * RT, sat = blockIdx.y;
     load_twiddles<PL>(tw, a.tw2, tid);
-    const cf* src = a.B + size_t(sat) * a.N2 * a.N1 + k1;
+    const cf* src = a.B + size_t(sat) * a.N2 * a.N1 + k1_0;
     constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    // the RT rows' pass-0 inputs of this lane, loaded up front (static indices: registers)
+    cf tile[RT][PL::IT0][PL::R0];
+#pragma unroll
+    for (int it = 0; it < PL::IT0; ++it) {
+        const int b = tid + it * PL::T;
+        if (b < NB0) {
+#pragma unroll
+            for (int r = 0; r < PL::R0; ++r) {
+                const cf* p = src + size_t(b + r * NB0) * a.N1;
+#pragma unroll
+                for (int j = 0; j < RT; ++j) tile[j][it][r] = p[j];
+            }
+        }
+    }
     float best = -1.0f;
     uint32_t bestk = 0xFFFFFFFFu;
-    lds_transform<PL, false>(
-        [&](int it, int r) { return src[size_t((tid + it * PL::T) + r * NB0) * a.N1]; },
-        [&](int it, int r, cf v) {
-            const uint32_t k = k1 + a.N1 * uint32_t((tid + it * PL::T) + r * NBL);
-            const float p = __builtin_fmaf(v.x, v.x, v.y * v.y);
-            if (p > best || (p == best && k < bestk)) { best = p; bestk = k; }   // first index of the maximum (:279-282)
-        },
-        lds, tw, tid);
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+        lds_transform<PL, false>(
+            [&](int it, int r) { return tile[j][it][r]; },
+            [&](int it, int r, cf v) {
+                const uint32_t k = (k1_0 + j) + a.N1 * uint32_t((tid + it * PL::T) + r * NBL);
+                const float p = __builtin_fmaf(v.x, v.x, v.y * v.y);
+                if (p > best || (p == best && k < bestk)) { best = p; bestk = k; }   // first index of the maximum (:279-282)
+            },
+            lds, tw, tid);
+    }
     for (int off = 32; off > 0; off >>= 1) {
         const float op = __shfl_xor(best, off);
         const uint32_t ok = __shfl_xor(bestk, off);
@@ -466,8 +491,8 @@ __global__ __launch_bounds__(PL::T) void fine_rows_kernel(FineArgs a) {     // g
     if (tid == 0) {
         for (int w = 1; w < PL::T / 64; ++w)
             if (s_p[w] > best || (s_p[w] == best && s_k[w] < bestk)) { best = s_p[w]; bestk = s_k[w]; }
-        a.rowmax[size_t(sat) * a.N1 + k1] = best;
-        a.rowarg[size_t(sat) * a.N1 + k1] = bestk;
+        a.rowmax[size_t(sat) * (a.N1 / RT) + blockIdx.x] = best;
+        a.rowarg[size_t(sat) * (a.N1 / RT) + blockIdx.x] = bestk;
     }
 }
 
@@ -602,12 +627,12 @@ template <class PL> struct Launch {
         if constexpr (POW2) hipLaunchKernelGGL(fine_cols_kernel<PL>, dim3(a.N2, n_sats), dim3(PL::T), 0, st, a);
     }
     static void fine_rows(hipStream_t st, const FineArgs& a, int n_sats) {
-        if constexpr (POW2) hipLaunchKernelGGL(fine_rows_kernel<PL>, dim3(a.N1, n_sats), dim3(PL::T), 0, st, a);
+        if constexpr (POW2) hipLaunchKernelGGL(fine_rows_kernel<PL>, dim3(a.N1 / FineRows<PL>::RT, n_sats), dim3(PL::T), 0, st, a);
     }
     static constexpr PlanOps ops() {
         return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL), SPLIT_SLAB,
                        &fill_tw, &mix_fft, &corr, &code_fft, &fft_batch, &comp_corr_fft,
-                       POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr};
+                       POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr, FineRows<PL>::RT};
     }
 };
 

@@ -754,7 +754,7 @@ int gm_acq_finer_doppler(gm_acq* a, const gm_acq_result* results, const uint8_t*
     gm::launch_fine_mean(a->stream, a->last_samples, a->last_fmt, a->M * a->N, f.d_mean);
     f.p1->fine_cols(a->stream, fa, int(S));
     f.p2->fine_rows(a->stream, fa, int(S));
-    gm::launch_fine_final(a->stream, f.d_rowmax, f.d_rowarg, N1, int(S), f.d_peak_pow, f.d_peak_idx);
+    gm::launch_fine_final(a->stream, f.d_rowmax, f.d_rowarg, N1 / uint32_t(f.p2->fine_rows_per_wg), int(S), f.d_peak_pow, f.d_peak_idx);
     HIPC(hipGetLastError());
     std::vector<float> pw(S);
     std::vector<uint32_t> pi(S);

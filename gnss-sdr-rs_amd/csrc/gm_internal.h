@@ -50,6 +50,7 @@ struct PlanOps {
     // four-step long FFT passes (power-of-two plans only, else null): this plan as N1 (columns) / as N2 (rows)
     void (*fine_cols)(hipStream_t, const FineArgs&, int n_sats);
     void (*fine_rows)(hipStream_t, const FineArgs&, int n_sats);
+    int fine_rows_per_wg;   // rows of the row pass one workgroup takes (its results: N1 / this per satellite)
 };
 // mean of the snapshot (finer_doppler :236) and the final per-satellite reduction over the rows
 void launch_fine_mean(hipStream_t, const void* samples, int fmt, uint32_t n, float* d_mean);
