@@ -414,8 +414,28 @@ def cfg1_leg(torch, dev, stream, ca, A, synth):
     res = eng.fetch_results()
     found = sorted(r["prn"] for r in res if r)
     eng.close()
+    # BASELINE configs[0] proper: ONE PRN (the reference's test_acquisition_with_real_data searches a single worker at a
+    # time): 29 items would leave the chip idle, so every item is cut into five parts (grid split of acq_corr_kernel)
+    one = A.AcquisitionEngine(sc["fs"], sc["f_if"], sc["N"], doppler_hz=sc["doppler_hz"], n_integrations=sc["M"],
+                              prn_ids=[sc["sats"][0]["prn"]])
+    one.set_stream(stream)
+    for _ in range(2):
+        one.search_dev(x.data_ptr(), A.FMT_I8_REAL)
+        one.decide_dev()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one.search_dev(x.data_ptr(), A.FMT_I8_REAL)
+        one.decide_dev()
+    torch.cuda.synchronize()
+    dt1 = (time.perf_counter() - t0) / reps
+    r1 = one.fetch_results(1)[0]
+    one.close()
     corr_bytes = P * D * M * N * 16
-    return {"workload": "32 PRN x 29 bins (+-7 kHz / 500 Hz) x 16368 phases, 10 x 1 ms, real int8 (reference test geometry)",
+    return {"single_prn": {"ms_per_dwell": dt1 * 1e3, "cells_per_s": D * N / dt1,
+                           "found_within_3_samples_of_truth": bool(r1 and min((r1["code_phase_samples"] - sc["sats"][0]["code_start"]) % N,
+                                                                                (sc["sats"][0]["code_start"] - r1["code_phase_samples"]) % N) <= 3)},
+            "workload": "32 PRN x 29 bins (+-7 kHz / 500 Hz) x 16368 phases, 10 x 1 ms, real int8 (reference test geometry)",
             "cells_per_s": P * D * N / dt, "ms_per_dwell": dt * 1e3, "corr_kernel_ms": ts["avg_corr_ms"],
             "corr_algorithmic_GBs": corr_bytes / (ts["avg_corr_ms"] * 1e-3) / 1e9 if ts["avg_corr_ms"] > 0 else None,
             "prns_found": found, "prns_in_scene": sorted(s["prn"] for s in sc["sats"])}

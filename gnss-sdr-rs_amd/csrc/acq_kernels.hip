@@ -588,12 +588,16 @@ template <class PL> struct Launch {
         static const int split_env = getenv("GM_CORR_SPLIT") ? atoi(getenv("GM_CORR_SPLIT")) : -1;
         static const int items_env = getenv("GM_CORR_SPLIT_ITEMS") ? atoi(getenv("GM_CORR_SPLIT_ITEMS")) : -1;
         int split_from = share, split_k = 1, split_items = 0;
-        if (SPLIT_SLAB && split_scratch && split_counter && split_env != 0 && !g_corr_stamps_armed && share > slots) {
+        if (SPLIT_SLAB && split_scratch && split_counter && split_env != 0 && !g_corr_stamps_armed &&
+            (share > slots || share <= GM_CORR_SPLIT_MAX_ITEMS / 8)) {
+            // share <= slots: the whole grid is resident at once and (for few workers, e.g. the reference's single-PRN
+            // search) leaves most of the chip idle: then EVERY item is cut, which multiplies the parallelism by k
+            const bool all = share <= slots;
             for (int k = 2; k <= GM_CORR_SPLIT_MAX_K; ++k)
-                if (n_int % k == 0) split_k = k;
+                if (n_int % k == 0 && (!all || share * k <= GM_CORR_SPLIT_MAX_SLABS / 8)) split_k = k;
             if (split_env > 1 && split_env <= GM_CORR_SPLIT_MAX_K && n_int % split_env == 0) split_k = split_env;
             if (split_k > 1) {
-                split_items = items_env > 0 ? items_env : (slots + split_k - 1) / split_k;
+                split_items = items_env > 0 ? items_env : (all ? share : (slots + split_k - 1) / split_k);
                 if (split_items > share) split_items = share;
                 if (split_items > GM_CORR_SPLIT_MAX_ITEMS / 8) split_items = GM_CORR_SPLIT_MAX_ITEMS / 8;
                 if (split_items * split_k > GM_CORR_SPLIT_MAX_SLABS / 8) split_items = GM_CORR_SPLIT_MAX_SLABS / 8 / split_k;

@@ -59,8 +59,8 @@ void launch_fine_final(hipStream_t, const float* rowmax, const uint32_t* rowarg,
 // tail split of the correlation grid: per XCD about one resident round of slots (64) worth of parts, at most
 // GM_CORR_SPLIT_MAX_K parts per item; the scratch holds GM_CORR_SPLIT_MAX_SLABS partial planes, one ticket per item
 constexpr int GM_CORR_SPLIT_MAX_K = 5;
-constexpr int GM_CORR_SPLIT_MAX_SLABS = 8 * 80;
-constexpr int GM_CORR_SPLIT_MAX_ITEMS = 8 * 40;
+constexpr int GM_CORR_SPLIT_MAX_SLABS = 8 * 160;
+constexpr int GM_CORR_SPLIT_MAX_ITEMS = 8 * 80;
 const PlanOps* find_plan(int n);
 int list_plans(uint32_t* sizes, int cap);
 
