@@ -221,3 +221,31 @@ def test_acquisition_beyond_one_lds_buffer(gpu, oracle, fs, code_len, code_rate,
     fine = eng.finer_doppler([r0, None, None])
     assert abs(fine[0]["freq_hz"] - 180.0) < 60.0
     eng.close()
+
+
+def test_composite_size_with_mask_and_ring(gpu, oracle):
+    """The composite path (N = 25000 = 5 x 5000) behind the other entry points: a PRN mask (only the selected workers'
+    planes are recomputed, the others report None) and the device-ring snapshot."""
+    from gnss_sdr_rs_amd import acquisition as A, tracking as T, synth
+    fs, N, M = 25.0e6, 25000, 2
+    t = oracle.ca_code_table()
+    dop = np.array([-500.0, 0.0, 500.0], np.float32)
+    sats = [dict(prn_row=4, cn0_dbhz=50.0, doppler_hz=120.0, code_start=20000),
+            dict(prn_row=11, cn0_dbhz=50.0, doppler_hz=-310.0, code_start=55)]
+    x = synth.to_c32(synth.make_scene(t, fs, 0.0, 3 * N, sats, config_id=75))
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=[5, 12, 20], n_integrations=M, decision_mode=A.DECIDE_BEST_BIN)
+    full = eng.search(x[:M * N])
+    assert full[0] and full[0]["code_phase_samples"] == 20000 and full[1] and full[1]["code_phase_samples"] == 55
+    masked = eng.search(x[:M * N], prn_mask=0b010)
+    assert masked[0] is None and masked[2] is None
+    assert {k: v for k, v in masked[1].items() if k != "mag_relative"} == {k: v for k, v in full[1].items() if k != "mag_relative"}
+    assert masked[1]["mag_relative"] == pytest.approx(full[1]["mag_relative"], rel=REL)
+    ring = T.MulticastRingBuffer(1 << 17)
+    ring.write_samples(x[:N + 777])
+    assert eng.search_ring(ring) == (None, None)           # fewer than M*N samples so far (:299)
+    ring.write_samples(x[N + 777:3 * N])
+    res, tail = eng.search_ring(ring)
+    assert tail == N
+    assert res[0]["code_phase_samples"] == 20000 and res[0]["sample_global_index"] == N + 20000
+    assert res[1]["code_phase_samples"] == 55
+    eng.close(); ring.close()
