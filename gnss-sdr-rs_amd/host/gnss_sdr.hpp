@@ -12,6 +12,7 @@
 #include <thread>
 #include <cstdint>
 #include <cmath>
+#include <limits>
 #include <optional>
 #include <set>
 #include <stdexcept>
@@ -137,6 +138,17 @@ public:
         for (uint32_t i = 0; i < n_prn_; ++i) if (f[i]) out[i] = r[i];
         return out;
     }
+    // finer_doppler (acquisition_bk.rs:215-302) on the snapshot of the last search: refined carrier (IF + Doppler) of
+    // every found result, to a fraction of the coarse bin; entries of not-found workers are left as NaN
+    std::vector<float> finer_doppler(const std::vector<std::optional<AcquisitionResult>>& results) {
+        std::vector<gm_acq_result> r(results.size());
+        std::vector<uint8_t> f(results.size(), 0);
+        for (size_t i = 0; i < results.size(); ++i) if (results[i]) { r[i] = *results[i]; f[i] = 1; }
+        std::vector<float> freq(results.size(), std::numeric_limits<float>::quiet_NaN());
+        check(gm_acq_finer_doppler(h_, r.data(), f.data(), uint32_t(results.size()), freq.data(), nullptr, nullptr, nullptr),
+              "finer_doppler");
+        return freq;
+    }
     std::vector<std::optional<AcquisitionResult>> search_i8(const std::vector<int8_t>& iq_interleaved, uint64_t local_tail,
                                                             uint64_t prn_mask = ~0ull) {
         std::vector<gm_acq_result> r(n_prn_);
@@ -200,6 +212,27 @@ public:
     // rf_thread's block step (rf_thread.rs:43-48): process_block + write_samples, fused on the GPU, non-blocking
     void write_ring(MulticastRingBuffer& ring, const Complex32* block, size_t n) { check(gm_frontend_write_ring(h_, ring.handle(), block, n, GM_FMT_C32), "write_ring"); }
     void write_ring_i8(MulticastRingBuffer& ring, const int8_t* iq, size_t n) { check(gm_frontend_write_ring(h_, ring.handle(), iq, n, GM_FMT_I8_IQ), "write_ring"); }
+};
+
+// ---- decoding::NavSyncStatus + nav_decoding's per-epoch step up to frame sync (src/decoding.rs:40-227, legacy)
+class NavSyncStatus {
+    gm_nav_sync* h_ = nullptr;
+public:
+    explicit NavSyncStatus(int mode = GM_NAV_FAITHFUL) { check(gm_nav_sync_create(mode, &h_), "NavSyncStatus::new"); }
+    ~NavSyncStatus() { gm_nav_sync_destroy(h_); }
+    NavSyncStatus(const NavSyncStatus&) = delete;
+    gm_nav_status update(float old_i_prompt, float i_prompt, uint64_t cnt, uint64_t buff_loc = 0) {
+        gm_nav_status st{};
+        check(gm_nav_sync_update(h_, old_i_prompt, i_prompt, cnt, buff_loc, &st), "nav_decoding");
+        return st;
+    }
+    std::vector<int8_t> frame_bits() const {
+        size_t n = 0;
+        check(gm_nav_sync_frame_bits(h_, nullptr, 0, &n), "frame_bits");
+        std::vector<int8_t> b(n);
+        if (n) check(gm_nav_sync_frame_bits(h_, b.data(), n, &n), "frame_bits");
+        return b;
+    }
 };
 
 // ---- tracking::do_tracking (src/tracking/do_tracking.rs)

@@ -176,6 +176,71 @@ static int test_receiver_threads() {
     return 0;
 }
 
+// The rows either side of the path through the C++ mirror: DigitalFrontend::process_block against a scalar restatement
+// of rf/frontend.rs:33-62 written here in plain C++ (bit-exact), finer_doppler after a search, NavSyncStatus on a
+// synthetic prompt stream.
+static int test_frontend_refinement_navsync() {
+    {   // front-end: 4096 floats = 2048 samples, f_if / fs = 1/8
+        DigitalFrontend fe(1.0e6f, 8.0e6f, 8.0e6f);
+        std::vector<float> raw(4096), want(4096);
+        uint64_t st = 99;
+        for (auto& v : raw) v = float(20.0 * gauss(st)) + 3.0f;
+        want = raw;
+        float lre[2048], lim[2048];
+        for (int i = 0; i < 2048; ++i) {
+            const float angle = ((2.0f * 3.14159265358979323846f) * float(i)) / 2048.0f;
+            lre[i] = std::cos(angle); lim[i] = -std::sin(angle);
+        }
+        const float step = (1.0e6f / 8.0e6f) * 2048.0f, alpha = 0.001f, con = 1.0f - alpha;
+        float bre[8] = {0}, bim[8] = {0}, phase = 0.0f;
+        for (size_t c = 0; c + 16 <= want.size(); c += 16) {
+            float re[8], im[8]; size_t idx[8];
+            for (int j = 0; j < 8; ++j) { re[j] = want[c + 2 * j]; im[j] = want[c + 2 * j + 1]; }
+            for (int j = 0; j < 8; ++j) {
+                bre[j] = bre[j] * con + re[j] * alpha; bim[j] = bim[j] * con + im[j] * alpha;
+                re[j] -= bre[j]; im[j] -= bim[j];
+            }
+            for (int j = 0; j < 8; ++j) { idx[j] = size_t(phase) % 2048; phase = std::fmod(phase + step, 2048.0f); }
+            for (int j = 0; j < 8; ++j) {
+                want[c + 2 * j] = re[j] * lre[idx[j]] + im[j] * lim[idx[j]];
+                want[c + 2 * j + 1] = re[j] * lim[idx[j]] - im[j] * lre[idx[j]];
+            }
+        }
+        fe.process_block(raw);
+        CHECK(std::memcmp(raw.data(), want.data(), raw.size() * sizeof(float)) == 0);
+    }
+    {   // refinement: PRN 6 at +1230 Hz, 500 Hz bins -> the refined carrier is within 40 Hz
+        const float FS = 4096000.0f;
+        const size_t M = 4, N = 4096;
+        auto x = synth(6, 1230.0f, FS, int(M), 900, 4.0f, 16.0f);
+        std::vector<float> dop;
+        for (float d = -2000.0f; d <= 2000.0f; d += 500.0f) dop.push_back(d);
+        AcquisitionEngine eng(FS, 0.0f, uint32_t(N), dop, std::vector<uint8_t>{6}, uint32_t(M), 7.0f, GM_DECIDE_BEST_BIN);
+        auto res = eng.search(x, 0);
+        CHECK(res[0].has_value() && res[0]->code_phase_samples == 900);
+        auto fine = eng.finer_doppler(res);
+        CHECK(std::fabs(fine[0] - 1230.0f) < 40.0f);
+        CHECK(std::fabs(res[0]->carrier_freq - 1230.0f) <= 250.0f);
+    }
+    {   // bit sync: sign changes every 20 epochs at offset 7, FIXED mode emits the bits
+        NavSyncStatus nav(GM_NAV_FIXED);
+        uint64_t st = 5;
+        float old = 0.0f;
+        int bit = 1, emitted = 0;
+        gm_nav_status last{};
+        for (uint64_t cnt = 1; cnt < 4000; ++cnt) {
+            if (cnt % 20 == 7) bit = (gauss(st) > 0.0) ? 1 : -1;
+            const float ip = float(bit) * 900.0f + float(100.0 * gauss(st));
+            last = nav.update(old, ip, cnt);
+            emitted += last.sync_sw;
+            old = ip;
+        }
+        CHECK(last.flag_bit_sync && last.frame_sync_ind == 7);
+        CHECK(emitted > 60 && nav.frame_bits().size() == size_t(emitted));
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const bool cpu_only = argc > 1 && !std::strcmp(argv[1], "--cpu-only");
     int rc = test_acquisition_manager();
@@ -186,5 +251,6 @@ int main(int argc, char** argv) {
     rc |= test_pll_frequency_pull_in();            std::printf("test_pll_frequency_pull_in %s\n", rc ? "FAILED" : "ok");
     rc |= test_acquisition_with_synthetic_data();  std::printf("test_acquisition_with_synthetic_data %s\n", rc ? "FAILED" : "ok");
     rc |= test_receiver_threads();                 std::printf("test_receiver_threads %s\n", rc ? "FAILED" : "ok");
+    rc |= test_frontend_refinement_navsync();      std::printf("test_frontend_refinement_navsync %s\n", rc ? "FAILED" : "ok");
     return rc;
 }
