@@ -481,26 +481,34 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // what wave 0 hands to the whole workgroup once per epoch
+// (the channel state itself stays in wave 0's registers for the whole launch: only what the correlating waves need
+// travels through LDS, and of the constants only the four that change from epoch to epoch)
 struct EpochShared {
-    gm_trk_state s;
+    uint64_t win;      // next_sample_index: first sample of the coming epoch's window
     uint32_t n;        // samples of the coming epoch (0: channel cannot run)
     int fast;          // fast_code_range(...) for the coming epoch
     EpochConsts ec;
 };
 
 // n_known: the epilogue has just stored round(fs/(code_rate/len)) for the CURRENT code_rate in num_samples_per_code
-__device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t head, EpochShared& sh, bool n_known = false) {
-    const gm_trk_state& s = sh.s;
+// first: write every constant (launch start); later calls write the four per-epoch ones
+__device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t head, const gm_trk_state& s, EpochShared& sh,
+                                              bool n_known, bool first) {
     const uint64_t n = n_known ? s.num_samples_per_code : samples_per_code(cfg, s.code_rate);     // update() :165-166
     bool run = s.active && n > 0 && n < (1ull << 31);
     if (run) run = (int64_t)(head - (s.next_sample_index + n)) >= 0;              // :170-172
+    sh.win = s.next_sample_index;
     sh.n = run ? uint32_t(n) : 0u;
-    sh.ec = epoch_consts(cfg, s);
-    sh.fast = fast_code_range(sh.ec, n) ? 1 : 0;
+    const EpochConsts ec = epoch_consts(cfg, s);
+    if (first) sh.ec = ec;
+    else { sh.ec.carrier_phase = ec.carrier_phase; sh.ec.two_pi_f = ec.two_pi_f; sh.ec.code_phase = ec.code_phase; sh.ec.step = ec.step; }
+    sh.fast = fast_code_range(ec, n) ? 1 : 0;
 }
 
 template <int ARMS, int MODE_T, int BOC_T, int T>
-__global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
+// second launch bound = waves per SIMD with TRK_PERSIST_WG_PER_CU workgroups resident: the co-residency the exchange relies
+// on must not be lost to a register count above 512 / that
+__global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persistent_kernel(TrkPersistArgs a) {
     constexpr int NV = 2 * ARMS, NW = T / 64, KPF = 4;
     const TrkDevCfg& cfg = a.cfg;
     const int ch = blockIdx.x / a.G, g = blockIdx.x % a.G, tid = threadIdx.x;
@@ -518,10 +526,11 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
     int e = 0;
     bool timed_out = false;
     const bool ran = s0.active && row >= 0 && row < cfg.n_codes;
+    gm_trk_state st = s0;               // the channel state: updated by wave 0 only, epoch after epoch, in registers
     if (ran) {
         const int8_t* crow = a.codes + size_t(row) * cfg.code_len;
         for (int i = tid; i < cfg.code_len; i += T) chips[i] = crow[i];
-        if (tid == 0) { ctl = 0; sh.s = s0; prepare_epoch(cfg, a.head, sh); }
+        if (tid == 0) { ctl = 0; prepare_epoch(cfg, a.head, s0, sh, false, true); }
         __syncthreads();
         // slice geometry, fixed for the launch: `per` samples per workgroup (multiple of 64 lanes); the last
         // workgroup also takes whatever a longer code period adds beyond G*per
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
             const uint32_t n = sh.n;
             if (n == 0) break;                     // state is identical in the G workgroups: they all leave
             const EpochConsts ec = sh.ec;
-            const uint64_t win = sh.s.next_sample_index;
+            const uint64_t win = sh.win;
             const bool st_on = a.stamps && blockIdx.x == 0 && tid == 0;
             long long* stp = a.stamps + size_t(e) * 48;
             if (st_on) stp[0] = stamp_now();
@@ -714,14 +723,14 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
                     for (int k = 0; k < NV; ++k) v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tk), k));
                 }
                 if (st_on) stp[5] = stamp_now();
-                gm_trk_state sn = sh.s;
-                sn.num_samples_per_code = n;                     // update() stores the length it used (:166)
                 uint8_t lst = 0, lprn = 0;
-                if (!to) epoch_epilogue<ARMS>(cfg, sn, v, n, TRK_MODE_DO_WORK, lst, lprn);
+                if (!to) {
+                    st.num_samples_per_code = n;                 // update() stores the length it used (:166)
+                    epoch_epilogue<ARMS>(cfg, st, v, n, TRK_MODE_DO_WORK, lst, lprn);
+                }
                 if (st_on) stp[6] = stamp_now();
                 if (lane == 0) {
-                    sh.s = sn;
-                    prepare_epoch(cfg, a.head, sh, !to);            // n / constants / gate of the NEXT epoch, once
+                    prepare_epoch(cfg, a.head, st, sh, !to, false);     // n / constants / gate of the NEXT epoch, once
                     ctl = to ? 1 : 0;
                     if (g == 0 && !to) {
                         const size_t o = size_t(e) * C + ch;
@@ -742,7 +751,7 @@ __global__ __launch_bounds__(T) void trk_persistent_kernel(TrkPersistArgs a) {
         if (tid == 0 && timed_out) *a.error_flag = 1;
     }
     if (leader) {
-        if (ran) a.states[ch] = sh.s;       // an idle channel's state is left as it was
+        if (ran) a.states[ch] = st;         // (the leader is lane 0 of wave 0) an idle channel's state is left as it was
         gm_trk_out z;
         z.ip = z.qp = z.ie = z.qe = z.il = z.ql = z.ive = z.qve = z.ivl = z.qvl = 0.0f;
         for (int r = e; r < a.epochs; ++r) {   // passes in which this channel did not run
