@@ -211,3 +211,60 @@ def test_frontend_oracle_vs_numpy_float32_twin():
     got = fe.process_block(x.copy())
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
     assert f32(fe.s.phase_accumulator) == phase and (np.array(fe.s.bias_re[:], f32) == bre).all()
+
+
+def _regression_vectors():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "restatement_vectors.json")))
+
+
+def _regen_acq(O, synth, case):
+    import numpy as np
+    t = O.ca_code_table()
+    x = synth.to_c32(synth.make_scene(t, case["fs"], case["f_if"], case["M"] * case["N"], case["sats"], config_id=case["config_id"]))
+    tables = [O.DopplerShiftTable(case["f_if"], float(d), case["fs"], case["N"]) for d in case["doppler_hz"]]
+    return x, tables
+
+
+def test_oracle_reproduces_its_committed_regression_vectors():
+    """tests/golden/restatement_vectors.json (SURVEY §8 c4's list: Doppler tables, mix output, per-(p, d) metrics of two small
+    scenes, AcquisitionResults, 5 tracking epochs in both code-index modes) — outputs of THIS restatement frozen at commit
+    time, regenerated here bit for bit from the seeds.  Guards the oracle against accidental change."""
+    import hashlib
+    import numpy as np
+    from oracle import oracle as O
+    from gnss_sdr_rs_amd import synth
+    vec = _regression_vectors()
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32).tolist()
+    for key in ("acq_scene_2048", "acq_scene_8000"):
+        case = vec[key]
+        x, tables = _regen_acq(O, synth, case)
+        if key == "acq_scene_2048":
+            assert [hashlib.sha256(tables[i].table.tobytes()).hexdigest() for i in (1, 2, 3)] == vec["doppler_tables"]["sha256"]
+            mixed = np.zeros(2048, np.complex64)
+            O.apply_doppler_shift(x[:2048], tables[3], mixed)
+            assert hashlib.sha256(mixed.tobytes()).hexdigest() == vec["mix"]["sha256"]
+        for prn, w in zip(case["prns"], case["workers"]):
+            exp, (bmax, barg, bsum, _) = O.AcquisitionWorker(prn, case["N"], case["fs"]).search_satellite(
+                x, tables, 1000, case["M"], want_planes=True, no_early_exit=True)
+            assert bits(bmax) == w["max_bits"] and np.asarray(barg).tolist() == w["argmax"] and bits(bsum) == w["sum_bits"]
+            assert exp == w["result"]
+    trk = vec["tracking"]
+    t = O.ca_code_table()
+    for mode in (0, 1):
+        chans = trk["modes"][str(mode)]
+        prns = [c["prn"] for c in chans]
+        rows = [p if mode == 0 else p - 1 for p in prns]
+        sc = synth.tracking_scene(t, trk["fs"], 0.0, prns, 7, config_id=trk["config_id"], cn0=50.0, code_rows=rows)
+        ring = O.MulticastRingBuffer(1 << 16)
+        ring.write_samples(synth.to_c32(sc["x"])[:6 * trk["n"] + 4000])
+        for i, c in enumerate(chans):
+            ch = O.TrackingChannel(i, trk["fs"], code_index_mode=mode)
+            ch.start(dict(prn=c["prn"], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=c["doppler_hz"] + 25.0,
+                          fs=trk["fs"], mag_relative=1.0, sample_global_index=c["code_start"]))
+            for ep in c["epochs"]:
+                rc, out6, _ = ch.update(ring)
+                assert rc == 1 and bits(out6) == ep["out_bits"]
+                assert bits([ch.c.carrier_freq, ch.c.code_rate, ch.c.carrier_phase, ch.c.code_phase]) == ep["state_bits"]
+                assert int(ch.c.next_sample_index) == ep["next_sample_index"]
