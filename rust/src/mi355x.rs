@@ -1,27 +1,12 @@
-# INTEGRATION — binding the MI355X path into kewei/gnss-sdr-rs
+// mi355x.rs — the ONE module a maintainer adds to kewei/gnss-sdr-rs to put the MI355X path behind the crate's own
+// acquisition / tracking API.  Mirror of include/gnss_mi355x.h (raw bindings) + safe wrappers with the
+// reference's names.  Shipped as source: the build image has no Rust toolchain, so this file was NOT compiled here; the
+// same ABI is exercised end to end by gnss-sdr-rs_amd/host/gnss_sdr.hpp + tests/cpp/test_host_api.cpp (C++) and by the
+// ctypes mirror used in tests/ (Python).  Generated from the code blocks of INTEGRATION.md (keep the two in step).
+#![allow(non_camel_case_types, dead_code)]
+use crate::acquisition::do_acquisition::{AcqError, AcquisitionResult};
 
-The reference's boundary for this path is its Rust API (SURVEY.md §8b); it has no FFI of its own here.
-`libgnss_mi355x.so` (built by `python __graft_entry__.py build`, or `python gnss-sdr-rs_amd/build.py`) exports the
-C ABI declared in `include/gnss_mi355x.h`.  A maintainer adds ONE module to the crate, e.g. `src/mi355x.rs`,
-holding the `extern "C"` block and safe wrappers with the same names and signatures as today's items, and then
-switches `src/main.rs:204-227` (or the tests) to them.  Nothing else in the crate changes: the stage threads,
-the crossbeam channels, `MulticastRingBuffer` and `AppConfig` stay as they are.
-
-(Rust is not installed in the build image, so the block below is shipped as source and was not compiled here.
-The same ABI is exercised end to end by the C++ mirror `gnss-sdr-rs_amd/host/gnss_sdr.hpp` +
-`tests/cpp/test_host_api.cpp` and by the Python `ctypes` mirror used in `tests/`.)
-
-## 1. `build.rs` addition
-
-```rust
-// build.rs (next to the existing bindgen call, build.rs:11-27)
-println!("cargo:rustc-link-search=native={}", std::env::var("GNSS_MI355X_LIB_DIR").unwrap());
-println!("cargo:rustc-link-lib=dylib=gnss_mi355x");
-```
-
-## 2. `src/mi355x.rs` — raw bindings (mirror of include/gnss_mi355x.h)
-
-```rust
+// ------------------------------------------------------------------ raw bindings
 use num_complex::Complex32;
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -107,22 +92,8 @@ extern "C" {
     pub fn gm_acq_decide_dev(a: *mut GmAcq, d_metrics: *const c_void, n_prn: u32, prn_ids: *const u8, local_tail: u64) -> c_int;
     pub fn gm_acq_fetch_results(a: *mut GmAcq, n_prn: u32, results: *mut GmAcqResult, found: *mut u8) -> c_int;
 }
-```
 
-Multi-GPU from Rust (one process per GPU, PRNs in contiguous blocks per rank): rank 0 calls `gm_comm_get_unique_id`
-and hands the 128 bytes to the other processes over whatever channel the deployment has (a file, a socket, MPI);
-every rank then runs `gm_init(local_gpu)`, `gm_comm_init(nranks, rank, id)`, and per dwell
-`gm_acq_search_dev` → `gm_acq_allgather_metrics` → `gm_acq_decide_dev(d_all, nranks·P, all_prn_ids, tail)` →
-`gm_acq_fetch_results`: every rank ends with the same `Option<AcquisitionResult>` list, bit-identical to the
-single-GPU search (checked by `tests/test_distributed_gloo.py` on the host replay and by the one-rank RCCL test in
-`tests/test_gpu_acquisition.py`).  No PyTorch is involved; `bench.py` uses `torch.distributed` only because the
-bench driver launches it that way (`GM_BENCH_NATIVE_COMM=1` switches it to these entries).
-
-`Complex32` is `#[repr(C)] {re: f32, im: f32}` in num-complex 0.4.6, identical to `gm_c32`.
-
-## 3. Safe wrappers with the reference's names
-
-```rust
+// ------------------------------------------------------------------ safe wrappers
 pub struct AcquisitionEngine { h: *mut GmAcq, n_prn: usize }   // replaces Vec<AcquisitionWorker> in run() (:268-271)
 unsafe impl Send for AcquisitionEngine {}
 
@@ -151,17 +122,10 @@ impl AcquisitionEngine {
     }
 }
 impl Drop for AcquisitionEngine { fn drop(&mut self) { unsafe { gm_acq_destroy(self.h); } } }
-```
 
-In `do_acquisition::run` the two changes are: build one `AcquisitionEngine` instead of the `workers` vector
-(`:268-271`), and replace the `par_iter_mut` block (`:302-313`) by `engine.search(&chunk_samples, local_tail, mask)`.
-`AcquisitionManager`, pacing, channel messages stay untouched.
-
-Tracking: `TrackingManager` keeps its `acq_to_trk` / `trk_to_acq` channels; `channels: Vec<TrackingChannel>` is
-replaced by one `*mut GmTrk` (+ a `GmRing` fed by `rf_thread` next to `MulticastRingBuffer::write_samples`,
-`rf_thread.rs:12-59`); `process_channels` (`:351-371`) becomes
-
-```rust
+// ------------------------------------------------------------------ TrackingManager::process_channels (do_tracking.rs:351-371)
+// the body that replaces the par_iter_mut fan-out (shown as it would sit inside `impl TrackingManager`):
+/*
 while let Ok(msg) = self.acq_to_trk.try_recv() {                       // unchanged (:352-362)
     if let Some(ch) = self.idle_channel() { let _ = self.trk_to_acq.send(TrackingMessage::SatelliteLocked(msg.prn));
         unsafe { gm_trk_start(self.h, ch, &to_raw(&msg)); } } }
@@ -169,31 +133,4 @@ let mut lost = vec![0u8; LOOP_MS * self.n]; let mut done = 0u32;
 unsafe { gm_trk_update_all(self.h, self.ring, LOOP_MS as u32, std::ptr::null_mut(), std::ptr::null_mut(),
                            lost.as_mut_ptr(), &mut done); }            // replaces par_iter_mut().for_each(update) (:364-371)
 for (i, l) in lost.iter().enumerate() { if *l != 0 { let _ = self.trk_to_acq.send(TrackingMessage::SatelliteLost(0)); } }
-```
-
-(`SatelliteLost` carries prn 0 in the reference because `reset()` runs before the message is built,
-`do_tracking.rs:199-201`; the ABI reports the same value through `lost_prn`.)
-
-### 3.1 The rows either side of the path (SURVEY §8 f1–f4)
-The same header carries the entries a maintainer would bind for the steps around the path; each mirrors a reference item:
-
-| reference item | C entry | Rust wrapper to add |
-|---|---|---|
-| `rf::frontend::DigitalFrontend::{new, process_block}` (`rf/frontend.rs:19-62`) | `gm_frontend_create / _process_block / _destroy` | `impl DigitalFrontend { pub fn new(f_if, fs_in, fs_out); pub fn process_block(&mut self, raw: &mut [f32]) }` |
-| `rf_thread`'s block step (`rf/rf_thread.rs:43-48`) | `gm_frontend_write_ring(fe, ring, samples, n, fmt)` | replaces `prepare_block` + `process_block` + `write_samples`; int8 sources use `GM_FMT_I8_IQ` |
-| ring `notifier` / `condvar` (`multicast_ring_buffer.rs:42-43,94-98`) | `gm_ring_wait_head`, `gm_ring_write_samples_async`, `gm_ring_flush` | `do_tracking::run`'s wait loop (`:392-406`) calls `wait_head(next_tracking_index)` |
-| `finer_doppler` (`acquisition_bk.rs:215-302`) | `gm_acq_finer_doppler(acq, results, found, n, freq, idx, mag, fft_size)` | call after `search`, before `to_tracking.send(result)`: `result.carrier_freq = freq[p]` |
-| `nav_decoding` up to frame sync, `parity_check` (`decoding.rs:102-227,259-352`) | `gm_nav_sync_create / _update / _frame_bits`, `gm_nav_parity_check` | one `NavSyncStatus` per tracking channel, fed with `gm_trk_out.ip` of each epoch |
-| many antennas / bands | `gm_frontend_process_dev_batch` | no reference item: one launch, one workgroup per stream |
-
-## 4. Behavioural notes for the maintainer
-* `fft_size` must be a multiple of 8 and one of `gm_fft_supported_sizes()` (8000, 16368, 16384, 16000, 15000, 12000, 10000, 8192, 6000,
-  5000, 4096, 4000, 2048, 2000, 1024, 512, 256), or 2/3/4/5/6/8 times one of them for the acquisition handle (32000, 25000, 50000 …:
-  composite path); other sizes return `GM_ERR_UNSUPPORTED_N` / `GM_ERR_ALIGNMENT` instead of silently using the
-  reference's stale SIMD tails (`doppler_shift.rs:26`, `do_acquisition.rs:230-234`).
-* `code_index_mode = GM_CODE_INDEX_FAITHFUL` reproduces `get_ca_chip`'s row `prn` (off by one) and so
-  cannot run PRN 32; use `GM_CODE_INDEX_FIXED` for a receiver that must actually track.
-* One handle per thread at a time; one process per GPU (`gm_init(device)`).
-* Inside a Python/PyTorch process import `torch` BEFORE the first `gm_*` call: PyTorch ships its own
-  `libamdhip64.so.7`, and a process that has already initialised `/opt/rocm`'s copy through this library cannot
-  initialise PyTorch's afterwards ("No HIP GPUs are available").  A Rust host has one HIP runtime and no such issue.
+*/

@@ -129,3 +129,30 @@ def test_fft_core_cpu_emulation_of_every_plan():
     r = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "Plan8000" in r.stdout and "Plan256" in r.stdout and "worst" in r.stdout
+
+
+def test_rust_binding_source_matches_the_abi(gm):
+    """rust/src/mi355x.rs (the reference-side binding shipped as source) cannot be compiled here, so its
+    layout is checked structurally: every #[repr(C)] struct lists the same fields in the same order as the ctypes mirror
+    the test suite exercises, and every extern fn it declares exists in include/gnss_mi355x.h."""
+    from gnss_sdr_rs_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "rust", "src", "mi355x.rs")).read()
+    hdr = open(os.path.join(root, "include", "gnss_mi355x.h")).read()
+
+    def rust_fields(name):
+        body = re.search(r"pub struct %s\s*\{([^}]*)\}" % name, src, re.S).group(1)
+        body = re.sub(r"//[^\n]*", "", body)
+        return re.findall(r"pub\s+(\w+)\s*:", body)
+
+    pairs = {"GmAcqResult": _lib.AcqResult, "GmAcqCfg": _lib.AcqCfg, "GmTrkState": _lib.TrkState, "GmTrkOut": _lib.TrkOut,
+             "GmTrkCfg": _lib.TrkCfg}
+    for rname, ct in pairs.items():
+        assert rust_fields(rname) == [f[0] for f in ct._fields_], rname
+    fns = set(re.findall(r"pub fn (gm_\w+)\s*\(", src))
+    assert len(fns) >= 25
+    declared = set(re.findall(r"\b(gm_[a-z0-9_]+)\s*\(", hdr))
+    assert fns <= declared, sorted(fns - declared)
+    # and INTEGRATION.md carries the same code
+    integ = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert "pub decision_mode: i32" in integ and "pub decision_mode: i32" in src
