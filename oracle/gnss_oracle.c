@@ -770,6 +770,79 @@ int orc_trk_update(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, f
     return rc == 1 ? 2 : 1;
 }
 
+/* update() :160-180 + do_work() :183-210 GENERALISED to the channel's code length / arm count / BOC flag (no reference
+ * code for those, SURVEY §8c5: the same statements with 1023 -> code_len and the E/P/L correlator -> _ex).  With the
+ * reference's GPS settings it performs exactly orc_trk_update's operations.  out10 as in _ex. */
+static size_t num_samples_per_code_len(float code_rate, float fs, float lenf) {
+    float v = roundf(fs / (code_rate / lenf));       /* ca_code.rs:13-16 with the code length as a parameter */
+    if (!(v > 0.0f)) return 0;
+    return (size_t)v;
+}
+int orc_trk_update_ex(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float out10[10],
+                      uint8_t *msg_prn) {
+    if (!orc_trk_is_active(c)) return 0;
+    const float lenf = c->custom_codes ? (float)c->code_len : 1023.0f;
+    if (!c->custom_codes && (c->prn < 1 || c->prn > 32)) return -1;
+    c->num_samples_per_code = num_samples_per_code_len(c->code_rate, c->fs, lenf);      /* :165-166 */
+    uint64_t head = orc_ring_get_head(ring);
+    if ((int64_t)(head - (c->next_sample_index + c->num_samples_per_code)) < 0) return 0; /* :170-172 */
+    orc_ring_copy_to_slice(ring, c->next_sample_index, scratch, (size_t)c->num_samples_per_code);
+    if (orc_trk_early_late_correlation_ex(c, scratch, out10, NULL)) return -1;            /* do_work :183-210 */
+    float power = out10[0] * out10[0] + out10[1] * out10[1];
+    if (power > LOCK_THRESHOLD) {
+        c->lost_counter = 0;
+        orc_trk_run_loop_filters(c, out10[0], out10[1], out10[2], out10[3], out10[4], out10[5]);
+        c->next_sample_index += c->num_samples_per_code;
+        c->num_samples_per_code = num_samples_per_code_len(c->code_rate, c->fs, lenf);
+        return 1;
+    }
+    c->lost_counter += 1;
+    if (c->lost_counter >= MAX_LOST_EPOCHS) {
+        orc_trk_reset(c);
+        if (msg_prn) *msg_prn = c->prn;
+        return 2;
+    }
+    c->next_sample_index += c->num_samples_per_code;
+    c->num_samples_per_code = num_samples_per_code_len(c->code_rate, c->fs, lenf);
+    return 1;
+}
+
+/* Teacher-forced form of orc_trk_update_ex for the parity tests of multi-epoch device launches: the correlation is
+ * computed from the channel's own state (-> computed10, what the device's correlator sums are compared with), but the
+ * lock decision, the loop filters and i/q_prompt then use forced10 (the device's sums of that epoch).  By induction the
+ * channel state entering every epoch is bit-for-bit what a device that does the reference's scalar arithmetic exactly
+ * must hold, so (a) every epoch's sums are compared from IDENTICAL inputs, and (b) the final state must match exactly. */
+int orc_trk_update_forced(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float computed10[10],
+                          const float forced10[10], uint8_t *msg_prn) {
+    if (!orc_trk_is_active(c)) return 0;
+    const float lenf = c->custom_codes ? (float)c->code_len : 1023.0f;
+    if (!c->custom_codes && (c->prn < 1 || c->prn > 32)) return -1;
+    c->num_samples_per_code = num_samples_per_code_len(c->code_rate, c->fs, lenf);
+    uint64_t head = orc_ring_get_head(ring);
+    if ((int64_t)(head - (c->next_sample_index + c->num_samples_per_code)) < 0) return 0;
+    orc_ring_copy_to_slice(ring, c->next_sample_index, scratch, (size_t)c->num_samples_per_code);
+    if (orc_trk_early_late_correlation_ex(c, scratch, computed10, NULL)) return -1;
+    const float *f = forced10;
+    c->i_prompt = f[0]; c->q_prompt = f[1];
+    float power = f[0] * f[0] + f[1] * f[1];
+    if (power > LOCK_THRESHOLD) {
+        c->lost_counter = 0;
+        orc_trk_run_loop_filters(c, f[0], f[1], f[2], f[3], f[4], f[5]);
+        c->next_sample_index += c->num_samples_per_code;
+        c->num_samples_per_code = num_samples_per_code_len(c->code_rate, c->fs, lenf);
+        return 1;
+    }
+    c->lost_counter += 1;
+    if (c->lost_counter >= MAX_LOST_EPOCHS) {
+        orc_trk_reset(c);
+        if (msg_prn) *msg_prn = c->prn;
+        return 2;
+    }
+    c->next_sample_index += c->num_samples_per_code;
+    c->num_samples_per_code = num_samples_per_code_len(c->code_rate, c->fs, lenf);
+    return 1;
+}
+
 /* TrackingManager::process_channels :351-371 — par_iter_mut over the channels, one task per channel, repeated
  * while any channel still finds a whole code period in the ring (the run() loop of :384-415 without the Condvar).
  * scratch: n_channels blocks of scratch_stride samples.  Returns channel-epochs processed, -1 on OOB. */

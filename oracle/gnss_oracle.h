@@ -186,6 +186,15 @@ void orc_ring_copy_to_slice(const orc_ring *r, uint64_t start, orc_c32 *dest, si
 int orc_trk_update(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float out6[6],
                    uint8_t *msg_prn);
 
+/* the same generalised to the channel's code length / arms / BOC (no reference code, parity unpinned) */
+int orc_trk_update_ex(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float out10[10],
+                      uint8_t *msg_prn);
+
+/* teacher-forced variant for multi-epoch parity tests: sums computed from the channel's state -> computed10; decision,
+ * loop filters and i/q_prompt driven by forced10 (see the .c) */
+int orc_trk_update_forced(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float computed10[10],
+                          const float forced10[10], uint8_t *msg_prn);
+
 /* ---------------- fine Doppler (src/acquisition/acquisition_bk.rs:215-302, LEGACY file outside the reference's module
  * tree, no test) — SURVEY §8 f3.  PARITY UNPINNED.  Restated on the live path's data: `samples` are the c32 snapshot of
  * do_acquisition.rs:300 (the legacy took i16 pairs, :225-235), size_signal_use = (num_integrations-1)*N (:240), code

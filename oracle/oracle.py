@@ -114,6 +114,8 @@ def lib(native=False):
     L.orc_ring_get_head.restype = u64
     L.orc_ring_copy_to_slice.argtypes = [RP, u64, vp, sz]
     L.orc_trk_update.argtypes = [TP, RP, vp, vp, C.POINTER(C.c_uint8)]
+    L.orc_trk_update_ex.argtypes = [TP, RP, vp, vp, C.POINTER(C.c_uint8)]
+    L.orc_trk_update_forced.argtypes = [TP, RP, vp, vp, vp, C.POINTER(C.c_uint8)]
     L.orc_trk_process_channels.argtypes = [vp, C.c_int, RP, vp, C.c_size_t, C.c_int, C.c_int]
     L.orc_trk_process_channels.restype = C.c_int64
     _libs[key] = L
@@ -369,6 +371,30 @@ class TrackingChannel:
         rc = lib().orc_trk_update(C.byref(self.c), C.byref(ring.r), _p(scratch), _p(out), C.byref(mp))
         if rc < 0:
             raise IndexError("update: the reference would panic")
+        return rc, out, (("SatelliteLost", mp.value) if rc == 2 else None)
+
+
+    def update_ex(self, ring):
+        """update() generalised to the channel's code length / arm count / BOC flag -> (rc, out10, msg)"""
+        scratch = np.zeros(max(int(self.c.num_samples_per_code) * 2, 16), np.complex64)
+        out = np.zeros(10, np.float32)
+        mp = C.c_uint8(255)
+        rc = lib().orc_trk_update_ex(C.byref(self.c), C.byref(ring.r), _p(scratch), _p(out), C.byref(mp))
+        if rc < 0:
+            raise IndexError("update_ex: the reference would panic")
+        return rc, out, (("SatelliteLost", mp.value) if rc == 2 else None)
+
+
+    def update_forced(self, ring, forced):
+        """Teacher-forced update (see orc_trk_update_forced): -> (rc, computed10, msg); state advanced with `forced`."""
+        scratch = np.zeros(max(int(self.c.num_samples_per_code) * 2, 16), np.complex64)
+        out = np.zeros(10, np.float32)
+        f = np.zeros(10, np.float32)
+        f[:len(forced)] = forced
+        mp = C.c_uint8(255)
+        rc = lib().orc_trk_update_forced(C.byref(self.c), C.byref(ring.r), _p(scratch), _p(out), _p(f), C.byref(mp))
+        if rc < 0:
+            raise IndexError("update_forced: the reference would panic")
         return rc, out, (("SatelliteLost", mp.value) if rc == 2 else None)
 
 
