@@ -1,0 +1,85 @@
+// gm_libm.h — the libm functions of the reference's scalar tracking epilogue, restated so that the device rounds like
+// the host the reference runs on.
+//
+// run_loop_filters (src/tracking/do_tracking.rs:279-302) calls f32::atan, which Rust's std forwards to the platform
+// libm's atanf: on linux-gnu that is glibc's sysdeps/ieee754/flt-32/s_atanf.c (the fdlibm float kernel: four-interval
+// argument reduction + an 11-term odd/even polynomial, plain f32 multiplies and adds, no FMA; glibc 2.35 ships no
+// multiarch variant of it).  It is accurate to < 1 ulp but NOT correctly rounded, so another < 1 ulp implementation (the
+// device's ocml atanf) differs from it by an ulp on a fraction of arguments — enough to make carrier_error / carrier_nco /
+// carrier_freq drift apart from the reference's by a few ulps per epoch.  The function below performs glibc's operations
+// in glibc's order (compile with -ffp-contract=off; divisions are IEEE), so loop state stays bit-identical.
+// tests/cpu/test_libm.cpp checks it against the host's atanf on 2^26 arguments, bit for bit.
+//
+// Host/device portable on purpose (same idea as fft_core.h): g++ validates it without a GPU.
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GM_LIBM_HD __host__ __device__ __forceinline__
+#else
+#define GM_LIBM_HD inline __attribute__((always_inline))
+#endif
+
+namespace gm {
+
+GM_LIBM_HD uint32_t f32_bits(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+GM_LIBM_HD float f32_from_bits(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
+
+// IEEE-754 correctly rounded f32 division on both sides
+GM_LIBM_HD float div_rn(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fdiv_rn(a, b);
+#else
+    return a / b;
+#endif
+}
+
+// IEEE-754 correctly rounded f32 square root on both sides.  NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS hipcc's
+// header maps that to __ocml_native_sqrt_f32 (v_sqrt_f32, 1 ulp); __builtin_sqrtf is lowered to the correctly rounded
+// sequence under -fhip-fp32-correctly-rounded-divide-sqrt (hipcc's default, also passed explicitly by build.py).
+GM_LIBM_HD float sqrt_rn(float a) { return __builtin_sqrtf(a); }
+
+GM_LIBM_HD float atanf_glibc(float x) {
+    // coefficients of s_atanf.c (atanhi / atanlo / aT[0..10]) as the bit patterns its decimal literals round to (aT[0] =
+    // 3.3333334327e-01 is 0x3eaaaaab: the 0x3eaaaaaa in that file's comment is off by one)
+    const float hi0 = f32_from_bits(0x3eed6338u), hi1 = f32_from_bits(0x3f490fdau), hi2 = f32_from_bits(0x3f7b985eu),
+                hi3 = f32_from_bits(0x3fc90fdau);
+    const float lo0 = f32_from_bits(0x31ac3769u), lo1 = f32_from_bits(0x33222168u), lo2 = f32_from_bits(0x33140fb4u),
+                lo3 = f32_from_bits(0x33a22168u);
+    const float a0 = f32_from_bits(0x3eaaaaabu), a1 = f32_from_bits(0xbe4ccccdu), a2 = f32_from_bits(0x3e124925u),
+                a3 = f32_from_bits(0xbde38e38u), a4 = f32_from_bits(0x3dba2e6eu), a5 = f32_from_bits(0xbd9d8795u),
+                a6 = f32_from_bits(0x3d886b35u), a7 = f32_from_bits(0xbd6ef16bu), a8 = f32_from_bits(0x3d4bda59u),
+                a9 = f32_from_bits(0xbd15a221u), a10 = f32_from_bits(0x3c8569d7u);
+    const uint32_t hx = f32_bits(x), ix = hx & 0x7fffffffu;
+    const bool neg = (hx >> 31) != 0;
+    if (ix >= 0x4c000000u) {                         // |x| >= 2^25
+        if (ix > 0x7f800000u) return x + x;          // NaN
+        return neg ? -hi3 - lo3 : hi3 + lo3;
+    }
+    int id;
+    float ahi = 0.0f, alo = 0.0f;
+    if (ix < 0x3ee00000u) {                          // |x| < 0.4375
+        if (ix < 0x31000000u) return x;              // |x| < 2^-29
+        id = -1;
+    } else {
+        x = f32_from_bits(ix);                       // fabsf
+        if (ix < 0x3f980000u) {                      // |x| < 1.1875
+            if (ix < 0x3f300000u) { id = 0; ahi = hi0; alo = lo0; x = div_rn(2.0f * x - 1.0f, 2.0f + x); }   // 7/16 <= |x| < 11/16
+            else { id = 1; ahi = hi1; alo = lo1; x = div_rn(x - 1.0f, x + 1.0f); }                           // 11/16 <= |x| < 19/16
+        } else {
+            if (ix < 0x401c0000u) { id = 2; ahi = hi2; alo = lo2; x = div_rn(x - 1.5f, 1.0f + 1.5f * x); }   // |x| < 2.4375
+            else { id = 3; ahi = hi3; alo = lo3; x = div_rn(-1.0f, x); }                                     // 2.4375 <= |x| < 2^25
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
+    const float s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = ahi - ((x * (s1 + s2) - alo) - x);
+    return neg ? -r : r;
+}
+
+}  // namespace gm

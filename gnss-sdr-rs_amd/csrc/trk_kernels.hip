@@ -23,6 +23,7 @@
 // Sums: the reference adds sequentially in f32; here each lane adds its strided samples in order
 // and lanes/waves/slices combine as a fixed tree (deterministic; closer to the exact sum).
 #include "gm_internal.h"
+#include "gm_libm.h"
 
 namespace gm {
 
@@ -324,7 +325,7 @@ __device__ __forceinline__ CarrierHalf carrier_half(const TrkDevCfg& cfg, const 
     if (locked) {
         o.lost_counter = 0;
         // run_loop_filters (:279-302), carrier part
-        const float pll_err = __fdiv_rn(atanf(__fdiv_rn(v[1], v[0])), 2.0f * GM_PI_F);
+        const float pll_err = __fdiv_rn(atanf_glibc(__fdiv_rn(v[1], v[0])), 2.0f * GM_PI_F);   // f32::atan = the host libm's atanf (gm_libm.h)
         o.carrier_nco = loop_filter_update(cfg.pll_dt_tau1, cfg.pll_tau2_tau1, pll_err, s.carrier_error);
         o.carrier_error = pll_err;
         o.carrier_freq = s.carrier_freq + o.carrier_nco;
@@ -354,8 +355,8 @@ __device__ __forceinline__ CodeHalf code_half(const TrkDevCfg& cfg, const gm_trk
     if (mode != TRK_MODE_DO_WORK) return o;
     const bool locked = trk_locked(cfg, v[0], v[1]);
     if (locked) {                                        // run_loop_filters (:279-302), code part
-        const float pow_e = __fsqrt_rn(v[2] * v[2] + v[3] * v[3]);
-        const float pow_l = __fsqrt_rn(v[4] * v[4] + v[5] * v[5]);
+        const float pow_e = sqrt_rn(v[2] * v[2] + v[3] * v[3]);     // f32::sqrt is correctly rounded (gm_libm.h)
+        const float pow_l = sqrt_rn(v[4] * v[4] + v[5] * v[5]);
         const float dll_err = ((pow_e + pow_l) != 0.0f) ? __fdiv_rn(pow_e - pow_l, pow_e + pow_l) : 0.0f;
         o.code_nco = loop_filter_update(cfg.dll_dt_tau1, cfg.dll_tau2_tau1, dll_err, s.code_error);
         o.code_error = dll_err;

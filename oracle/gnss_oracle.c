@@ -811,9 +811,10 @@ int orc_trk_update_ex(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch
  * computed from the channel's own state (-> computed10, what the device's correlator sums are compared with), but the
  * lock decision, the loop filters and i/q_prompt then use forced10 (the device's sums of that epoch).  By induction the
  * channel state entering every epoch is bit-for-bit what a device that does the reference's scalar arithmetic exactly
- * must hold, so (a) every epoch's sums are compared from IDENTICAL inputs, and (b) the final state must match exactly. */
+ * must hold, so (a) every epoch's sums are compared from IDENTICAL inputs, and (b) the final state must match exactly.
+ * computed64 (may be NULL): the same per-sample f32 products accumulated in double. */
 int orc_trk_update_forced(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float computed10[10],
-                          const float forced10[10], uint8_t *msg_prn) {
+                          double computed64[10], const float forced10[10], uint8_t *msg_prn) {
     if (!orc_trk_is_active(c)) return 0;
     const float lenf = c->custom_codes ? (float)c->code_len : 1023.0f;
     if (!c->custom_codes && (c->prn < 1 || c->prn > 32)) return -1;
@@ -821,7 +822,7 @@ int orc_trk_update_forced(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scr
     uint64_t head = orc_ring_get_head(ring);
     if ((int64_t)(head - (c->next_sample_index + c->num_samples_per_code)) < 0) return 0;
     orc_ring_copy_to_slice(ring, c->next_sample_index, scratch, (size_t)c->num_samples_per_code);
-    if (orc_trk_early_late_correlation_ex(c, scratch, computed10, NULL)) return -1;
+    if (orc_trk_early_late_correlation_ex(c, scratch, computed10, computed64)) return -1;
     const float *f = forced10;
     c->i_prompt = f[0]; c->q_prompt = f[1];
     float power = f[0] * f[0] + f[1] * f[1];

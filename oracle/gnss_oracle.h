@@ -193,7 +193,7 @@ int orc_trk_update_ex(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch
 /* teacher-forced variant for multi-epoch parity tests: sums computed from the channel's state -> computed10; decision,
  * loop filters and i/q_prompt driven by forced10 (see the .c) */
 int orc_trk_update_forced(orc_trk_channel *c, const orc_ring *ring, orc_c32 *scratch, float computed10[10],
-                          const float forced10[10], uint8_t *msg_prn);
+                          double computed64[10], const float forced10[10], uint8_t *msg_prn);
 
 /* ---------------- fine Doppler (src/acquisition/acquisition_bk.rs:215-302, LEGACY file outside the reference's module
  * tree, no test) — SURVEY §8 f3.  PARITY UNPINNED.  Restated on the live path's data: `samples` are the c32 snapshot of

@@ -115,7 +115,7 @@ def lib(native=False):
     L.orc_ring_copy_to_slice.argtypes = [RP, u64, vp, sz]
     L.orc_trk_update.argtypes = [TP, RP, vp, vp, C.POINTER(C.c_uint8)]
     L.orc_trk_update_ex.argtypes = [TP, RP, vp, vp, C.POINTER(C.c_uint8)]
-    L.orc_trk_update_forced.argtypes = [TP, RP, vp, vp, vp, C.POINTER(C.c_uint8)]
+    L.orc_trk_update_forced.argtypes = [TP, RP, vp, vp, vp, vp, C.POINTER(C.c_uint8)]
     L.orc_trk_process_channels.argtypes = [vp, C.c_int, RP, vp, C.c_size_t, C.c_int, C.c_int]
     L.orc_trk_process_channels.restype = C.c_int64
     _libs[key] = L
@@ -386,16 +386,18 @@ class TrackingChannel:
 
 
     def update_forced(self, ring, forced):
-        """Teacher-forced update (see orc_trk_update_forced): -> (rc, computed10, msg); state advanced with `forced`."""
+        """Teacher-forced update (see orc_trk_update_forced): -> (rc, computed10 f32, computed10 f64-accumulated, msg);
+        state advanced with `forced`."""
         scratch = np.zeros(max(int(self.c.num_samples_per_code) * 2, 16), np.complex64)
         out = np.zeros(10, np.float32)
         f = np.zeros(10, np.float32)
         f[:len(forced)] = forced
         mp = C.c_uint8(255)
-        rc = lib().orc_trk_update_forced(C.byref(self.c), C.byref(ring.r), _p(scratch), _p(out), _p(f), C.byref(mp))
+        acc = np.zeros(10, np.float64)
+        rc = lib().orc_trk_update_forced(C.byref(self.c), C.byref(ring.r), _p(scratch), _p(out), _p(acc), _p(f), C.byref(mp))
         if rc < 0:
             raise IndexError("update_forced: the reference would panic")
-        return rc, out, (("SatelliteLost", mp.value) if rc == 2 else None)
+        return rc, out, acc, (("SatelliteLost", mp.value) if rc == 2 else None)
 
 
 def process_channels(channels, ring, max_passes, n_threads=1, native=False):

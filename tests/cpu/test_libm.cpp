@@ -1,0 +1,27 @@
+// tests/cpu/test_libm.cpp — gnss-sdr-rs_amd/csrc/gm_libm.h against the host libm (glibc), bit for bit.
+// The reference's f32::atan (do_tracking.rs:280) is this host function; the device runs gm::atanf_glibc.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include "gm_libm.h"
+
+int main() {
+    unsigned long long bad = 0, n = 0;
+    // every 61st f32 bit pattern (odd stride: all exponents, both signs, ~7.0e7 values) ...
+    for (unsigned long long u = 0; u < 0x100000000ull; u += 61) {
+        const float x = gm::f32_from_bits(uint32_t(u));
+        const float a = gm::atanf_glibc(x), b = atanf(x);
+        const bool same = gm::f32_bits(a) == gm::f32_bits(b) || (a != a && b != b);
+        if (!same && bad++ < 10) printf("MISMATCH x=%a ours=%a libm=%a\n", x, a, b);
+        ++n;
+    }
+    // ... and a dense sweep of the PLL's operating range |q/i| <= 4 (2^24 values)
+    for (unsigned i = 0; i <= (1u << 24); ++i) {
+        const float x = -4.0f + 8.0f * float(i) / float(1u << 24);
+        const float a = gm::atanf_glibc(x), b = atanf(x);
+        if (gm::f32_bits(a) != gm::f32_bits(b) && bad++ < 10) printf("MISMATCH x=%a ours=%a libm=%a\n", x, a, b);
+        ++n;
+    }
+    printf("atanf_glibc: %llu arguments, %llu mismatches\n", n, bad);
+    return bad ? 1 : 0;
+}

@@ -131,6 +131,19 @@ def test_fft_core_cpu_emulation_of_every_plan():
     assert "Plan8000" in r.stdout and "Plan256" in r.stdout and "worst" in r.stdout
 
 
+def test_device_atanf_restatement_matches_host_libm_bit_for_bit():
+    """tests/cpu/test_libm.cpp: gm::atanf_glibc (csrc/gm_libm.h, what the tracking epilogue runs on the device for
+    f32::atan of do_tracking.rs:280) equals this host's atanf on 8.7e7 arguments, bit for bit."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tempfile.mkdtemp(prefix="gm_libm_"), "test_libm")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "gnss-sdr-rs_amd", "csrc"),
+                    os.path.join(root, "tests", "cpu", "test_libm.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
+
+
 def test_rust_binding_source_matches_the_abi(gm):
     """rust/src/mi355x.rs (the reference-side binding shipped as source) cannot be compiled here, so its
     layout is checked structurally: every #[repr(C)] struct lists the same fields in the same order as the ctypes mirror

@@ -11,19 +11,21 @@ Two comparisons per case, both through gm_trk_update_all on the device ring:
     compared with the device's sums of that epoch at 1e-5 of the prompt envelope (north_star's tolerance), and then the
     oracle advances its loop state with the DEVICE's sums (orc_trk_update_forced).  By induction both sides enter every
     epoch with identical state, so 1e-5 holds at EVERY epoch, not just the first, and the final state words must agree:
-    integer bookkeeping exactly, f32 loop state to ATAN_ULPS (the device's atanf and glibc's are both < 1 ulp but not
-    the same function; everything else in the epilogue is IEEE-exact).
+    every word of it, bit for bit (the epilogue is IEEE-exact f32 arithmetic and its one libm call, f32::atan, runs
+    glibc's algorithm on the device: csrc/gm_libm.h).
+    The same sums are also held to 5e-7 of the oracle's f64 accumulation of the same f32 products (the kernel's own
+    error; the rest of the 1e-5 is the reference's sequential f32 summation order).
   * FREE-RUNNING: the oracle's plain update() from the same start.  The sums at epoch e then also carry the loop
     feedback of the earlier epochs' (sub-1e-5) differences: a 1-ulp difference of carrier_freq (2.4e-4 Hz at 3 kHz) turns
-    the carrier by 1.5e-6 rad per epoch and accumulates in carrier_phase, so the bound is FREE_REL = 5e-5 over >= 10 epochs.
+    the carrier by 1.5e-6 rad per epoch and accumulates in carrier_phase, so the bound is FREE_REL = 2.5e-5 over >= 10 epochs (measured: <= 1.3e-5).
 """
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 REL = 1e-5          # north_star: correlator I/Q within 1e-5 relative (to the prompt envelope)
-FREE_REL = 5e-5     # free-running bound (see the module docstring)
-ATAN_ULPS = 4       # f32 loop-state words after >= 10 epochs of teacher-forced updates
+FREE_REL = 2.5e-5     # free-running bound (see the module docstring)
+F64_REL = 5e-7      # against the same per-sample f32 products accumulated in f64: what the kernel's own error is
 
 
 def _acq_result(prn, carrier_freq, fs, idx):
@@ -41,7 +43,7 @@ def _ulps(a, b):
     return abs(ia - ib)
 
 
-def _compare(mgr, ring, oring, starts, make_oracle, arms, epochs_req, epochs_expect):
+def _compare(mgr, ring, oring, starts, make_oracle, arms, epochs_req, epochs_expect, rel=REL, free_rel=FREE_REL):
     """Run update_all once; replay it against teacher-forced and free-running oracle channels."""
     forced, free = [], []
     for i, r in enumerate(starts):
@@ -53,10 +55,10 @@ def _compare(mgr, ring, oring, starts, make_oracle, arms, epochs_req, epochs_exp
     outs, proc, lost, done = mgr.update_all(ring, epochs_req)
     assert done == epochs_expect and not lost.any()
     nv = 2 * arms
-    worst = dict(forced=0.0, free=0.0, ulps=0)
+    worst = dict(forced=0.0, free=0.0, f64=0.0, ulps=0)
     for i in range(len(starts)):
         for ep in range(epochs_req):
-            rc_f, comp, _ = forced[i].update_forced(oring, outs[ep, i])
+            rc_f, comp, comp64, _ = forced[i].update_forced(oring, outs[ep, i])
             rc_r, exp, _ = free[i].update_ex(oring)
             assert (rc_f != 0) == bool(proc[ep, i]) == (rc_r != 0), (i, ep)
             if not rc_f:
@@ -65,9 +67,11 @@ def _compare(mgr, ring, oring, starts, make_oracle, arms, epochs_req, epochs_exp
             assert env > 100.0, (i, ep, env)                      # a signal is under the correlator
             e1 = float(np.max(np.abs(outs[ep, i] - comp[:nv]))) / env
             e2 = float(np.max(np.abs(outs[ep, i] - exp[:nv]))) / float(np.hypot(exp[0], exp[1]))
-            worst["forced"], worst["free"] = max(worst["forced"], e1), max(worst["free"], e2)
-            assert e1 <= REL, ("teacher-forced", i, ep, e1)
-            assert e2 <= FREE_REL, ("free-running", i, ep, e2)
+            e64 = float(np.max(np.abs(outs[ep, i] - comp64[:nv]))) / env
+            worst["forced"], worst["free"], worst["f64"] = max(worst["forced"], e1), max(worst["free"], e2), max(worst["f64"], e64)
+            assert e1 <= rel, ("teacher-forced", i, ep, e1)
+            assert e64 <= F64_REL, ("teacher-forced vs f64 accumulation", i, ep, e64)
+            assert e2 <= free_rel, ("free-running", i, ep, e2)
         s, o = mgr.channels[i].state, forced[i].c
         assert s.next_sample_index == o.next_sample_index == free[i].c.next_sample_index
         assert s.num_samples_per_code == o.num_samples_per_code
@@ -76,12 +80,8 @@ def _compare(mgr, ring, oring, starts, make_oracle, arms, epochs_req, epochs_exp
         for k in ("carrier_freq", "carrier_phase", "carrier_error", "carrier_nco", "code_phase", "code_error", "code_nco",
                   "code_rate"):
             u = _ulps(getattr(s, k), getattr(o, k))
-            if k in ("carrier_phase", "carrier_error", "carrier_nco", "code_error", "code_nco") and u > ATAN_ULPS:
-                # words near zero: compare on the scale of the quantity they feed
-                assert abs(float(getattr(s, k)) - float(getattr(o, k))) <= 1e-6, (i, k, getattr(s, k), getattr(o, k))
-                continue
             worst["ulps"] = max(worst["ulps"], u)
-            assert u <= ATAN_ULPS, (i, k, getattr(s, k), getattr(o, k))
+            assert u == 0, (i, k, getattr(s, k), getattr(o, k))
     return worst
 
 
@@ -144,7 +144,11 @@ def test_cfg5_36_channels_50msps_boc_five_arms(gpu, oracle):
     def mk(i):
         return oracle.TrackingChannel(i, fs, code_index_mode=1, n_arms=5, el_space=0.25, vel_space=0.6, boc11=True,
                                       codes=codes, code_rate=rate)
-    w = _compare(mgr, ring, oring, starts, mk, 5, E, E)
+    # n = 200 000: the sequential f32 sum the oracle inherits from the reference (do_tracking.rs:256-262) carries
+    # ~eps/2 * sqrt(n/3) = 1.5e-5 of the envelope in rounding noise by itself, above north_star's 1e-5.  The device's
+    # tree sum is held to 5e-7 of the f64-accumulated products (F64_REL, as in every other case) and to 4e-5 of the
+    # sequential f32 sum.
+    w = _compare(mgr, ring, oring, starts, mk, 5, E, E, rel=4e-5, free_rel=1e-4)
     print("cfg5", w)
     mgr.close(); ring.close()
 
