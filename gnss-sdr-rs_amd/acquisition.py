@@ -70,7 +70,8 @@ class AcquisitionEngine:
     all AcquisitionWorkers of one stage in one handle."""
 
     def __init__(self, fs, f_if, fft_size, doppler_hz=None, prn_ids=None, n_integrations=LONG_SAMPLES_LENGTH,
-                 tables=None, codes=None, code_rate=1.023e6, threshold=7.0, decision_mode=0, device=None):
+                 tables=None, codes=None, code_rate=1.023e6, threshold=7.0, decision_mode=0, strict_sum_order=False,
+                 device=None):
         _lib.init(device if device is not None else (_lib._initialised or 0))
         self.fs, self.f_if, self.fft_size, self.M = float(fs), float(f_if), int(fft_size), int(n_integrations)
         self.prn_ids = np.ascontiguousarray(prn_ids if prn_ids is not None else np.arange(1, 33), np.uint8)
@@ -95,6 +96,7 @@ class AcquisitionEngine:
             keep.append(cd)
         cfg.threshold = threshold
         cfg.decision_mode = decision_mode
+        cfg.strict_sum_order = int(bool(strict_sum_order))
         self.P = int(cfg.n_prn)
         h = C.c_void_p()
         check(lib().gm_acq_create(C.byref(cfg), C.byref(h)), "gm_acq_create")

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ tw_inv,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
     const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int map_mode,
-    int split_from, int split_k, int split_items, float* __restrict__ split_scratch, uint32_t* __restrict__ split_counter) {
+    int split_from, int split_k, int split_items, float* __restrict__ split_scratch, uint32_t* __restrict__ split_counter,
+    int strict_sum) {
     // XCD-aware tile map: blocks b and b+8 share an XCD (round-robin dispatch, speed only).  The (bin, worker)
     // items are numbered bin-major and every XCD takes one contiguous, EQUAL share of them: the workers of a
     // Doppler bin stay on one XCD (at most two), so that bin's M spectra (M*8N bytes) are served by that XCD's L2,
@@ -299,6 +300,38 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
         }
     }
 
+    // strict_sum_order: is_good_satellite's plane sum in the reference's own order (do_acquisition.rs:229-235): eight
+    // running f32 sums over chunks_exact(8) — lane l adds power[8c + l] for c = 0, 1, ... — then reduce_sum, an ordered
+    // add of the eight lanes starting from -0.0.  The plane goes to LDS once (the transform buffer is free now) and eight
+    // lanes of wave 0 walk it sequentially: N/8 dependent adds (~4 us at N = 8000), paid only when the caller asks for
+    // bit-faithful detector sums; the default is the tree sum below.
+    float strict_total = 0.0f;
+    if (strict_sum) {
+        __syncthreads();
+        float* pl = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int it = 0; it < PL::ITL; ++it) {
+            const int b = tid + it * PL::T;
+            if (b < NBL) {
+#pragma unroll
+                for (int r = 0; r < PL::RL; ++r) pl[b + r * NBL] = acc[it][r];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float ls = 0.0f;                                        // f32x8::splat(0.0)
+            if (tid < 8) {
+                constexpr int CHUNKS = PL::N / 8;                   // chunks_exact(8) drops a tail
+#pragma unroll 8
+                for (int c = 0; c < CHUNKS; ++c) ls = ls + pl[c * 8 + tid];
+            }
+            float t = -0.0f;                                        // simd_reduce_add_ordered(v, -0.0)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) t = t + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ls), l));
+            strict_total = t;
+        }
+    }
+
     // per-lane: first strict maximum + partial sum
     float bv = 0.0f, sum = 0.0f;
     uint32_t bi = 0xffffffffu;
@@ -336,7 +369,7 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
         for (int w = 1; w < NW; ++w) { take_better(fv, fi, sv[w], si[w]); fs += ss[w]; }
         if (fi == 0xffffffffu) fi = 0;   // all-NaN plane: the reference keeps (0.0, 0)
         const size_t o = size_t(p) * n_bins + d;
-        mmax[o] = fv; margmax[o] = fi; msum[o] = fs;
+        mmax[o] = fv; margmax[o] = fi; msum[o] = strict_sum ? strict_total : fs;
     }
 }
 
@@ -565,7 +598,7 @@ template <class PL> struct Launch {
     static constexpr int SPLIT_SLAB = (PL::RL % 4 == 0) ? PL::ITL * PL::RL * PL::T : 0;   // floats per partial plane
     static void corr(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
-                     int n_int, float* split_scratch, uint32_t* split_counter) {
+                     int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum) {
         if (n_workers <= 0) return;
         // Tile map: whole Doppler bins per XCD (best L2 locality) unless that costs an XCD an extra round of
         // workgroups (2 x 32 resident per XCD) compared with equal shares of the item list.  Measured on configs[1]
@@ -588,7 +621,8 @@ template <class PL> struct Launch {
         static const int split_env = getenv("GM_CORR_SPLIT") ? atoi(getenv("GM_CORR_SPLIT")) : -1;
         static const int items_env = getenv("GM_CORR_SPLIT_ITEMS") ? atoi(getenv("GM_CORR_SPLIT_ITEMS")) : -1;
         int split_from = share, split_k = 1, split_items = 0;
-        if (SPLIT_SLAB && split_scratch && split_counter && split_env != 0 && !g_corr_stamps_armed &&
+        // (strict_sum_order also keeps the reference's sequential accumulation over the integrations: no split)
+        if (SPLIT_SLAB && split_scratch && split_counter && split_env != 0 && !g_corr_stamps_armed && !strict_sum &&
             (share > slots || share <= GM_CORR_SPLIT_MAX_ITEMS / 8)) {
             // share <= slots: the whole grid is resident at once and (for few workers, e.g. the reference's single-PRN
             // search) leaves most of the chip idle: then EVERY item is cut, which multiplies the parallelism by k
@@ -608,11 +642,11 @@ template <class PL> struct Launch {
         if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
             hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, true>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
-                               split_from, split_k, split_items, split_scratch, split_counter);
+                               split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
         else
             hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, false>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
-                               split_from, split_k, split_items, split_scratch, split_counter);
+                               split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
     }
     static void code_fft(hipStream_t st, const int8_t* code_samples, const cf* tw_fwd, cf* out, int n_codes) {
         hipLaunchKernelGGL(acq_code_fft_kernel<PL>, dim3(n_codes), dim3(PL::T), 0, st, code_samples, tw_fwd, out);

@@ -427,6 +427,8 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
             }
     }
     if (!pl) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this fft_size, nor for fft_size / 2..8");
+    if (cfg->strict_sum_order && comp_q > 1)
+        return set_err(GM_ERR_INVALID_ARG, "strict_sum_order needs an fft_size with an in-LDS plan (gm_fft_supported_sizes)");
     if (int rc = ensure_device(g_device)) return rc;
 
     gm_acq* a = new gm_acq();
@@ -569,7 +571,7 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     if (a->Q == 1) {
         a->plan->corr(a->stream, a->d_spectra, a->d_code_fft, a->d_tw_inv, reinterpret_cast<float*>(met), met + PD,
                       reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M),
-                      a->d_split_scratch, a->d_split_counter);
+                      a->d_split_scratch, a->d_split_counter, a->cfg.strict_sum_order ? 1 : 0);
     } else if (a->n_workers) {
         const uint32_t n_dm = a->D * a->M;
         a->plan->comp_corr_fft(a->stream, a->d_spectra, a->d_code_fft, a->d_tw_inv, a->d_comp_y, a->d_worker_list, a->Q, n_dm,

@@ -39,7 +39,7 @@ struct PlanOps {
     // {max, first argmax, sum} per (worker, bin)  (do_acquisition.rs:184-202, 229-235)
     void (*corr)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                  uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
-                 int n_int, float* split_scratch, uint32_t* split_counter);
+                 int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum);
     // AcquisitionWorker::new's replica spectrum (do_acquisition.rs:132-138)
     void (*code_fft)(hipStream_t, const int8_t* code_samples, const cf* tw_fwd, cf* code_fft, int n_codes);
     // FFT<T>::execute (fft.rs:21-25) on `batch` contiguous transforms

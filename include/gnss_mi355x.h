@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GM_ABI_VERSION 1
+#define GM_ABI_VERSION 2
 
 typedef enum {
     GM_OK = 0,
@@ -120,6 +120,11 @@ typedef struct {
                                   (the reference's early exit, :211-222).  GM_DECIDE_BEST_BIN (1): strongest bin of the
                                   whole grid, reported if IT passes the ratio test — not the reference's behaviour; for
                                   callers that hand the carrier to a PLL (a strong signal passes the test 1-2 kHz early) */
+    int32_t strict_sum_order;  /* 0: the plane sum of is_good_satellite (:229-235) is a per-lane + shuffle-tree sum (within
+                                  ~2e-6 of the reference's, FFT rounding aside).  1: summed in the reference's own order —
+                                  eight running f32 sums over chunks_exact(8), then reduce_sum from -0.0 — and the
+                                  integrations accumulated strictly in sequence (no grid-tail split); costs ~4 us per
+                                  (worker, bin) workgroup.  In-LDS sizes only (fft_size one of gm_fft_supported_sizes()). */
 } gm_acq_cfg;
 typedef enum { GM_DECIDE_REFERENCE = 0, GM_DECIDE_BEST_BIN = 1 } gm_decision_mode;
 

@@ -28,6 +28,7 @@ pub struct GmAcqCfg {               // gm_acq_cfg
     pub n_prn: u32, pub prn_ids: *const u8, pub codes: *const i8, pub code_len: u32, pub code_rate: f32,
     pub threshold: f32,
     pub decision_mode: i32,          // 0 = the reference's early exit (GM_DECIDE_REFERENCE), 1 = strongest bin
+    pub strict_sum_order: i32,       // 1 = is_good_satellite's sum in the reference's 8-lane order (do_acquisition.rs:229-235)
 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct GmTrkState {             // gm_trk_state  <->  the evolving fields of TrackingChannel (do_tracking.rs:88-116)
@@ -103,7 +104,7 @@ impl AcquisitionEngine {
         let cfg = GmAcqCfg { fs, f_if, fft_size: fft_size as u32, n_integrations: n_int as u32,
             n_bins: doppler_hz.len() as u32, doppler_hz: doppler_hz.as_ptr(), tables: std::ptr::null(),
             table_freq: std::ptr::null(), n_prn: prn_ids.len() as u32, prn_ids: prn_ids.as_ptr(),
-            codes: std::ptr::null(), code_len: 0, code_rate: 0.0, threshold: 7.0, decision_mode: 0 };
+            codes: std::ptr::null(), code_len: 0, code_rate: 0.0, threshold: 7.0, decision_mode: 0, strict_sum_order: 0 };
         let mut h = std::ptr::null_mut();
         if unsafe { gm_acq_create(&cfg, &mut h) } != 0 { return Err(AcqError); }
         Ok(Self { h, n_prn: prn_ids.len() })

@@ -1,0 +1,123 @@
+"""The reference's own synthetic tracking tests, replayed: test_pll_frequency_pull_in (do_tracking.rs:464-570) and
+test_dll_code_phase_tracking (:572-655), on generate_synthetic_signal (:434-462) restated bit for bit
+(tests/golden/make_tracking_synthetic.py -> tests/golden/tracking_synthetic.npz).
+
+They are the only known answers for the tracking channel the reference holds that do not need the missing capture.  They
+run in FAITHFUL code-index mode (GPS_CA_CODE_32_PRN[prn], saturating late-arm index: the arithmetic as written), with
+the one documented deviation that update()'s sample buffer is sized (as committed, `data_samples[0..n]` slices an empty Vec
+and panics: SURVEY §4).  The reference's assertions are kept verbatim except
+    assert!((true_doppler - err2).abs() < (true_doppler - err1).abs())          (:547, :570)
+which compares a frequency in Hz (3000) with a phase error in cycles (~0.01): it holds or fails by accident of sign and
+says nothing about pull-in (SURVEY §4 "vacuous"); it is evaluated and reported, not asserted.
+
+CPU part: the oracle.  GPU part (-m gpu): the same sequence through the C ABI (device ring mirror + gm_trk_update_all),
+against the committed vectors and, teacher-forced, against the oracle with every state word compared bit for bit.
+"""
+import hashlib
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REL = 1e-5
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("make_tracking_synthetic", os.path.join(HERE, "golden", "make_tracking_synthetic.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _fixture():
+    return np.load(os.path.join(HERE, "golden", "tracking_synthetic.npz"))
+
+
+@pytest.mark.parametrize("name", ["pll", "dll"])
+def test_generator_reproduces_the_committed_signal(oracle, name):
+    g, fx = _gen(), _fixture()
+    sc = g.scenario(oracle, name)
+    sig = sc["signal"]
+    assert sig.size == 4096 and sig.dtype == np.complex64
+    assert hashlib.sha256(sig.tobytes()).hexdigest() == hashlib.sha256(fx[name + "_signal"].tobytes()).hexdigest()
+    # noise-free, unit-modulus: code_val = +-1 times (cos, sin)
+    assert np.allclose(np.abs(sig), 1.0, atol=1e-6)
+    if name == "dll":          # doppler 0, phase 0 -> purely real +-1
+        assert (sig.imag == 0).all() and set(np.unique(sig.real)) == {-1.0, 1.0}
+
+
+def _reference_asserts(name, recs, n_sig):
+    """The assertions of do_tracking.rs:503-569 / :613-654 on the records of the three update() calls."""
+    r1, r2, r3 = recs
+    assert r1["head"] == n_sig                                                  # :477 / :585
+    if name == "pll":
+        assert r1["carrier_error"] > 0.0                                        # :503-507 "Discriminator failed"
+        assert r1["carrier_nco"] > 0.0                                          # :509-513 "Filter failed"
+        assert r1["carrier_freq"] > 2950.0                                      # :515-519 "State update failed"
+    assert r2["head"] == 3 * n_sig                                              # :524 / :610
+    assert r1["next_sample_index"] == r1["num_samples_per_code"]                # :525 / :611
+    assert r3["head"] == 4 * n_sig                                              # :551 / :635
+    assert r2["next_sample_index"] == r1["num_samples_per_code"] + r2["num_samples_per_code"]     # :552-555 / :636-639
+    assert r3["next_sample_index"] == r2["next_sample_index"] + r3["num_samples_per_code"]        # :565-568 / :650-653
+
+
+@pytest.mark.parametrize("name", ["pll", "dll"])
+def test_reference_synthetic_tests_through_the_oracle(oracle, name):
+    g, fx = _gen(), _fixture()
+    sc = g.scenario(oracle, name)
+    recs = g.replay_oracle(oracle, sc)
+    _reference_asserts(name, recs, sc["signal"].size)
+    if name == "pll":   # the Hz-vs-cycles comparisons (:547, :570): evaluated for the record only
+        e = [float(r["carrier_error"]) for r in recs]
+        print("vacuous asserts would read:", abs(3000.0 - e[1]) < abs(3000.0 - e[0]), abs(3000.0 - e[2]) < abs(3000.0 - e[1]))
+    # frozen restatement outputs (regression guard of the oracle; the GPU test checks the device against the same file)
+    for k, r in enumerate(recs):
+        assert (r["out"] == fx[name + "_out"][k]).all()
+        assert [r["head"], r["next_sample_index"], r["num_samples_per_code"]] == fx[name + "_index"][k].tolist()
+        assert (np.array([r[w] for w in g.STATE_WORDS], np.float32).view(np.uint32) ==
+                fx[name + "_state"][k].view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pll", "dll"])
+def test_reference_synthetic_tests_through_the_hip_path(gpu, oracle, name):
+    from gnss_sdr_rs_amd import tracking as T
+    g, fx = _gen(), _fixture()
+    sc = g.scenario(oracle, name)
+    sig, fs = sc["signal"], sc["fs"]
+    ring, oring = T.MulticastRingBuffer(sc["ring"]), oracle.MulticastRingBuffer(sc["ring"])
+    mgr = T.TrackingManager(fs, n_channels=4, code_index_mode=T.CODE_INDEX_FAITHFUL)
+    ch = mgr.channels[sc["ch_id"]]
+    forced = oracle.TrackingChannel(sc["ch_id"], fs, code_index_mode=oracle.CODE_INDEX_FAITHFUL)
+    r0 = dict(prn=sc["prn"], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=sc["start_freq"], fs=fs,
+              mag_relative=10.0, sample_global_index=0, doppler_bin=0)
+    ch.start(r0)
+    forced.start(r0)
+    recs = []
+    for k, writes in enumerate((1, 2, 1)):
+        for _ in range(writes):
+            ring.write_samples(sig)          # the DLL test's ring holds 2 ms: the third and fourth writes wrap (:581, :608-609)
+            oring.write_samples(sig)
+        outs, proc, lost, done = mgr.update_all(ring, 1)
+        assert done == 1 and proc[0, sc["ch_id"]] and proc.sum() == 1 and not lost.any()
+        got = outs[0, sc["ch_id"]]
+        s = ch.state
+        recs.append(dict(out=got, head=ring.get_head(), next_sample_index=s.next_sample_index,
+                         num_samples_per_code=s.num_samples_per_code, carrier_error=s.carrier_error,
+                         carrier_nco=s.carrier_nco, carrier_freq=s.carrier_freq))
+        # correlator sums: within 1e-5 of the prompt envelope of the committed restatement output (oracle-free) ...
+        exp = fx[name + "_out"][k]
+        env = float(np.hypot(exp[0], exp[1]))
+        if k == 0:     # later epochs start from loop state that already carries the first epoch's rounding differences
+            assert np.max(np.abs(got - exp)) <= REL * env, (k, got, exp)
+        # ... and of the teacher-forced oracle at EVERY epoch, whose state must then equal the device's bit for bit
+        rc, comp, comp64, _ = forced.update_forced(oring, got)
+        assert rc == 1
+        assert np.max(np.abs(got - comp[:6])) <= REL * float(np.hypot(comp[0], comp[1])), (k, got, comp)
+        for w in g.STATE_WORDS:
+            assert np.float32(getattr(s, w)).view(np.uint32) == np.float32(getattr(forced.c, w)).view(np.uint32), (k, w)
+        assert s.next_sample_index == forced.c.next_sample_index and s.num_samples_per_code == forced.c.num_samples_per_code
+    _reference_asserts(name, recs, sig.size)
+    mgr.close(); ring.close()
