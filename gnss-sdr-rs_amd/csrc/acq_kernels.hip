@@ -79,6 +79,50 @@ __device__ __forceinline__ cf buf_load_cf(__amdgpu_buffer_rsrc_t rsrc, int voff_
     return cf_make(__uint_as_float(v.x), __uint_as_float(v.y));
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Paired layout of the stage F -> stage C spectra and of the code spectra the correlation kernel reads.
+// Lane b of pass 0 of the inverse transform consumes elements b + r*NB0, r = 0..R0-1.  With 8-byte elements stored in
+// natural order that is R0 8-byte loads per lane, and pass 0 is bound by the texture-address path (an 8-byte-per-lane
+// load moves half the bytes of a 16-byte one per issue slot: configs[1] 213 -> 190 us per launch with pairs).  So the
+// elements of one lane are stored two by two: position of natural index k = b + r*NB0 is
+//     r < 2*(R0/2):  ((r/2)*NB0 + b)*2 + (r & 1)        [R0/2][NB0][2]  -> one 16-byte load per pair, coalesced over b
+//     r = R0-1, R0 odd:  2*(R0/2)*NB0 + b                 [NB0]           -> one 8-byte load
+// Only acq_mix_fft_kernel (writer), pair_codes_kernel (writer) and acq_corr_kernel (reader) know this layout.
+// Plans whose first radix is too large for both arrays' pass-0 elements to sit in registers at once (R0 = 31, 32, 33: the
+// hoisted loads cost Plan16368 20 % at 167 VGPRs) keep the natural order and the element-by-element loads.
+template <class PL> struct PairLayout {
+    static constexpr int R0 = PL::R0, NB0 = PL::NB(0), NPAIR = R0 / 2;
+    static constexpr bool PAIRED = R0 <= 25;
+    static __host__ __device__ __forceinline__ int pos(int k) {
+        if constexpr (!PAIRED) return k;
+        const int r = k / NB0, b = k - r * NB0;
+        return r < 2 * NPAIR ? ((r >> 1) * NB0 + b) * 2 + (r & 1) : 2 * NPAIR * NB0 + b;
+    }
+};
+
+template <class PL> struct CorrLayout { static constexpr bool CODE_PAIRED = PairLayout<PL>::PAIRED; };
+
+// one lane's pass-0 elements of one paired array, in registers: R0/2 16-byte loads (+ one 8-byte load when R0 is odd)
+template <class PL> struct PairLoad {
+    static constexpr int NPAIR = PL::R0 / 2, NB0 = PL::NB(0);
+    static constexpr bool ODD = (PL::R0 & 1) != 0;
+    u32x4 q[NPAIR > 0 ? NPAIR : 1];
+    cf last;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int b, int base_elems) {
+        const int oob = 0x7ffffff0;                         // b >= NB0: out of the descriptor's range -> no request, zeros
+        const int v16 = b < NB0 ? b * 16 : oob, v8 = b < NB0 ? b * 8 : oob;
+#pragma unroll
+        for (int rp = 0; rp < NPAIR; ++rp) q[rp] = __builtin_amdgcn_raw_buffer_load_b128(rs, v16, (base_elems + rp * 2 * NB0) * 8, 0);
+        if constexpr (ODD) last = buf_load_cf(rs, v8, (base_elems + 2 * NPAIR * NB0) * 8);
+    }
+    __device__ __forceinline__ cf get(int r) const {   // r is a compile-time constant after unrolling
+        if (ODD && r == PL::R0 - 1) return last;
+        const u32x4 v = q[r >> 1];
+        return (r & 1) ? cf_make(__uint_as_float(v.z), __uint_as_float(v.w)) : cf_make(__uint_as_float(v.x), __uint_as_float(v.y));
+    }
+};
+
 __device__ __forceinline__ cf load_sample(const void* samples, int fmt, size_t idx) {
     if (fmt == GM_FMT_C32) return reinterpret_cast<const cf*>(samples)[idx];
     if (fmt == GM_FMT_I8_IQ) {
@@ -111,7 +155,7 @@ __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restri
             // multiply_simd_block (doppler_shift.rs:43-58): a*c + (b*d*(-1)), a*d + (b*c*(+1))
             return cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);
         },
-        [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
+        [&](int it, int r, cf val) { dst[PairLayout<PL>::pos((tid + it * PL::T) + r * NBL)] = val; }, lds, tw, tid);   // paired layout
 }
 
 // diagnostic phase stamps of the correlation kernel (gm_acq_debug_stamps): s_memtime of lane 0 of every wave of
@@ -198,15 +242,19 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
 
     // conj(code spectrum) for this lane's pass-0 elements: resident in registers across the m loop
     // when the register budget allows (KEEP_CODE), else re-read from L2 next to the spectrum
+    using PLd = PairLoad<PL>;
+    constexpr bool CODE_PAIRED = CorrLayout<PL>::CODE_PAIRED;    // both arrays paired, or both natural (PairLayout)
     cf cc[KEEP_CODE ? PL::IT0 : 1][KEEP_CODE ? PL::R0 : 1];
     if constexpr (KEEP_CODE) {
 #pragma unroll
         for (int it = 0; it < PL::IT0; ++it) {
             const int b = tid + it * PL::T;
             if (b < NB0) {
+                PLd q;
+                if constexpr (CODE_PAIRED) q.load(crs, b, 0);
 #pragma unroll
                 for (int r = 0; r < PL::R0; ++r) {
-                    const cf c = buf_load_cf(crs, b * 8, r * NB0 * 8);
+                    const cf c = CODE_PAIRED ? q.get(r) : buf_load_cf(crs, b * 8, r * NB0 * 8);
                     cc[it][r] = cf_make(c.x, -c.y);
                 }
             }
@@ -223,12 +271,22 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     const int wv = tid >> 6;
     const int m_per = n_int / parts, m_begin = part * m_per, m_end = m_begin + m_per;
     for (int m = m_begin; m < m_end; ++m) {
+        // all pass-0 loads of this transform are issued here, pairs as 16-byte loads (PairLayout)
+        PLd xq[PL::IT0], cq[(KEEP_CODE || !CODE_PAIRED) ? 1 : PL::IT0];
+#pragma unroll
+        for (int it = 0; it < PL::IT0; ++it) {
+            // no branch around the loads (values that live across control flow made hipcc spill 68 VGPRs): lanes without a
+            // pass-0 butterfly get an offset beyond the descriptor's range, which the buffer unit drops without a memory request
+            const int b = tid + it * PL::T;
+            if constexpr (CODE_PAIRED) xq[it].load(xrs, b, m * PL::N);
+            if constexpr (!KEEP_CODE && CODE_PAIRED) cq[it].load(crs, b, 0);
+        }
         auto in = [&](int it, int r) {
-            const int voff = (tid + it * PL::T) * 8;
-            const cf a = buf_load_cf(xrs, voff, (m * PL::N + r * NB0) * 8);
+            const cf a = CODE_PAIRED ? xq[it].get(r) : buf_load_cf(xrs, (tid + it * PL::T) * 8, (m * PL::N + r * NB0) * 8);
             cf c;
             if constexpr (KEEP_CODE) c = cc[it][r];
-            else { const cf g = buf_load_cf(crs, voff, r * NB0 * 8); c = cf_make(g.x, -g.y); }
+            else if constexpr (CODE_PAIRED) { const cf g = cq[it].get(r); c = cf_make(g.x, -g.y); }
+            else { const cf g = buf_load_cf(crs, (tid + it * PL::T) * 8, r * NB0 * 8); c = cf_make(g.x, -g.y); }
             // result_buf[i] *= conj(code[i])  (:184-186), num-complex Mul, no FMA
             return cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
         };
@@ -257,7 +315,6 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
 
     if constexpr (PL::RL % 4 == 0 && !STAMPS) {
         if (parts > 1) {
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             constexpr int SLAB = PL::ITL * PL::RL * PL::T;                        // floats per partial plane, register order
             const size_t item_slab = (size_t(xcd) * split_items + (slot - split_from)) * parts;
             const __amdgpu_buffer_rsrc_t srs =
@@ -387,6 +444,17 @@ __global__ __launch_bounds__(PL::T) void acq_code_fft_kernel(const int8_t* __res
     constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
     lds_transform<PL, false>([&](int it, int r) { return cf_make(float(src[(tid + it * PL::T) + r * NB0]), 0.0f); },
                              [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
+}
+
+// natural-order code spectra [P][N] -> the paired layout acq_corr_kernel reads (once, at gm_acq_create)
+template <class PL>
+__global__ __launch_bounds__(256) void pair_codes_kernel(const cf* __restrict__ nat, cf* __restrict__ paired, int n_codes) {
+    const size_t total = size_t(n_codes) * PL::N;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += size_t(gridDim.x) * 256) {
+        const size_t c = i / PL::N;
+        const int k = int(i - c * PL::N);
+        paired[c * PL::N + PairLayout<PL>::pos(k)] = nat[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------ composite sizes: product + inverse
@@ -651,6 +719,9 @@ template <class PL> struct Launch {
     static void code_fft(hipStream_t st, const int8_t* code_samples, const cf* tw_fwd, cf* out, int n_codes) {
         hipLaunchKernelGGL(acq_code_fft_kernel<PL>, dim3(n_codes), dim3(PL::T), 0, st, code_samples, tw_fwd, out);
     }
+    static void pair_codes(hipStream_t st, const cf* nat, cf* paired, int n_codes) {
+        hipLaunchKernelGGL(pair_codes_kernel<PL>, dim3(n_codes * 4 < 1024 ? n_codes * 4 : 1024), dim3(256), 0, st, nat, paired, n_codes);
+    }
     static void comp_corr_fft(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, cf* z,
                               const uint32_t* worker_list, uint32_t Q, uint32_t n_dm, uint32_t n_workers) {
         hipLaunchKernelGGL(comp_corr_fft_kernel<PL>, dim3(n_workers * n_dm * Q), dim3(PL::T), 0, st, spectra, code_fft, tw_inv,
@@ -669,7 +740,8 @@ template <class PL> struct Launch {
     }
     static constexpr PlanOps ops() {
         return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL), SPLIT_SLAB,
-                       &fill_tw, &mix_fft, &corr, &code_fft, &fft_batch, &comp_corr_fft,
+                       CorrLayout<PL>::CODE_PAIRED ? 1 : 0,
+                       &fill_tw, &mix_fft, &corr, &code_fft, &pair_codes, &fft_batch, &comp_corr_fft,
                        POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr, FineRows<PL>::RT};
     }
 };

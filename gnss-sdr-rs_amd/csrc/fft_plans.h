@@ -30,8 +30,10 @@ using Plan512 = Plan<512, 64, 8, 8, 8>;           // factors of the long fine-Do
 using Plan256 = Plan<256, 64, 16, 16>;
 }  // namespace gm
 
+#ifndef GM_FOR_EACH_PLAN   // tools/corr_lab restricts the list to one plan for fast experimental builds
 #define GM_FOR_EACH_PLAN(X) \
     X(gm::Plan8000) X(gm::Plan16368) X(gm::Plan4096) X(gm::Plan2048) X(gm::Plan1024) \
     X(gm::Plan4000) X(gm::Plan10000) X(gm::Plan12000) X(gm::Plan16000) \
     X(gm::Plan2000) X(gm::Plan5000) X(gm::Plan6000) X(gm::Plan8192) X(gm::Plan15000) X(gm::Plan16384) \
     X(gm::Plan512) X(gm::Plan256)
+#endif

@@ -184,6 +184,7 @@ struct gm_acq {
     std::vector<float> table_freq;
     std::vector<uint8_t> prn_ids, dev_prn_ids;
     cf *d_tables = nullptr, *d_tw_fwd = nullptr, *d_tw_inv = nullptr, *d_code_fft = nullptr, *d_spectra = nullptr;
+    cf* d_code_fft_paired = nullptr;   // Q == 1: the code spectra in the layout acq_corr_kernel reads (PairLayout)
     float* d_table_freq = nullptr;
     int8_t* d_code_samples = nullptr;
     void* d_samples = nullptr;
@@ -399,7 +400,7 @@ int gm_acq_destroy(gm_acq* a) {
     hipFree(a->fine.d_rowmax); hipFree(a->fine.d_rowarg); hipFree(a->fine.d_sat_worker); hipFree(a->fine.d_sat_cp);
     hipFree(a->fine.d_peak_pow); hipFree(a->fine.d_peak_idx);
     if (a->device >= 0) hipSetDevice(a->device);
-    hipFree(a->d_tables); hipFree(a->d_tw_fwd); hipFree(a->d_tw_inv); hipFree(a->d_code_fft);
+    hipFree(a->d_tables); hipFree(a->d_tw_fwd); hipFree(a->d_tw_inv); hipFree(a->d_code_fft); hipFree(a->d_code_fft_paired);
     hipFree(a->d_spectra); hipFree(a->d_table_freq); hipFree(a->d_code_samples); hipFree(a->d_samples);
     hipFree(a->d_metrics); hipFree(a->d_worker_list); hipFree(a->d_results); hipFree(a->d_found);
     hipFree(a->d_prn_ids);
@@ -514,6 +515,8 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     // replica spectra: forward FFT of the resampled code (:136-138)
     if (a->Q == 1) {
         pl->code_fft(a->stream, a->d_code_samples, a->d_tw_fwd, a->d_code_fft, int(P));
+        HIPA(hipMalloc(&a->d_code_fft_paired, P * N * 8));
+        pl->pair_codes(a->stream, a->d_code_fft, a->d_code_fft_paired, int(P));
     } else {     // same two steps as the signal, so the spectra share its decimated bin order
         gm::launch_comp_pre(a->stream, nullptr, GM_FMT_C32, nullptr, a->d_code_fft, a->Q, a->Nb, 1, uint32_t(P), a->d_code_samples);
         pl->fft_batch(a->stream, a->d_code_fft, a->d_tw_fwd, 0, int(P * a->Q));
@@ -569,7 +572,7 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     }
     if (t) HIPC(hipEventRecord(ev[1], a->stream));
     if (a->Q == 1) {
-        a->plan->corr(a->stream, a->d_spectra, a->d_code_fft, a->d_tw_inv, reinterpret_cast<float*>(met), met + PD,
+        a->plan->corr(a->stream, a->d_spectra, a->plan->code_paired ? a->d_code_fft_paired : a->d_code_fft, a->d_tw_inv, reinterpret_cast<float*>(met), met + PD,
                       reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M),
                       a->d_split_scratch, a->d_split_counter, a->cfg.strict_sum_order ? 1 : 0);
     } else if (a->n_workers) {

@@ -30,18 +30,22 @@ struct PlanOps {
     int tw_total;      // base-twiddle table entries (per direction)
     int lds_bytes;     // static LDS per workgroup of the correlation kernel
     int split_slab;    // floats of one partial power plane of the tail split (0: this plan cannot split)
+    int code_paired;   // 1: corr() takes the code spectra in the paired layout (pair_codes), 0: in natural order
     void (*fill_tw)(cf* tw, bool inverse);
     // stage F: carrier mix (apply_doppler_shift, doppler_shift.rs:25-58) fused into the forward FFT
     // (do_acquisition.rs:177-182).  One workgroup per (doppler bin, ms block); shared by all PRNs.
     void (*mix_fft)(hipStream_t, const void* samples, int fmt, const cf* tables, const cf* tw_fwd,
                     cf* spectra, int n_bins, int n_int);
-    // stage C: x conj(code spectrum) -> inverse FFT -> |.|^2 accumulated over the integrations ->
+    // stage C (spectra and code_fft in the PAIRED layout): x conj(code spectrum) -> inverse FFT -> |.|^2 accumulated over the integrations ->
     // {max, first argmax, sum} per (worker, bin)  (do_acquisition.rs:184-202, 229-235)
     void (*corr)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                  uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
                  int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum);
     // AcquisitionWorker::new's replica spectrum (do_acquisition.rs:132-138)
     void (*code_fft)(hipStream_t, const int8_t* code_samples, const cf* tw_fwd, cf* code_fft, int n_codes);
+    // the same spectra re-stored in the paired layout stage C reads (PairLayout in acq_kernels.hip); stage F writes its
+    // spectra in that layout directly
+    void (*pair_codes)(hipStream_t, const cf* natural, cf* paired, int n_codes);
     // FFT<T>::execute (fft.rs:21-25) on `batch` contiguous transforms
     void (*fft_batch)(hipStream_t, cf* data, const cf* tw, int inverse, int batch);
     // composite sizes (N = Q * n): inverse transforms with the x conj(code spectrum) product fused into their loads
