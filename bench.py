@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (256 CUs x 4 SIMD-32 x 2 flop x 2.4 GHz)
+VALU_NS_PER_WAVE_INST = 1.02    # measured: one wave64 f32 VALU instruction per SIMD per 1.0-1.1 ns at 4 waves/SIMD (tools/ubench/valu_forms)
 
 
 def gold_codes(delays):
@@ -208,13 +210,38 @@ def main():
     mix_bytes = D * M * N * (2 + 8)
     corr_s = tsum["avg_corr_ms"] * 1e-3
     achieved = corr_bytes / corr_s / 1e9 if corr_s > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("acq_corr_kernel_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # measured fabric traffic and SQ counters of this kernel: collected by separate rocprofv3 --pmc passes of this same
+    # command (tools/profile_round.sh) and committed under profiles/ — read from there, not measured by this run
+    traffic, sq = None, None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("acq_corr_kernel_hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["gm::acq_corr_kernel"]
+    except Exception:
+        sq = None
+    n_transforms = P * D * M
+    # useful flops per launch: 5 N log2 N per transform (the usual FFT convention) + 6 N (x conj(code), num-complex order)
+    # + 4 N (|.|^2 and the accumulation)
+    flops = n_transforms * (5.0 * N * np.log2(N) + 10.0 * N)
+    compute = {"bound": "valu-f32", "achieved": flops / corr_s / 1e12 if corr_s > 0 else 0.0, "peak": FP32_VALU_PEAK_TFLOPS,
+               "unit": "TFLOP/s", "flops_per_launch": flops, "transforms_per_launch": n_transforms,
+               "flop_model": "5*N*log2(N) + 10*N per inverse transform of N = %d" % N}
+    compute["frac"] = compute["achieved"] / FP32_VALU_PEAK_TFLOPS
+    if sq and corr_s > 0:
+        insts = sq.get("SQ_INSTS_VALU")
+        if insts:
+            compute["valu_wave_insts_per_launch"] = insts
+            compute["valu_wave_insts_per_transform"] = insts / n_transforms
+            # a gfx950 SIMD issues one wave64 f32 VALU instruction per 2 cycles with >= 2 waves resident
+            # (MI355X_MICROARCH.md; tools/ubench/valu_forms: 1.0-1.1 ns per instruction per SIMD at 4 waves, every CU busy)
+            compute["valu_issue_frac"] = insts / 1024.0 * VALU_NS_PER_WAVE_INST * 1e-9 / corr_s
+            compute["valu_issue_model"] = "insts / 1024 SIMDs x %.2f ns (profiles/r02_ubench_valu_forms.txt) / kernel time" % VALU_NS_PER_WAVE_INST
+        for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+            if k in sq:
+                compute[k] = sq[k]
+        compute["counters_source"] = "profiles/sq_counters.json (rocprofv3 --pmc passes of this command, per-launch averages)"
     out = {
         "metric": "acq PRN×Doppler cells/s + tracking ch×Msps at 1/2/4/8 GPU; % HBM roofline",
         "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -227,6 +254,16 @@ def main():
                    "parallelism": f"prn-shard x{world}", "exchange_overlapped_with_next_dwell": bool(world > 1 and not native_comm and overlap["on"]), "exchange": ("gm_comm (RCCL via the C ABI)" if native_comm else "torch.distributed nccl" if world > 1 else None), "detections_ok": bool(detections_ok)},
         "roofline": {"bound": "hbm", "kernel": "acq_corr_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command)",
+                     "traffic_over_algorithmic": (traffic / corr_bytes) if traffic else None,
+                     "fabric_GBs": (traffic / corr_s / 1e9) if (traffic and corr_s > 0) else None,
+                     "fabric_frac_of_hbm_peak": (traffic / corr_s / 1e9 / HBM_PEAK_GBS) if (traffic and corr_s > 0) else None,
+                     "reading": "achieved/frac follow SURVEY 8d's algorithmic-byte model, which counts every worker's re-read of "
+                                "a Doppler bin's spectra (32x) as HBM bytes; on the chip those re-reads are served by the XCD's "
+                                "L2, so frac can pass 1 and says nothing about HBM: the measured fabric traffic is `traffic` "
+                                "(fabric_frac_of_hbm_peak of the 8 TB/s), and the kernel is bound by f32 VALU issue + LDS "
+                                "round trips + workgroup barriers: see `compute`",
+                     "compute": compute,
                      "algorithmic_bytes_per_launch": corr_bytes, "avg_launch_ms": tsum["avg_corr_ms"],
                      "launches_timed": tsum["launches"],
                      "stage_F": {"kernel": "acq_mix_fft_kernel", "algorithmic_bytes_per_launch": mix_bytes,
@@ -237,8 +274,7 @@ def main():
     if rank == 0 and world == 1:
         try:
             c = hbm_ceiling(torch, dev)
-            out["roofline"]["measured_d2d_copy_GBs"] = c
-            out["roofline"]["frac_of_measured_copy"] = achieved / c
+            out["roofline"]["measured_d2d_copy_GBs"] = c      # the measured copy ceiling beside the 8 TB/s peak
         except Exception as e:
             out["roofline"]["measured_d2d_copy_GBs"] = repr(e)
     if rank == 0:
@@ -584,7 +620,7 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0,
         trk_cpu = tracking_cpu_baseline(sc, fs, n, cpu_seconds)
     return {"metric": "tracking ch×Msps", "cpu_baseline": trk_cpu, "value": ch_msps * world, "unit": "ch*Msps", "channels_per_gpu": C,
             "fs_msps": 25.0, "epochs": epochs, "ms_per_epoch": dt / epochs * 1e3, "channels_locked": locked,
-            "roofline": {"bound": "hbm", "kernel": "trk_correlate_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "trk_persistent_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_epoch": bytes_per_epoch}}
 
 

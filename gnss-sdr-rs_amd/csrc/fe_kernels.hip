@@ -135,7 +135,183 @@ __global__ __launch_bounds__(FE_T) void frontend_kernel(FrontendArgs a) {
     if (nco_lane) st.state->phase_accumulator = phase;
     if (dc_lane) { if (dl < 8) st.state->bias_re[dl] = bias; else st.state->bias_im[dl - 8] = bias; }
 }
+// ------------------------------------------------------------------------------------ table-driven fast form
+// The NCO phase chain is data-independent: from phase 0 it is ONE fixed orbit of r -> fract(fl(r + s)), and that orbit is
+// periodic after a few steps with a period of at most 2^23 (measured: 4 ... 8 388 607 steps for front-end settings from
+// 2 to 50 Msps).  gm_frontend builds it once on the host (exactly the f32 operations of the sequential form) and the
+// kernel looks phases up instead of running the chain.  What stays sequential is the DC remover: 16 one-pole recurrences
+// (eight SIMD lanes x I/Q, dc_remove.rs:22-28) that round at every step and depend on the data.  They run on 16 lanes of
+// ONE wave — two dependent VALU operations per 8 samples — and that wave does nothing else:
+//   stage A (waves 1..):  load + convert segment t, xa = x * alpha               -> LDS xa[t & 1][lane][step]
+//   stage B (wave 0):     bias = bias * con + xa, step after step; the bias after every 4th step -> LDS ckpt[(t-1) & 1]
+//   stage C (waves 1..):  segment t-2: each lane takes 4 consecutive steps of one SIMD lane j (re and im), replays them from
+//                         the checkpoint with the same two operations, x - bias, table phase -> LUT index -> gather,
+//                         mix_simd, store
+// One workgroup barrier per segment; the stages of three different segments overlap.  Writing only checkpoints matters:
+// a 16-byte LDS store costs the lone chain wave ~26 cycles (its address and data cross to the LDS at 2 cycles per dword
+// on one half of the path), as much as four chain steps; per 16 steps it now issues 4 reads, 32 VALU and 1 store.
+// LDS rows are padded by 4 floats: the 16 chain lanes read 16 bytes each at a stride of one row (conflict-free over 64 banks).
+constexpr int FF_T = 1024;
+constexpr int FF_SEG = FE_FAST_SEG, FF_STEPS = FF_SEG / 8, FF_ROW = FF_STEPS + 4;
+constexpr int FF_QUADS = FF_STEPS / 4, FF_QROW = FF_QUADS + 4;
+
+template <int FMT>
+__global__ __launch_bounds__(FF_T) void frontend_fast_kernel(FrontendArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_xa[2][16][FF_ROW];
+    __shared__ __attribute__((aligned(16))) float s_ckpt[2][16][FF_QROW];     // bias after quad q of the segment
+    __shared__ float s_start[2][16];                                            // bias entering the segment
+    __shared__ float s_lre[LUT], s_lim[LUT];
+    const int tid = threadIdx.x;
+    const FrontendArgs::Stream st = a.streams ? a.streams[blockIdx.x] : a.one;
+    for (int i = tid; i < LUT; i += FF_T) { s_lre[i] = a.lut[i]; s_lim[i] = a.lut[LUT + i]; }
+    const size_t n8 = st.n_samples & ~size_t(7);          // chunks_exact_mut(16 floats) (frontend.rs:35)
+    const int nseg = int((n8 + FF_SEG - 1) / FF_SEG);
+    const float alpha = a.alpha, con = a.con;
+    const bool chain_wave = tid < 64;
+    const int hl = tid - 64, HT = FF_T - 64;               // helper lane index / count
+    float bias = 0.0f;
+    if (tid < 16) bias = tid < 8 ? st.state->bias_re[tid] : st.state->bias_im[tid - 8];
+
+    // stage A operands of the next iteration, requested one iteration ahead (their latency overlaps work and barrier)
+    constexpr int UA = (FF_SEG + (FF_T - 64) - 1) / (FF_T - 64);
+    float nar[UA], nai[UA];
+    auto stage_a_loads = [&](int tt) {
+        const bool dA = tt < nseg;
+        const size_t sA = size_t(dA ? tt : 0) * FF_SEG;
+        const int lA = dA ? int(n8 - sA < size_t(FF_SEG) ? n8 - sA : size_t(FF_SEG)) : 0;
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int i = hl + u * HT;
+            nar[u] = nai[u] = 0.0f;
+            if (i < lA) load_sample<FMT>(st.in, sA + i, nar[u], nai[u]);
+        }
+    };
+    // stage C operands likewise: item = (quad q, SIMD lane j) of segment tt - 2; one item per helper lane (FE_FAST_SEG)
+    static_assert(FF_QUADS * 8 <= FF_T - 64, "one stage-C item per helper lane");
+    float nxr[4], nxi[4], nph[4];
+    auto stage_c_loads = [&](int tt) {
+        const int scn = tt - 2;
+        const bool dC = scn >= 0 && scn < nseg;
+        const size_t sC = size_t(dC ? scn : 0) * FF_SEG;
+        const int stepsC = dC ? int((n8 - sC < size_t(FF_SEG) ? n8 - sC : size_t(FF_SEG)) / 8) : 0;
+        // table index of the segment's first sample: tab_pos + sC, folded back into [0, tab_len)
+        uint64_t p0 = uint64_t(st.tab_pos) + sC;
+        if (p0 >= st.tab_len) p0 = (st.tab_len - st.tab_lambda) + (p0 - (st.tab_len - st.tab_lambda)) % st.tab_lambda;
+        const int j = hl & 7, q = hl >> 3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * q + k, i = 8 * c + j;
+            nxr[k] = nxi[k] = nph[k] = 0.0f;
+            if (c < stepsC) {
+                load_sample<FMT>(st.in, sC + i, nxr[k], nxi[k]);
+                uint32_t p = uint32_t(p0) + uint32_t(i);              // i < FF_SEG <= tab_lambda: one fold at most
+                if (p >= st.tab_len) p -= st.tab_lambda;
+                nph[k] = st.ph_table[p];
+            }
+        }
+    };
+    if (!chain_wave) { stage_a_loads(0); stage_c_loads(0); }
+    __syncthreads();
+
+    for (int t = 0; t < nseg + 2; ++t) {
+        if (chain_wave) {
+            const int sb = t - 1;                          // stage B: the 16 chains over segment sb
+            if (sb >= 0 && sb < nseg && tid < 16) {
+                __builtin_amdgcn_s_setprio(3);             // the chain is the critical path: never queue behind a helper wave
+                const size_t seg = size_t(sb) * FF_SEG;
+                const int steps = int((n8 - seg < size_t(FF_SEG) ? n8 - seg : size_t(FF_SEG)) / 8);
+                const float4* xa4 = reinterpret_cast<const float4*>(&s_xa[sb & 1][tid][0]);
+                float4* ck4 = reinterpret_cast<float4*>(&s_ckpt[sb & 1][tid][0]);
+                s_start[sb & 1][tid] = bias;
+                // con in a VGPR: a VALU instruction with an SGPR source runs at half rate on gfx950 (tools/ubench/valu_forms)
+                float conv = con;
+                asm volatile("" : "+v"(conv));
+                // a lone wave issues one instruction per ~4.5-6 cycles whatever it is: fewest instructions per step
+                auto quad = [&](const float4 v) {
+                    bias = bias * conv + v.x;              // bias = bias * con + input * alpha  (dc_remove.rs:24-25)
+                    bias = bias * conv + v.y;
+                    bias = bias * conv + v.z;
+                    bias = bias * conv + v.w;
+                    return bias;
+                };
+                const int q4 = steps / 4, q16 = q4 / 4;
+                for (int g = 0; g < q16; ++g) {
+                    const float4 v0 = xa4[4 * g], v1 = xa4[4 * g + 1], v2 = xa4[4 * g + 2], v3 = xa4[4 * g + 3];
+                    float4 o;
+                    o.x = quad(v0); o.y = quad(v1); o.z = quad(v2); o.w = quad(v3);
+                    ck4[g] = o;
+                }
+                for (int q = q16 * 4; q < q4; ++q) s_ckpt[sb & 1][tid][q] = quad(xa4[q]);
+                for (int k = q4 * 4; k < steps; ++k) bias = bias * conv + s_xa[sb & 1][tid][k];
+                __builtin_amdgcn_s_setprio(0);
+            }
+        } else {
+            float ar[UA], ai[UA];
+#pragma unroll
+            for (int u = 0; u < UA; ++u) { ar[u] = nar[u]; ai[u] = nai[u]; }
+            const int sc = t - 2;
+            const bool doA = t < nseg, doC = sc >= 0 && sc < nseg;
+            const size_t segA = size_t(doA ? t : 0) * FF_SEG, segC = size_t(doC ? sc : 0) * FF_SEG;
+            const int LA = doA ? int(n8 - segA < size_t(FF_SEG) ? n8 - segA : size_t(FF_SEG)) : 0;
+            const int LC = doC ? int(n8 - segC < size_t(FF_SEG) ? n8 - segC : size_t(FF_SEG)) : 0;
+            stage_a_loads(t + 1);
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {                 // stage A: segment t
+                const int i = hl + u * HT;
+                if (i < LA) {
+                    s_xa[t & 1][i & 7][i >> 3] = ar[u] * alpha;
+                    s_xa[t & 1][8 + (i & 7)][i >> 3] = ai[u] * alpha;
+                }
+            }
+            float xr[4], xi[4], ph[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { xr[k] = nxr[k]; xi[k] = nxi[k]; ph[k] = nph[k]; }
+            stage_c_loads(t + 1);
+            if (doC) {                                     // stage C: segment t - 2, this lane's item (quad q, SIMD lane j)
+                const int stepsC = LC / 8;
+                const int j = hl & 7, q = hl >> 3;
+                if (4 * q < stepsC) {
+                    float bre = q ? s_ckpt[sc & 1][j][q - 1] : s_start[sc & 1][j];
+                    float bim = q ? s_ckpt[sc & 1][8 + j][q - 1] : s_start[sc & 1][8 + j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = 4 * q + k, i = 8 * c + j;
+                        if (c < stepsC) {
+                            bre = bre * con + xr[k] * alpha;               // the chain's own two operations, replayed
+                            bim = bim * con + xi[k] * alpha;
+                            const float re = xr[k] - bre, im = xi[k] - bim;               // input - bias (dc_remove.rs:27)
+                            const uint32_t idx = as_usize_mod_lut(ph[k] * st.tab_scale);   // `phase_accumulator as usize % LUT_SIZE` (:49)
+                            const float lc = s_lre[idx], ls = s_lim[idx];
+                            float2 o;
+                            o.x = re * lc + im * ls;                       // mix_simd nco_lut.rs:8-15
+                            o.y = re * ls - im * lc;
+                            reinterpret_cast<float2*>(st.out)[(st.out_start + segC + i) & st.out_mask] = o;
+                        }
+                    }
+                }
+            }
+        }
+        // workgroup barrier that orders LDS traffic only: the next iteration's global loads (and this one's output stores)
+        // stay in flight across it (__syncthreads() would wait for vmcnt(0))
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    // the tail that chunks_exact leaves untouched: converted, not processed
+    for (size_t i = n8 + tid; i < st.n_samples; i += FF_T) {
+        float2 o;
+        load_sample<FMT>(st.in, i, o.x, o.y);
+        reinterpret_cast<float2*>(st.out)[(st.out_start + i) & st.out_mask] = o;
+    }
+    if (tid == 0) st.state->phase_accumulator = st.ph_table[st.tab_pos_end] * st.tab_scale;   // -0.0 for a negative chain on 0
+    if (tid < 16) { if (tid < 8) st.state->bias_re[tid] = bias; else st.state->bias_im[tid - 8] = bias; }
+}
 }  // namespace
+
+void launch_frontend_fast(hipStream_t s, const FrontendArgs& a, int n_streams, int fmt) {
+    if (fmt == GM_FMT_C32) frontend_fast_kernel<GM_FMT_C32><<<n_streams, FF_T, 0, s>>>(a);
+    else frontend_fast_kernel<GM_FMT_I8_IQ><<<n_streams, FF_T, 0, s>>>(a);
+}
 
 void launch_frontend(hipStream_t s, const FrontendArgs& a, int n_streams, int fmt) {
     if (fmt == GM_FMT_C32) frontend_kernel<GM_FMT_C32><<<n_streams, FE_T, 0, s>>>(a);

@@ -1454,7 +1454,56 @@ struct gm_frontend {
     void* d_raw[gm_ring::SLOTS] = {nullptr, nullptr, nullptr, nullptr};   // raw-format landing zones of the ring writer
     gm::FrontendArgs::Stream* d_batch = nullptr;   // stream descriptors of gm_frontend_process_dev_batch
     uint32_t batch_cap = 0;
+    // tabulated NCO phase orbit (fe_kernels.hip, fast form): built on first use
+    bool tab_tried = false, on_orbit = true;       // on_orbit: the device phase_accumulator is entry `pos` of the orbit from 0
+    std::vector<float> tab;                        // |phase| / 2048 before step k, k < mu + lambda'
+    float* d_tab = nullptr;
+    uint32_t tab_mu = 0, tab_lambda = 0;           // lambda' = the period repeated until >= FE_FAST_SEG
+    uint32_t pos = 0;                              // table index of the next sample
 };
+
+// r -> fract(fl(r + s)): the fast form of `(phase + step) % 2048` in revolutions (fe_kernels.hip nco_segment_fast)
+static inline float fe_orbit_step(float r, float s) { const float t = r + s; return t - floorf(t); }
+
+// The orbit of the NCO phase from 0: transient mu and period lambda by Brent's algorithm, then the table.  Only for the
+// settings the sequential kernel's fast form covers (|step| < 2048, not denormal-small); false otherwise or when the
+// orbit is longer than 2^24 + 2^16 steps (never seen: periods are <= 2^23).
+static bool frontend_build_table(gm_frontend* f) {
+    if (f->tab_tried) return !f->tab.empty();
+    f->tab_tried = true;
+    const float step = f->phase_step;
+    if (!(fabsf(step) < 2048.0f) || !(step == 0.0f || fabsf(step) > 1.0e-20f)) return false;
+    const float s = fabsf(step) * (1.0f / 2048.0f);
+    const uint64_t cap = (1ull << 24) + (1ull << 16);
+    uint64_t power = 1, lam = 1;
+    float tort = 0.0f, hare = fe_orbit_step(0.0f, s);
+    while (tort != hare) {
+        if (power == lam) { tort = hare; power *= 2; lam = 0; }
+        hare = fe_orbit_step(hare, s);
+        if (++lam > cap) return false;
+    }
+    uint64_t mu = 0;
+    tort = hare = 0.0f;
+    for (uint64_t i = 0; i < lam; ++i) hare = fe_orbit_step(hare, s);
+    while (tort != hare) { tort = fe_orbit_step(tort, s); hare = fe_orbit_step(hare, s); if (++mu > cap) return false; }
+    const uint64_t reps = (uint64_t(gm::FE_FAST_SEG) + lam - 1) / lam;
+    const uint64_t lam2 = lam * reps;
+    if (mu + lam2 > cap) return false;
+    f->tab.resize(size_t(mu + lam2));
+    float r = 0.0f;
+    for (size_t k = 0; k < f->tab.size(); ++k) { f->tab[k] = r; r = fe_orbit_step(r, s); }
+    if (hipMalloc(&f->d_tab, f->tab.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(f->d_tab, f->tab.data(), f->tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(f->d_tab); f->d_tab = nullptr; f->tab.clear();
+        return false;
+    }
+    f->tab_mu = uint32_t(mu); f->tab_lambda = uint32_t(lam2);
+    return true;
+}
+static inline uint32_t frontend_fold(const gm_frontend* f, uint64_t p) {
+    const uint64_t len = uint64_t(f->tab_mu) + f->tab_lambda;
+    return uint32_t(p < len ? p : f->tab_mu + (p - f->tab_mu) % f->tab_lambda);
+}
 
 static gm::FrontendArgs::Stream frontend_stream(gm_frontend* f, const void* d_in, void* d_out, uint64_t out_start,
                                                  uint64_t out_mask, size_t n) {
@@ -1462,6 +1511,16 @@ static gm::FrontendArgs::Stream frontend_stream(gm_frontend* f, const void* d_in
     s.in = d_in; s.out = d_out; s.out_start = out_start; s.out_mask = out_mask; s.n_samples = n; s.state = f->d_state;
     s.phase_step = f->phase_step;
     s.fast_fmod = fabsf(f->phase_step) < 2048.0f ? 1 : 0;     // false for NaN too
+    s.ph_table = nullptr;
+    if (f->on_orbit && frontend_build_table(f)) {             // fast form: phases looked up, position tracked on the host
+        const size_t n8 = n & ~size_t(7);
+        s.ph_table = f->d_tab;
+        s.tab_len = f->tab_mu + f->tab_lambda; s.tab_lambda = f->tab_lambda;
+        s.tab_pos = f->pos;
+        s.tab_pos_end = frontend_fold(f, uint64_t(f->pos) + n8);
+        s.tab_scale = f->phase_step < 0.0f ? -2048.0f : 2048.0f;
+        f->pos = s.tab_pos_end;
+    }
     return s;
 }
 
@@ -1471,7 +1530,8 @@ static int frontend_launch(gm_frontend* f, hipStream_t st, const void* d_in, int
     a.streams = nullptr;
     a.one = frontend_stream(f, d_in, d_out, out_start, out_mask, n);
     a.lut = f->d_lut; a.alpha = f->alpha; a.con = f->con;
-    gm::launch_frontend(st, a, 1, fmt);
+    if (a.one.ph_table) gm::launch_frontend_fast(st, a, 1, fmt);
+    else gm::launch_frontend(st, a, 1, fmt);
     HIPC(hipGetLastError());
     return GM_OK;
 }
@@ -1507,7 +1567,7 @@ int gm_frontend_destroy(gm_frontend* f) {
     if (!f) return GM_OK;
     hipSetDevice(f->device);
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
-    hipFree(f->d_lut); hipFree(f->d_state); hipFree(f->d_io); hipFree(f->d_batch);
+    hipFree(f->d_lut); hipFree(f->d_state); hipFree(f->d_io); hipFree(f->d_batch); hipFree(f->d_tab);
     for (void* p : f->d_raw) hipFree(p);
     delete f;
     return GM_OK;
@@ -1542,6 +1602,19 @@ int gm_frontend_set_state(gm_frontend* f, float phase_accumulator, const float b
     memcpy(s.bias_im, bias_im, sizeof(s.bias_im));
     HIPC(hipStreamSynchronize(f->stream));
     HIPC(hipMemcpy(f->d_state, &s, sizeof(s), hipMemcpyHostToDevice));
+    // where on the tabulated orbit is this phase?  (0 = its start; any other value is looked up; a phase that is not on
+    // the orbit from 0 sends this front-end down the sequential kernel from here on)
+    f->on_orbit = false;
+    if (phase_accumulator == 0.0f && !std::signbit(phase_accumulator)) { f->on_orbit = true; f->pos = 0; }
+    else if (frontend_build_table(f)) {
+        const bool neg = f->phase_step < 0.0f;
+        const bool sign_ok = neg ? !(phase_accumulator > 0.0f) : !(phase_accumulator < 0.0f);
+        if (sign_ok && fabsf(phase_accumulator) < 2048.0f) {
+            const float r = fabsf(phase_accumulator) * (1.0f / 2048.0f);
+            for (size_t k = 0; k < f->tab.size(); ++k)
+                if (f->tab[k] == r && (r != 0.0f || std::signbit(phase_accumulator) == neg || k == 0)) { f->on_orbit = true; f->pos = uint32_t(k); break; }
+        }
+    }
     return GM_OK;
 }
 
@@ -1598,7 +1671,10 @@ int gm_frontend_process_dev_batch(gm_frontend* const* fes, uint32_t n_streams, c
     HIPC(hipStreamSynchronize(st));     // the descriptors were read from pageable host memory
     gm::FrontendArgs a{};
     a.streams = f0->d_batch; a.lut = f0->d_lut; a.alpha = f0->alpha; a.con = f0->con;
-    gm::launch_frontend(st, a, int(n_streams), fmt);
+    bool all_fast = true;
+    for (uint32_t i = 0; i < n_streams; ++i) all_fast = all_fast && h[i].ph_table != nullptr;
+    if (all_fast) gm::launch_frontend_fast(st, a, int(n_streams), fmt);
+    else gm::launch_frontend(st, a, int(n_streams), fmt);
     HIPC(hipGetLastError());
     return GM_OK;
 }

@@ -157,6 +157,13 @@ struct FrontendArgs {
         FeState* state;
         float phase_step;          // NcoLut.phase_step of this stream's front-end
         int fast_fmod;             // |phase_step| < 2048: fmodf reduces to one exact conditional add/subtract
+        // tabulated NCO phase orbit (fast kernel; null: the sequential phase chain of frontend_kernel)
+        const float* ph_table;     // |phase_accumulator| / 2048 before step k of the orbit that starts at phase 0
+        uint32_t tab_len;          // entries: transient mu + period lambda' (lambda' = the period repeated to >= FE_FAST_SEG)
+        uint32_t tab_lambda;       // lambda'
+        uint32_t tab_pos;          // table index of this call's first sample (< tab_len)
+        uint32_t tab_pos_end;      // table index after this call's last processed sample
+        float tab_scale;           // +-2048: sign of phase_step
     };
     const Stream* streams;         // device array, one entry (and one workgroup) per stream
     Stream one;                    // used when streams == nullptr (single-stream launches need no upload)
@@ -164,5 +171,9 @@ struct FrontendArgs {
     float alpha, con;
 };
 void launch_frontend(hipStream_t, const FrontendArgs&, int n_streams, int fmt);
+// every stream carries a phase table: the pipelined kernel (DC chains on one wave, everything else data-parallel)
+void launch_frontend_fast(hipStream_t, const FrontendArgs&, int n_streams, int fmt);
+constexpr int FE_FAST_SEG = 3840;      // samples per pipeline segment of the fast kernel: 480 chain steps = 120 quads x 8 SIMD
+                                       // lanes = 960 stage-C items = one per helper lane (the table period is padded to >= this)
 
 }  // namespace gm

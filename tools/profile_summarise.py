@@ -63,3 +63,26 @@ traffic = {
 }
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
+
+
+# SQ / LDS counters (tools/pmc_sq.sh -> gpurun_out/pmc_sq/{a,b,c}): per-launch averages per kernel
+sqdir = os.path.join(root, "gpurun_out", "pmc_sq")
+sq = {}
+for f in glob.glob(os.path.join(sqdir, "*", "*counter_collection.csv")):
+    acc = {}
+    for row in csv.DictReader(open(f)):
+        k = short(row["Kernel_Name"])
+        if not k.startswith("gm::"):
+            continue
+        a = acc.setdefault((k, row["Counter_Name"]), [0, 0.0])
+        a[0] += 1
+        a[1] += float(row["Counter_Value"])
+    for (k, c), (n, v) in acc.items():
+        sq.setdefault(k, {})[c] = v / n
+        sq[k]["launches_" + os.path.basename(os.path.dirname(f))] = n
+if sq:
+    sq["_source"] = ("rocprofv3 --pmc (SQ_* / GRBM_* groups in separate passes, --kernel-trace only) -- python3 bench.py --steps 6 "
+                     "--warmup 2 --no-cpu-baseline; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves")
+    json.dump(sq, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1, sort_keys=True)
+    shutil.copy(os.path.join(dst, "sq_counters.json"), os.path.join(dst, f"{rr}_sq_counters.json"))
+    print("sq counters:", sorted(k for k in sq if not k.startswith("_")))

@@ -42,13 +42,45 @@ add("v_mul_f64 D,A,D", lambda d: f"v_mul_f64 v[{32+2*d}:{33+2*d}], v[{48+2*((d+1
 add("v_rndne_f64 D,A", lambda d: f"v_rndne_f64 v[{32+2*d}:{33+2*d}], v[{48+2*((d+1)%8)}:{49+2*((d+1)%8)}]")
 add("v_cvt_f64_f32 D,a", lambda d: f"v_cvt_f64_f32 v[{32+2*d}:{33+2*d}], v{16+((d+1)%8)}")
 
+add("v_cndmask_b32 d,a,b,s[22:23] (VOP3 sgpr mask)", lambda d: f"v_cndmask_b32 v{8+d}, v{16+((d+1)%8)}, v{24+((d+2)%8)}, s[22:23]")
+add("v_cmp_gt_f32 vcc,a,b (VOPC)", lambda d: f"v_cmp_gt_f32 vcc, v{16+((d+1)%8)}, v{24+((d+2)%8)}")
+add("v_cmp_gt_f32 s[24:25],a,b (VOP3)", lambda d: f"v_cmp_gt_f32 s[24:25], v{16+((d+1)%8)}, v{24+((d+2)%8)}")
+add("v_cmp + v_cndmask pairs (vcc)", lambda d: [f"v_cmp_gt_f32 vcc, v{16+((d+1)%8)}, v{24+((d+2)%8)}", f"v_cndmask_b32 v{8+d}, v{16+((d+1)%8)}, v{24+((d+2)%8)}, vcc"][d % 2])
+add("v_add_u32 d,a,d", lambda d: f"v_add_u32 v{8+d}, v{16+((d+1)%8)}, v{8+d}")
+add("v_and_b32 d,a,d", lambda d: f"v_and_b32 v{8+d}, v{16+((d+1)%8)}, v{8+d}")
+add("v_lshl_add_u64 D,A,3,D", lambda d: f"v_lshl_add_u64 v[{32+2*d}:{33+2*d}], v[{48+2*((d+1)%8)}:{49+2*((d+1)%8)}], 3, v[{32+2*d}:{33+2*d}]")
+add("v_cvt_i32_f32 d,a", lambda d: f"v_cvt_i32_f32 v{8+d}, v{16+((d+1)%8)}")
+add("v_cvt_f32_u32 d,a", lambda d: f"v_cvt_f32_u32 v{8+d}, v{16+((d+1)%8)}")
+add("v_fract_f32 d,a", lambda d: f"v_fract_f32 v{8+d}, v{16+((d+1)%8)}")
+add("v_trunc_f32 d,a", lambda d: f"v_trunc_f32 v{8+d}, v{16+((d+1)%8)}")
+add("v_rndne_f32 d,a", lambda d: f"v_rndne_f32 v{8+d}, v{16+((d+1)%8)}")
+add("v_max_f32 d,a,d", lambda d: f"v_max_f32 v{8+d}, v{16+((d+1)%8)}, v{8+d}")
+add("v_min_i32 d,a,d", lambda d: f"v_min_i32 v{8+d}, v{16+((d+1)%8)}, v{8+d}")
+add("v_med3_f32 d,a,b,d", lambda d: f"v_med3_f32 v{8+d}, v{16+((d+1)%8)}, v{24+((d+2)%8)}, v{8+d}")
+add("v_bfe_i32 d,a,4,8", lambda d: f"v_bfe_i32 v{8+d}, v{16+((d+1)%8)}, 4, 8")
+add("v_mul_lo_u32 d,a,b", lambda d: f"v_mul_lo_u32 v{8+d}, v{16+((d+1)%8)}, v{24+((d+2)%8)}")
+add("v_mad_u32_u24 d,a,b,d", lambda d: f"v_mad_u32_u24 v{8+d}, v{16+((d+1)%8)}, v{24+((d+2)%8)}, v{8+d}")
+add("v_xor_b32 d,a,d", lambda d: f"v_xor_b32 v{8+d}, v{16+((d+1)%8)}, v{8+d}")
+add("v_sin_f32 d,a", lambda d: f"v_sin_f32 v{8+d}, v{16+((d+1)%8)}")
+add("v_rcp_f32 d,a", lambda d: f"v_rcp_f32 v{8+d}, v{16+((d+1)%8)}")
+add("v_sqrt_f32 d,a", lambda d: f"v_sqrt_f32 v{8+d}, v{16+((d+1)%8)}")
+add("v_perm_b32 d,a,b,d", lambda d: f"v_perm_b32 v{8+d}, v{16+((d+1)%8)}, v{24+((d+2)%8)}, v{8+d}")
+add("v_readlane_b32 s26,a,5", lambda d: f"v_readlane_b32 s26, v{16+((d+1)%8)}, 5")
+add("v_mov_b32_dpp row_shr:1", lambda d: f"v_mov_b32_dpp v{8+d}, v{16+((d+1)%8)} row_shr:1 row_mask:0xf bank_mask:0xf")
+add("v_add_f32_dpp row_shr:1", lambda d: f"v_add_f32_dpp v{8+d}, v{16+((d+1)%8)}, v{8+d} row_shr:1 row_mask:0xf bank_mask:0xf")
+# dependent chains (one destination register: the latency of back-to-back dependent instructions of ONE wave)
+add("DEP v_mul d,a,d ; v_add d,b,d (vgpr)", lambda d: [f"v_mul_f32 v8, v16, v8", f"v_add_f32 v8, v24, v8"][d % 2])
+add("DEP v_mul d,s,d ; v_add d,b,d (sgpr con)", lambda d: [f"v_mul_f32 v8, s20, v8", f"v_add_f32 v8, v24, v8"][d % 2])
+add("DEP v_fma d,a,b,d", lambda d: f"v_fma_f32 v8, v16, v24, v8")
+add("DEP v_add d,a,d", lambda d: f"v_add_f32 v8, v16, v8")
+add("DEP 2 chains interleaved mul/add", lambda d: [f"v_mul_f32 v8, v16, v8", f"v_mul_f32 v9, v16, v9", f"v_add_f32 v8, v24, v8", f"v_add_f32 v9, v24, v9"][d % 4])
 UNROLL = 64
 clob = ", ".join(f'"v{i}"' for i in range(8, 80))
 
 src = ['// GENERATED by tools/ubench/gen_valu_forms.py — do not edit.', '#include <hip/hip_runtime.h>', '#include <cstdio>', '#include <vector>', '#include <algorithm>',
        'template <int KIND> __global__ void k(long long* cyc, int iters, float seed) {',
        '    // registers v8..v79 are owned by the asm blocks (declared as clobbers); values stay finite: every source is 1.0 or 0.0',
-       '    asm volatile("s_mov_b32 s20, 1.0" ::: "s20");',
+       '    asm volatile("s_mov_b32 s20, 1.0\\n\\ts_mov_b64 s[22:23], -1" ::: "s20", "s22", "s23");',
        '    for (int r = 8; r < 80; ++r) {}',
        ]
 init = "\\n\\t".join([f"v_mov_b32 v{i}, 0" for i in range(8, 16)] + [f"v_mov_b32 v{i}, 1.0" for i in range(16, 32)] +
@@ -59,7 +91,7 @@ src.append('    asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier\\n\\ts_memtime
 src.append('    for (int i = 0; i < iters; ++i) {')
 for ki, (name, fn) in enumerate(V):
     body = "\\n\\t".join(fn(j % 8) for j in range(UNROLL))
-    src.append(f'        if constexpr (KIND == {ki}) asm volatile("{body}" ::: {clob}, "vcc");')
+    src.append(f'        if constexpr (KIND == {ki}) asm volatile("{body}" ::: {clob}, "vcc", "s20", "s22", "s23", "s24", "s25", "s26");')
 src.append('    }')
 src.append('    asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");')
 src.append('    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = (long long)(t1 - t0);')
