@@ -1210,7 +1210,8 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
         const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
         const int nv = 2 * d.n_arms;
         int g = 1;
-        while (g * 2 <= 32 && size_t(g) * 2 * t->C <= size_t(cus) * gm::TRK_PERSIST_WG_PER_CU && g * 2 * nv <= 256) g *= 2;
+        const int per_cu = gm::trk_persistent_blocks_per_cu(d);      // occupancy of this instantiation, capped at the design's 2
+        while (g * 2 <= 32 && size_t(g) * 2 * t->C <= size_t(cus) * per_cu && g * 2 * nv <= 256) g *= 2;
         t->G = g;
         const size_t xb = size_t(2) * t->C * g * nv * sizeof(unsigned long long);
         HIPT(hipMalloc(&t->d_xchg, xb));
@@ -1346,11 +1347,24 @@ int gm_trk_do_work(gm_trk* t, uint32_t ch, const gm_c32* samples, size_t n, gm_t
     return trk_unit(t, ch, samples, n, gm::TRK_MODE_DO_WORK, out, lost, lost_prn);
 }
 
+// The persistent kernel's workgroups wait for one another, so its whole grid must be resident at once: ONE persistent
+// launch per device at a time.  Launches of different handles (different streams) are chained through an event per device:
+// each waits, on the GPU, for the previous persistent launch of that device and records the event behind itself — no host
+// blocking, and two tracking managers can no longer strand half of each other's grids until the 0.2 s time-out.
+namespace {
+struct PersistChain { std::mutex mu; hipEvent_t ev = nullptr; bool armed = false; };
+PersistChain g_persist_chain[16];
+}
+
 int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
     if (!t || !ring || !epochs) return set_err(GM_ERR_INVALID_ARG, "bad argument");
     if (t->device != ring->device) return set_err(GM_ERR_INVALID_ARG, "ring lives on another device");
     if (int rc = ensure_device(t->device)) return rc;
     if (int rc = trk_reserve_epochs(t, epochs)) return rc;
+    PersistChain& chain = g_persist_chain[t->device & 15];
+    std::lock_guard<std::mutex> chain_lock(chain.mu);
+    if (!chain.ev) HIPC(hipEventCreateWithFlags(&chain.ev, hipEventDisableTiming));
+    if (chain.armed) HIPC(hipStreamWaitEvent(t->stream, chain.ev, 0));
     if (t->timing) HIPC(hipEventRecord(t->ev0, t->stream));
     // one persistent launch per <= 4095 epochs (the epoch index lives in the low 12 bits of the granule tag)
     for (uint32_t e0 = 0; e0 < epochs; e0 += 4095) {
@@ -1363,6 +1377,8 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
                                   t->d_lostprn + o, t->d_error, (t->d_stamps && e0 == 0 && ne <= t->stamps_cap) ? t->d_stamps : nullptr);
     }
     if (t->timing) { HIPC(hipEventRecord(t->ev1, t->stream)); t->timed_launches = epochs; }
+    HIPC(hipEventRecord(chain.ev, t->stream));
+    chain.armed = true;
     HIPC(hipGetLastError());
     return GM_OK;
 }

@@ -140,6 +140,7 @@ void launch_trk_epoch(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_t
 constexpr int TRK_PERSIST_THREADS = 512;
 constexpr int TRK_PERSIST_WG_PER_CU = 2;
 
+int trk_persistent_blocks_per_cu(const TrkDevCfg&);   // resident workgroups per CU of the instantiation this config selects
 // persistent multi-epoch tracking (one launch = `epochs` passes over all channels); G workgroups per channel
 void launch_trk_persistent(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_trk_state* d_states,
                            const cf* ring, uint64_t mask, uint64_t head, int G, int epochs, uint32_t tag_base,

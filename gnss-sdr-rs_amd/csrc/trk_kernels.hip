@@ -521,6 +521,9 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     __shared__ float gathered[256];     // the G*NV partials of one epoch (wave 0 only)
     extern __shared__ int8_t chips[];   // the channel's chip row
 
+    // an earlier launch of the same call (more than 4095 passes are several launches) has timed out: do nothing, the host
+    // reports the error after it synchronises (the flag lives in pinned host memory: one read per launch)
+    if (__hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
     gm_trk_state s0 = a.states[ch];
     const int row = code_row(cfg, s0);
     const bool leader = (g == 0 && tid == 0);
@@ -656,6 +659,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (pending[q] && uint32_t(gr[q] >> 32) == tag) pending[q] = false;
+                    __builtin_amdgcn_s_sleep(2);   // a straggler is being waited for: leave the issue slots to whoever shares the SIMD
                     if ((++rounds & 63u) == 0u && wall_clock64() - t0 > 20000000ll) to = true;   // 0.2 s at 100 MHz
                 }
 #pragma unroll
@@ -795,6 +799,29 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
         case 6: hipLaunchKernelGGL((trk_persistent_kernel<5, 1, 0, T>), grid, dim3(T), lds, st, a); break;
         default: hipLaunchKernelGGL((trk_persistent_kernel<5, 1, 1, T>), grid, dim3(T), lds, st, a); break;
     }
+}
+
+// Workgroups of the persistent kernel one CU can hold at once (occupancy API for THIS instantiation and its dynamic LDS,
+// capped by the design's TRK_PERSIST_WG_PER_CU): the exchange between the G workgroups of a channel needs all
+// n_channels * G of them resident together.
+int trk_persistent_blocks_per_cu(const TrkDevCfg& cfg) {
+    const size_t lds = size_t((cfg.code_len + 15) & ~15);
+    const int key = (cfg.n_arms == 5 ? 4 : 0) | (cfg.code_index_mode == GM_CODE_INDEX_FIXED ? 2 : 0) | (cfg.boc11 ? 1 : 0);
+    constexpr int T = TRK_PERSIST_THREADS;
+    int n = 0;
+    hipError_t e = hipSuccess;
+    switch (key) {
+        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<3, 0, 0, T>, T, lds); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<3, 0, 1, T>, T, lds); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<3, 1, 0, T>, T, lds); break;
+        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<3, 1, 1, T>, T, lds); break;
+        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<5, 0, 0, T>, T, lds); break;
+        case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<5, 0, 1, T>, T, lds); break;
+        case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<5, 1, 0, T>, T, lds); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<5, 1, 1, T>, T, lds); break;
+    }
+    if (e != hipSuccess || n < 1) n = 1;
+    return n < TRK_PERSIST_WG_PER_CU ? n : TRK_PERSIST_WG_PER_CU;
 }
 
 void launch_trk_epoch(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_codes, gm_trk_state* d_states,

@@ -174,3 +174,43 @@ def test_channel_count_sweep_covers_every_G(gpu, oracle, C):
     w = _compare(mgr, ring, oring, starts, lambda i: oracle.TrackingChannel(i, fs, code_index_mode=1), 3, E, E)
     print("sweep C", C, w)
     mgr.close(); ring.close()
+
+
+def test_two_managers_on_two_streams_do_not_strand_each_other(gpu, oracle):
+    """The persistent kernel needs its whole grid resident; two handles (two streams) launched back to back used to be able
+    to hold half of each other's workgroups until the 0.2 s exchange time-out (GM_ERR_HIP).  Persistent launches are now
+    chained per device on the GPU: both calls complete, with exactly the results of running them one after the other."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    fs, n, E, C = 8.0e6, 8000, 40, 32
+    t = oracle.ca_code_table()
+    prns = [2, 5, 9, 13, 17, 22, 26, 30]
+    sc = synth.tracking_scene(t, fs, 0.0, prns, E + 2, config_id=62, cn0=50.0)
+    ring = T.MulticastRingBuffer(1 << 19)
+    ring.write_samples(synth.to_c32(sc["x"])[:(E + 1) * n])
+
+    def fresh(offset):
+        m = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED)     # own stream each
+        for i in range(C):
+            s = sc["sats"][i % 8]
+            m.channels[i].start(_acq_result(s["prn"], s["doppler_hz"] + offset - 0.3 * (i // 8), fs, s["code_start"]))
+        return m
+    # reference: one after the other, synchronised in between
+    a, b = fresh(20.0), fresh(-15.0)
+    a.update_all_dev(ring, E); a.synchronize()
+    b.update_all_dev(ring, E); b.synchronize()
+    want = [[m.channels[i].state for i in range(C)] for m in (a, b)]
+    a.close(); b.close()
+    # both in flight: launch, launch, then wait (repeated: the interleaving is up to the dispatcher)
+    for _ in range(3):
+        a, b = fresh(20.0), fresh(-15.0)
+        a.update_all_dev(ring, E)
+        b.update_all_dev(ring, E)
+        a.synchronize(); b.synchronize()          # raises GmError on an exchange time-out
+        for m, w in zip((a, b), want):
+            for i in range(C):
+                s = m.channels[i].state
+                assert s.next_sample_index == w[i].next_sample_index and s.lost_counter == w[i].lost_counter == 0
+                for k in ("carrier_freq", "carrier_phase", "code_phase", "code_rate", "i_prompt", "q_prompt"):
+                    assert _ulps(getattr(s, k), getattr(w[i], k)) == 0, (i, k)
+        a.close(); b.close()
+    ring.close()
