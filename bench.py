@@ -315,7 +315,7 @@ def main():
     # ------------------------------------------------------------------ configs[0] geometry on the GPU (informative)
     if rank == 0 and world == 1:
         try:
-            out["cfg1_geometry"] = cfg1_leg(torch, dev, stream, ca, A, synth)
+            out["cfg1_geometry"] = cfg1_leg(torch, dev, stream, ca, A, synth, with_cpu=not args.no_cpu_baseline)
         except Exception as e:
             out["cfg1_geometry"] = {"error": repr(e)}
 
@@ -391,7 +391,7 @@ def cfg4_leg(torch, dev, A, synth):
     res = eng.fetch_results(P)
     ok = all(res[s["prn_row"]] and res[s["prn_row"]]["code_phase_samples"] == s["code_start"] for s in sats)
     eng.close()
-    return {"workload": "36 codes x 41 bins x 32000 phases (4092-chip code, 4 ms), 2 periods, 8 Msps int8; N = 2 x 16000 composite",
+    return {"workload": "36 codes x 41 bins x 32000 phases (4092-chip code, 4 ms), 2 periods, 8 Msps int8; N = 2 x 16000 composite (decimated in time, inverse fused with the power reduction)",
             "cells_per_s": P * dop.size * N / dt, "ms_per_dwell": dt * 1e3, "simulated_found_at_true_phase": bool(ok)}
 
 
@@ -425,7 +425,37 @@ def pipelined_leg(torch, dev, sc, A, d_samples, P, D, N, M):
     return {"cells_per_s": P * D * N * K / dt, "ms_per_dwell": dt / K * 1e3, "detections_ok": bool(ok)}
 
 
-def cfg1_leg(torch, dev, stream, ca, A, synth):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cfg1_cpu_single_prn(sc, prn):
+    """BASELINE configs[0] as the reference runs it (test_acquisition_with_real_data, do_acquisition.rs:399-466): ONE
+    AcquisitionWorker, one thread, 29 Doppler tables, 10 x 16368 samples, early exit — the oracle on this host."""
+    from oracle import oracle as O
+    from gnss_sdr_rs_amd import synth
+    O.build(native=True)
+    x = synth.to_c32(sc["x"])
+    tables = [O.DopplerShiftTable(sc["f_if"], float(d), sc["fs"], sc["N"]) for d in sc["doppler_hz"]]
+    w = O.AcquisitionWorker(prn, sc["N"], sc["fs"], native=True)
+    O.search_all([w], 1, x, tables, 0, sc["M"], n_threads=1, native=True)
+    ts, cells = [], 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res, cells = O.search_all([w], 1, x, tables, 0, sc["M"], n_threads=1, native=True)
+        ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
+    return {"ms_per_search": dt * 1e3, "cells_per_s": cells / dt, "bins_visited": cells // sc["N"], "cores": 1, "kind": "port",
+            "cpu": cpu_model(), "found": bool(res[0])}
+
+
+def cfg1_leg(torch, dev, stream, ca, A, synth, with_cpu=False):
     """The reference's own test geometry (do_acquisition.rs:399-466: fs 16.3676 MHz, IF 4.1304 MHz, N = 16368, 29 bins,
     10 ms, real int8, 32 PRNs) on the synthetic stand-in for the missing capture; not part of `value`."""
     cap = json.load(open(os.path.join(ROOT, "tests", "golden", "capture_config.json")))
@@ -468,7 +498,13 @@ def cfg1_leg(torch, dev, stream, ca, A, synth):
     r1 = one.fetch_results(1)[0]
     one.close()
     corr_bytes = P * D * M * N * 16
-    return {"single_prn": {"ms_per_dwell": dt1 * 1e3, "cells_per_s": D * N / dt1,
+    cpu1 = None
+    if with_cpu:
+        try:
+            cpu1 = cfg1_cpu_single_prn(sc, sc["sats"][0]["prn"])
+        except Exception as e:
+            cpu1 = {"error": repr(e)}
+    return {"single_prn": {"ms_per_dwell": dt1 * 1e3, "cells_per_s": D * N / dt1, "cpu_baseline": cpu1,
                            "found_within_3_samples_of_truth": bool(r1 and min((r1["code_phase_samples"] - sc["sats"][0]["code_start"]) % N,
                                                                                 (sc["sats"][0]["code_start"] - r1["code_phase_samples"]) % N) <= 3)},
             "workload": "32 PRN x 29 bins (+-7 kHz / 500 Hz) x 16368 phases, 10 x 1 ms, real int8 (reference test geometry)",
@@ -659,7 +695,7 @@ def tracking_cpu_baseline(sc, fs, n, budget_s):
     t0 = time.perf_counter()
     got1 = O.process_channels(one_ch, ring, min(avail - 2, 40), n_threads=1, native=True)
     one = (time.perf_counter() - t0) / max(got1, 1)
-    return {"value": n / per_ch_epoch / 1e6, "unit": "ch*Msps", "cores": nthreads, "kind": "port",
+    return {"value": n / per_ch_epoch / 1e6, "unit": "ch*Msps", "cores": nthreads, "kind": "port", "cpu": cpu_model(),
             "sample": f"{done} channel-epochs (32 ch x 25 Msps scene of the GPU leg, 1 ms epochs)",
             "single_thread_ch_msps": n / one / 1e6}
 
@@ -705,7 +741,7 @@ def cpu_baseline(sc, budget_s):
     t0 = time.perf_counter()
     _, cells1 = O.search_all(workers[:4], 0xF, x, tables, 0, sc["M"], n_threads=1, native=True)
     r1 = cells1 / (time.perf_counter() - t0)
-    return {"value": float(np.median(rates)), "unit": "cells/s", "cores": nthreads, "kind": "port",
+    return {"value": float(np.median(rates)), "unit": "cells/s", "cores": nthreads, "kind": "port", "cpu": cpu_model(),
             "sample": f"{len(rates)} dwells of the bench scene (32 PRN x 41 bins x 8000 phases, 10 ms, early exit as in "
                       f"the reference; cells = bins visited x 8000), median dwell {np.median(dwell_s):.3f} s",
             "single_thread_cells_per_s": float(r1),

@@ -1,35 +1,33 @@
 // acq_composite.hip — acquisition at transform sizes that do not fit one LDS buffer (N > 16384), e.g. a Galileo E1
-// code period at 8 Msps (N = 32000, BASELINE configs[3]): N = Q * Nb with Nb one of the in-LDS plans and Q in 2..8.
+// code period at 8 Msps (N = 32000, BASELINE configs[3]) or GPS C/A at 25 Msps (N = 25000): N = Q * Nb with Nb one of six
+// in-LDS plans (16000, 8000, 8192, 6000, 5000, 4000) and Q in {2, 3, 4, 5, 6, 8}; the largest Nb that divides N is taken
+// (every spectrum element is re-read Q times: measured at N = 32000, 2 x 16000 takes 0.48 ms per dwell, 4 x 8000 0.62 ms).
 //
 // Same algorithm as acq_kernels.hip (AcquisitionWorker::search_satellite, do_acquisition.rs:158-226: mix -> FFT ->
-// x conj(code FFT) -> IFFT -> |.|^2 accumulated over the integrations -> first strict argmax / max / plane sum), with
-// the length-N transforms taken apart (n = n1*Nb + n2, k = Q*k2 + k1):
+// x conj(code FFT) -> IFFT -> |.|^2 accumulated over the integrations -> first strict argmax / max / plane sum), with the
+// length-N transforms decimated in time, n = Q*n2 + n1 and k = k1*Nb + k2:
 //
-//   forward   X[Q k2 + k1] = sum_n2 W_Nb^{n2 k2} * ( W_N^{n2 k1} * sum_n1 x[n1 Nb + n2] W_Q^{n1 k1} )
-//             comp_pre_kernel (the Q-point DFTs across the Q blocks + twiddle, the carrier mix fused in) ->
-//             the batched in-LDS transform of size Nb (fft_batch_kernel) -> spectrum in "decimated" order [k1][k2]
-//   product   elementwise in that order (the code spectra are produced by the same two steps), fused into the loads of
-//   inverse   y[n1 Nb + n2] = sum_k1 W_Q^{-n1 k1} * ( W_N^{-n2 k1} * IFFT_Nb(Y[Q k2 + k1])[n2] )
-//             the batched inverse transforms (comp_corr_fft_kernel in acq_kernels.hip), then comp_post_kernel: twiddle + Q-point inverse DFTs, |y|^2 accumulated over
-//             the integrations in registers, reduced to {max, first argmax, sum} per (worker, bin): no plane is stored.
+//   forward   X[k1 Nb + k2] = sum_n1 W_Q^{n1 k1} * W_N^{n1 k2} * ( sum_n2 x[Q n2 + n1] W_Nb^{n2 k2} )
+//             comp_fwd_sub_kernel: Q in-LDS transforms over the decimated inputs (carrier mix fused into the loads), then
+//             comp_fwd_post_kernel: twiddle + Q-point DFTs across n1 -> the spectrum in NATURAL block order, each block of
+//             Nb stored in the paired layout acq_corr reads (PairLayout).  The code spectra are made by the same two steps.
+//   inverse   y[Q n2 + n1] = sum_k2 W_Nb^{-n2 k2} * ( W_N^{-n1 k2} * sum_k1 Y[k1 Nb + k2] W_Q^{-n1 k1} ),   Y = X conj(C)
+//             comp_corr_kernel: ONE workgroup per (worker, bin) runs, for n1 = 0 .. Q-1 and every integration, one in-LDS
+//             transform whose pass-0 inputs are formed on the fly (Q products X conj(C), the Q-point DFT row n1, the
+//             twiddle) and whose outputs ARE final correlation values y[Q n2 + n1]: |y|^2 is accumulated over the
+//             integrations in registers and reduced to {max, first argmax, sum} — nothing goes back to HBM.
 //
-// Intermediates travel through HBM / L2 (about four passes over P*D*M*N*8 bytes): a first, correct version of the
-// large-N case; the fused single-LDS-buffer kernels remain the path for N <= 16384.
-#include "gm_internal.h"
+// Round 1 decimated in frequency instead: its inverse sub-transforms produced intermediate planes z that a second kernel had
+// to combine, 721 MB written and read back per dwell at configs[3] geometry (2.2 GB of fabric traffic for 1.5 GB of
+// algorithmic bytes).  Here every spectrum element is re-read Q times from L2 (once per n1), which costs pass-0 load
+// slots but no HBM traffic: the working set is the spectra (D*M*N*8 B) and the code spectra (P*N*8 B).
+#include "acq_device.h"
+#include <vector>
 
 namespace gm {
 
 namespace {
 constexpr int CT = 256;
-
-__device__ __forceinline__ cf comp_load(const void* samples, int fmt, size_t idx) {
-    if (fmt == GM_FMT_C32) return reinterpret_cast<const cf*>(samples)[idx];
-    if (fmt == GM_FMT_I8_IQ) {
-        const char2 v = reinterpret_cast<const char2*>(samples)[idx];
-        return cf_make(float(v.x), float(v.y));
-    }
-    return cf_make(float(reinterpret_cast<const int8_t*>(samples)[idx]), 0.0f);
-}
 
 // e^{-+ 2 pi i t / n} for integer t in [0, n): the argument is formed from the exact integer phase
 __device__ __forceinline__ cf unit_root(uint32_t t, uint32_t n, bool inverse) {
@@ -37,126 +35,219 @@ __device__ __forceinline__ cf unit_root(uint32_t t, uint32_t n, bool inverse) {
     sincospif(2.0f * (float(t) / float(n)), &sn, &cs);
     return cf_make(cs, inverse ? sn : -sn);
 }
-__device__ __forceinline__ cf cmulf(cf a, cf b) {
-    return cf_make(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+
+// ------------------------------------------------------------------------------------ forward, step 1
+// grid n_items * Q: item = (d, m) for the signal (tables != null: apply_doppler_shift fused, doppler_shift.rs:43-58, same
+// products) or a code index for the replicas (int8 chips, :134); n1 = blockIdx % Q.  A[item][n1][k2], natural order.
+template <class PL>
+__global__ __launch_bounds__(PL::T) void comp_fwd_sub_kernel(const void* __restrict__ samples, int fmt,
+                                                             const cf* __restrict__ tables,
+                                                             const int8_t* __restrict__ code_samples,
+                                                             const cf* __restrict__ tw_fwd, cf* __restrict__ A,
+                                                             uint32_t Q, uint32_t n_int) {
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    load_twiddles<PL>(tw, tw_fwd, tid);
+    const uint32_t item = blockIdx.x / Q, n1 = blockIdx.x % Q;
+    const size_t N = size_t(Q) * PL::N;
+    const uint32_t d = item / n_int, m = item % n_int;
+    cf* dst = A + size_t(blockIdx.x) * PL::N;
+    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    lds_transform<PL, false>(
+        [&](int it, int r) {
+            const size_t n = size_t(Q) * uint32_t((tid + it * PL::T) + r * NB0) + n1;
+            if (code_samples) return cf_make(float(code_samples[size_t(item) * N + n]), 0.0f);
+            const cf s = load_sample(samples, fmt, size_t(m) * N + n);
+            const cf t = tables[size_t(d) * N + n];
+            return cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);           // multiply_simd_block
+        },
+        [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
 }
 
-// forward pre-pass.  grid (ceil(Nb / CT), n_items); item = (d, m) for the signal (tables != null: carrier mix
-// apply_doppler_shift fused, doppler_shift.rs:43-58, same products) or a code index for the replicas (int8 chips).
-// out[item][k1][n2]
-template <uint32_t Q>
-__global__ __launch_bounds__(CT) void comp_pre_kernel(const void* __restrict__ in, int fmt, const cf* __restrict__ tables,
-                                                      cf* __restrict__ out, uint32_t Nb, uint32_t n_int,
-                                                      const int8_t* __restrict__ code_samples) {
-    const uint32_t n2 = blockIdx.x * CT + threadIdx.x;
-    if (n2 >= Nb) return;
-    const uint32_t item = blockIdx.y, N = Q * Nb;
-    cf x[Q], wq[Q];                                 // compile-time Q: both arrays stay in registers
+// ------------------------------------------------------------------------------------ forward, step 2
+// grid (ceil(Nb / CT), n_items): X[item][k1][place(k2)] = sum_n1 W_Q^{n1 k1} W_N^{n1 k2} A[item][n1][k2];
+// place = PairLayout<PL>::pos (paired != 0) or the identity.
+template <class PL, uint32_t Q>
+__global__ __launch_bounds__(CT) void comp_fwd_post_kernel(const cf* __restrict__ A, cf* __restrict__ X, int paired) {
+    const uint32_t k2 = blockIdx.x * CT + threadIdx.x;
+    if (k2 >= uint32_t(PL::N)) return;
+    const uint32_t item = blockIdx.y, Nb = PL::N, N = Q * Nb;
+    cf a[Q], wq[Q];
 #pragma unroll
     for (uint32_t j = 0; j < Q; ++j) wq[j] = unit_root(j, Q, false);
 #pragma unroll
-    for (uint32_t n1 = 0; n1 < Q; ++n1) {
-        const uint32_t n = n1 * Nb + n2;
-        if (code_samples) {
-            x[n1] = cf_make(float(code_samples[size_t(item) * N + n]), 0.0f);        // :134 (i8 -> f32, im = 0)
-        } else {
-            const uint32_t d = item / n_int, m = item % n_int;
-            const cf s = comp_load(in, fmt, size_t(m) * N + n);
-            const cf t = tables[size_t(d) * N + n];
-            x[n1] = cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);           // multiply_simd_block
-        }
-    }
+    for (uint32_t n1 = 0; n1 < Q; ++n1)
+        a[n1] = cf_mul(A[(size_t(item) * Q + n1) * Nb + k2], unit_root(uint32_t((uint64_t(n1) * k2) % N), N, false));
+    const uint32_t place = paired ? uint32_t(PairLayout<PL>::pos(int(k2))) : k2;
 #pragma unroll
     for (uint32_t k1 = 0; k1 < Q; ++k1) {
-        cf acc = x[0];
+        cf acc = a[0];
 #pragma unroll
-        for (uint32_t n1 = 1; n1 < Q; ++n1) acc = cf_add(acc, cmulf(x[n1], wq[(n1 * k1) % Q]));
-        const cf w = unit_root(uint32_t((uint64_t(n2) * k1) % N), N, false);
-        out[(size_t(item) * Q + k1) * Nb + n2] = cmulf(acc, w);
+        for (uint32_t n1 = 1; n1 < Q; ++n1) acc = cf_add(acc, cf_mul(a[n1], wq[(n1 * k1) % Q]));
+        X[(size_t(item) * Q + k1) * Nb + place] = acc;
     }
 }
 
-// inverse post-pass + power accumulation + reduction.  One workgroup per (w, d); z[w][d][m][k1][n2].
-template <uint32_t Q>
-__global__ __launch_bounds__(CT) void comp_post_kernel(const cf* __restrict__ z, uint32_t Nb, uint32_t n_int,
-                                                       uint32_t n_bins, const uint32_t* __restrict__ worker_list,
-                                                       float* __restrict__ mmax, uint32_t* __restrict__ margmax,
-                                                       float* __restrict__ msum) {
-    __shared__ float s_p[CT / 64], s_s[CT / 64];
-    __shared__ uint32_t s_k[CT / 64];
-    const uint32_t d = blockIdx.x, w = blockIdx.y, N = Q * Nb, tid = threadIdx.x;
-    const cf* base = z + (size_t(w) * n_bins + d) * n_int * N;
-    float best = 0.0f, sum = 0.0f;                 // running max starts from 0.0 like the reference (:195-202)
-    uint32_t bestn = 0;
-    bool any = false;
-    cf wq[Q];
+// ------------------------------------------------------------------------------------ inverse, fused
+// One workgroup per (worker, bin).  spectra [d][m][k1][paired k2], code [p][k1][paired k2], twn [n1][paired k2] =
+// W_N^{-n1 k2} (e^{+...}: inverse).
+template <class PL, uint32_t Q>
+__global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void comp_corr_kernel(
+    const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ twn, const cf* __restrict__ tw_inv,
+    float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
+    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int) {
+    static_assert(PL::IT0 == 1 && PairLayout<PL>::PAIRED, "composite base plans: one pass-0 butterfly per lane, paired layout");
+    // equal contiguous share of the bin-major item list per XCD (blocks b and b + 8 share an XCD: speed only)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int items = n_bins * n_workers, share = (items + 7) >> 3;
+    const int item = xcd * share + slot;
+    if (slot >= share || item >= items) return;
+    const int d = item / n_workers, p = int(worker_list[item - d * n_workers]);
+
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    load_twiddles<PL>(tw, tw_inv, tid);
+    constexpr int Nb = PL::N, NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1), NPAIR = PL::R0 / 2;
+    constexpr bool ODD0 = (PL::R0 & 1) != 0;
+    constexpr uint32_t N = Q * uint32_t(Nb);
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(spectra + size_t(d) * n_int * N, unsigned(n_int) * N * 8u);
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(code_fft + size_t(p) * N, N * 8u);
+    const __amdgpu_buffer_rsrc_t trs = make_rsrc(twn, N * 8u);
+    const int oob = 0x7ffffff0;                              // lanes without a pass-0 butterfly: dropped by the range check
+    const int v16 = tid < NB0 ? tid * 16 : oob, v8 = tid < NB0 ? tid * 8 : oob;
+    auto lo = [](u32x4 v) { return cf_make(__uint_as_float(v.x), __uint_as_float(v.y)); };
+    auto hi = [](u32x4 v) { return cf_make(__uint_as_float(v.z), __uint_as_float(v.w)); };
+    auto prod = [](cf a, cf g) {                             // result_buf[i] *= conj(code[i]) (:184-186), num-complex Mul, no FMA
+        const float cx = g.x, cy = -g.y;
+        return cf_make(a.x * cx - a.y * cy, a.x * cy + a.y * cx);
+    };
+
+    float bv = 0.0f, sum = 0.0f;
+    uint32_t bi = 0xffffffffu;
+    for (uint32_t n1 = 0; n1 < Q; ++n1) {
+        cf wq[Q];                                            // row n1 of the Q-point inverse DFT: W_Q^{-n1 k1}
 #pragma unroll
-    for (uint32_t j = 0; j < Q; ++j) wq[j] = unit_root(j, Q, true);
-    for (uint32_t n2 = tid; n2 < Nb; n2 += CT) {
-        float acc[Q];
-        cf wn[Q];                                  // W_N^{-n2 k1}, the same for every integration
+        for (uint32_t k1 = 0; k1 < Q; ++k1) wq[k1] = unit_root((n1 * k1) % Q, Q, true);
+        float acc[PL::ITL][PL::RL];
 #pragma unroll
-        for (uint32_t k1 = 0; k1 < Q; ++k1) { acc[k1] = 0.0f; wn[k1] = unit_root(uint32_t((uint64_t(n2) * k1) % N), N, true); }
-        for (uint32_t m = 0; m < n_int; ++m) {
-            cf u[Q];
+        for (int it = 0; it < PL::ITL; ++it)
 #pragma unroll
-            for (uint32_t k1 = 0; k1 < Q; ++k1) u[k1] = cmulf(base[(size_t(m) * Q + k1) * Nb + n2], wn[k1]);
+            for (int r = 0; r < PL::RL; ++r) acc[it][r] = 0.0f;
+        for (int m = 0; m < n_int; ++m) {
+            cf vals[PL::R0];
 #pragma unroll
-            for (uint32_t n1 = 0; n1 < Q; ++n1) {
-                cf y = u[0];
+            for (int rp = 0; rp < NPAIR; ++rp) {
+                const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(trs, v16, (int(n1) * Nb + rp * 2 * NB0) * 8, 0);
+                cf s0 = cf_make(0.f, 0.f), s1 = s0;
 #pragma unroll
-                for (uint32_t k1 = 1; k1 < Q; ++k1) y = cf_add(y, cmulf(u[k1], wq[(n1 * k1) % Q]));
-                acc[n1] += y.x * y.x + y.y * y.y;  // norm_sqr accumulated per integration (:190-192)
+                for (uint32_t k1 = 0; k1 < Q; ++k1) {
+                    const u32x4 x4 = __builtin_amdgcn_raw_buffer_load_b128(xrs, v16, ((m * int(Q) + int(k1)) * Nb + rp * 2 * NB0) * 8, 0);
+                    const u32x4 c4 = __builtin_amdgcn_raw_buffer_load_b128(crs, v16, (int(k1) * Nb + rp * 2 * NB0) * 8, 0);
+                    const cf p0 = prod(lo(x4), lo(c4)), p1 = prod(hi(x4), hi(c4));
+                    if (k1 == 0) { s0 = p0; s1 = p1; }
+                    else { s0 = cf_add(s0, cf_mul(p0, wq[k1])); s1 = cf_add(s1, cf_mul(p1, wq[k1])); }
+                }
+                vals[2 * rp] = cf_mul(s0, lo(t4));
+                vals[2 * rp + 1] = cf_mul(s1, hi(t4));
+            }
+            if constexpr (ODD0) {
+                const cf t1 = buf_load_cf(trs, v8, (int(n1) * Nb + 2 * NPAIR * NB0) * 8);
+                cf s0 = cf_make(0.f, 0.f);
+#pragma unroll
+                for (uint32_t k1 = 0; k1 < Q; ++k1) {
+                    const cf x1 = buf_load_cf(xrs, v8, ((m * int(Q) + int(k1)) * Nb + 2 * NPAIR * NB0) * 8);
+                    const cf c1 = buf_load_cf(crs, v8, (int(k1) * Nb + 2 * NPAIR * NB0) * 8);
+                    const cf p0 = prod(x1, c1);
+                    s0 = k1 == 0 ? p0 : cf_add(s0, cf_mul(p0, wq[k1]));
+                }
+                vals[PL::R0 - 1] = cf_mul(s0, t1);
+            }
+            lds_transform<PL, true>([&](int, int r) { return vals[r]; },
+                                    [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y); },   // += norm_sqr() (:190-192)
+                                    lds, tw, tid);
+        }
+        // this sub-transform's outputs are y[Q n2 + n1]: fold them into the lane's running first strict maximum / sum
+#pragma unroll
+        for (int it = 0; it < PL::ITL; ++it) {
+            const int b = tid + it * PL::T;
+            if (b < NBL) {
+#pragma unroll
+                for (int r = 0; r < PL::RL; ++r) {
+                    take_better(bv, bi, acc[it][r], Q * uint32_t(b + r * NBL) + n1);
+                    sum += acc[it][r];
+                }
             }
         }
+    }
 #pragma unroll
-        for (uint32_t n1 = 0; n1 < Q; ++n1) {
-            const uint32_t n = n1 * Nb + n2;
-            sum += acc[n1];
-            if (acc[n1] > best || (acc[n1] == best && any && n < bestn && acc[n1] > 0.0f)) { best = acc[n1]; bestn = n; any = true; }
-        }
-    }
-    // first strict maximum over n: larger value wins, equal values -> smaller index
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ob = __shfl_xor(best, off), os = __shfl_xor(sum, off);
-        const uint32_t on = __shfl_xor(bestn, off);
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const uint32_t oi = uint32_t(__shfl_xor(int(bi), off, 64));
+        const float os = __shfl_xor(sum, off, 64);
+        take_better(bv, bi, ov, oi);
         sum += os;
-        if (ob > best || (ob == best && on < bestn)) { best = ob; bestn = on; }
     }
-    if ((tid & 63) == 0) { s_p[tid >> 6] = best; s_k[tid >> 6] = bestn; s_s[tid >> 6] = sum; }
+    __syncthreads();   // everyone is done with the LDS transform buffer: reuse it as scratch
+    float* sv = reinterpret_cast<float*>(lds);
+    uint32_t* si = reinterpret_cast<uint32_t*>(lds) + 64;
+    float* ss = reinterpret_cast<float*>(lds) + 128;
+    const int wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = PL::T / 64;
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; ss[wave] = sum; }
     __syncthreads();
     if (tid == 0) {
-        for (int i = 1; i < CT / 64; ++i) {
-            sum += s_s[i];
-            if (s_p[i] > best || (s_p[i] == best && s_k[i] < bestn)) { best = s_p[i]; bestn = s_k[i]; }
-        }
-        const size_t o = size_t(worker_list[w]) * n_bins + d;
-        mmax[o] = best; margmax[o] = best > 0.0f ? bestn : 0u; msum[o] = sum;
+        float fv = sv[0], fs = ss[0];
+        uint32_t fi = si[0];
+        for (int w = 1; w < NW; ++w) { take_better(fv, fi, sv[w], si[w]); fs += ss[w]; }
+        if (fi == 0xffffffffu) fi = 0;   // all-NaN / all-zero plane: the reference keeps (0.0, 0)
+        const size_t o = size_t(p) * n_bins + d;
+        mmax[o] = fv; margmax[o] = fi; msum[o] = fs;
     }
 }
+
+template <class PL, uint32_t Q> struct CompLaunch {
+    static void fwd_sub(hipStream_t st, const void* samples, int fmt, const cf* tables, const int8_t* code_samples,
+                        const cf* tw_fwd, cf* A, uint32_t n_items, uint32_t n_int) {
+        hipLaunchKernelGGL(comp_fwd_sub_kernel<PL>, dim3(n_items * Q), dim3(PL::T), 0, st, samples, fmt, tables, code_samples,
+                           tw_fwd, A, Q, n_int);
+    }
+    static void fwd_post(hipStream_t st, const cf* A, cf* X, uint32_t n_items, int paired) {
+        hipLaunchKernelGGL((comp_fwd_post_kernel<PL, Q>), dim3((PL::N + CT - 1) / CT, n_items), dim3(CT), 0, st, A, X, paired);
+    }
+    static void corr(hipStream_t st, const cf* spectra, const cf* code_paired, const cf* twn, const cf* tw_inv, float* mmax,
+                     uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int) {
+        if (n_workers <= 0) return;
+        const int share = (n_workers * n_bins + 7) / 8;
+        hipLaunchKernelGGL((comp_corr_kernel<PL, Q>), dim3(8 * share), dim3(PL::T), 0, st, spectra, code_paired, twn, tw_inv,
+                           mmax, margmax, msum, worker_list, n_workers, n_bins, n_int);
+    }
+    // W_N^{-n1 k2} (inverse sign) for n1 < Q, in the paired position of k2: built in double on the host
+    static void fill_twn(cf* out) {
+        const uint32_t Nb = PL::N, N = Q * Nb;
+        for (uint32_t n1 = 0; n1 < Q; ++n1)
+            for (uint32_t k2 = 0; k2 < Nb; ++k2) {
+                const double a = 2.0 * ct::kPi * double((uint64_t(n1) * k2) % N) / double(N);
+                out[size_t(n1) * Nb + PairLayout<PL>::pos(int(k2))] = cf_make(float(::cos(a)), float(::sin(a)));
+            }
+    }
+    static constexpr CompOps ops() { return CompOps{PL::N, int(Q), &fwd_sub, &fwd_post, &corr, &fill_twn}; }
+};
 }  // namespace
 
-#define GM_COMP_Q_SWITCH(Q, CALL)                       \
-    switch (Q) {                                        \
-        case 2: { constexpr uint32_t QQ = 2; CALL; } break; \
-        case 3: { constexpr uint32_t QQ = 3; CALL; } break; \
-        case 4: { constexpr uint32_t QQ = 4; CALL; } break; \
-        case 5: { constexpr uint32_t QQ = 5; CALL; } break; \
-        case 6: { constexpr uint32_t QQ = 6; CALL; } break; \
-        default: { constexpr uint32_t QQ = 8; CALL; } break; \
-    }
+// base plans of the composite sizes: first radix <= 25 (paired layout), one pass-0 butterfly per lane
+#define GM_COMP_ENTRY(PL)                                                                            \
+    CompLaunch<PL, 2>::ops(), CompLaunch<PL, 3>::ops(), CompLaunch<PL, 4>::ops(), CompLaunch<PL, 5>::ops(), \
+        CompLaunch<PL, 6>::ops(), CompLaunch<PL, 8>::ops(),
+static const CompOps g_comp[] = {GM_COMP_ENTRY(Plan16000) GM_COMP_ENTRY(Plan8000) GM_COMP_ENTRY(Plan8192) GM_COMP_ENTRY(Plan6000) GM_COMP_ENTRY(Plan5000)
+                                     GM_COMP_ENTRY(Plan4000)};
 
-bool comp_q_supported(uint32_t Q) { return Q == 2 || Q == 3 || Q == 4 || Q == 5 || Q == 6 || Q == 8; }
-
-void launch_comp_pre(hipStream_t st, const void* in, int fmt, const cf* tables, cf* out, uint32_t Q, uint32_t Nb,
-                     uint32_t n_int, uint32_t n_items, const int8_t* code_samples) {
-    GM_COMP_Q_SWITCH(Q, hipLaunchKernelGGL(comp_pre_kernel<QQ>, dim3((Nb + CT - 1) / CT, n_items), dim3(CT), 0, st, in, fmt,
-                                           tables, out, Nb, n_int, code_samples))
-}
-void launch_comp_post(hipStream_t st, const cf* z, uint32_t Q, uint32_t Nb, uint32_t n_int, uint32_t n_bins,
-                      const uint32_t* worker_list, uint32_t n_workers, float* mmax, uint32_t* margmax, float* msum) {
-    GM_COMP_Q_SWITCH(Q, hipLaunchKernelGGL(comp_post_kernel<QQ>, dim3(n_bins, n_workers), dim3(CT), 0, st, z, Nb, n_int,
-                                           n_bins, worker_list, mmax, margmax, msum))
+// N = Q * Nb: the largest base plan first (fewest sub-transform passes over the spectra)
+const CompOps* find_comp(uint32_t n) {
+    for (const CompOps& c : g_comp)
+        if (uint32_t(c.nb) * uint32_t(c.q) == n) return &c;
+    return nullptr;
 }
 
 }  // namespace gm

@@ -18,119 +18,10 @@
 //
 // Compiled with -ffp-contract=off: the "faithful" products below must round like rustc's
 // (no FMA); the FFT butterflies use explicit __builtin_fmaf.
-#include "gm_internal.h"
-#include "fft_plans.h"
+#include "acq_device.h"
 #include <cstdlib>
 
 namespace gm {
-
-struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
-
-template <class PL, bool INV, int S> struct MiddlePasses {
-    // st(k): optional diagnostic stamp hook, called only next to barriers (k = 4.. in program order)
-    template <class St = NoStamp>
-    static __device__ __forceinline__ void run(cf* lds, const cf* tw, int tid, St st = St()) {
-        if constexpr (S <= PL::NP - 2) {
-            cf v[PL::IT(S)][PL::R[S]];
-            Fft<PL, INV>::template mid_stage1<S>(v, lds, tw, tid);
-            st(4);
-            __syncthreads();   // every lane has read its inputs: the image may be overwritten
-            st(5);
-            Fft<PL, INV>::template mid_stage2<S>(v, lds, tid);
-            st(6);
-            __syncthreads();
-            st(7);
-            MiddlePasses<PL, INV, S + 1>::run(lds, tw, tid);
-        }
-    }
-};
-
-// One length-N transform by the whole workgroup: in(it, r) feeds pass 0, out(it, r, value) receives
-// the natural-order outputs.  Safe to call back to back (the first barrier orders the scatter after
-// the previous transform's last LDS reads and after the twiddle-table load).
-template <class PL, bool INV, class In, class Out>
-__device__ __forceinline__ void lds_transform(In&& in, Out&& out, cf* lds, const cf* tw, int tid) {
-    {
-        cf v0[PL::IT0][PL::R0];
-        Fft<PL, INV>::pass0_stage1(v0, in, tid);
-        __syncthreads();
-        Fft<PL, INV>::pass0_stage2(v0, lds, tid);
-    }
-    __syncthreads();
-    MiddlePasses<PL, INV, 1>::run(lds, tw, tid);
-    cf vl[PL::ITL][PL::RL];
-    Fft<PL, INV>::last_stage1(vl, lds, tw, tid);
-    Fft<PL, INV>::last_stage2(vl, out, tid);
-}
-
-template <class PL> __device__ __forceinline__ void load_twiddles(cf* tw_lds, const cf* tw_g, int tid) {
-    for (int i = tid; i < PL::TW_TOTAL; i += PL::T) tw_lds[i] = tw_g[i];
-}
-
-// Buffer-descriptor loads: the 128-bit resource sits in SGPRs, the per-lane byte offset is ONE VGPR
-// shared by every element of the butterfly, the per-element stride goes into the scalar offset.
-// (Flat addressing made hipcc keep one 64-bit VGPR address per element live across the m loop.)
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, int(bytes), 0x00020000);
-}
-__device__ __forceinline__ cf buf_load_cf(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_bytes, soff_bytes, 0);
-    return cf_make(__uint_as_float(v.x), __uint_as_float(v.y));
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// Paired layout of the stage F -> stage C spectra and of the code spectra the correlation kernel reads.
-// Lane b of pass 0 of the inverse transform consumes elements b + r*NB0, r = 0..R0-1.  With 8-byte elements stored in
-// natural order that is R0 8-byte loads per lane, and pass 0 is bound by the texture-address path (an 8-byte-per-lane
-// load moves half the bytes of a 16-byte one per issue slot: configs[1] 213 -> 190 us per launch with pairs).  So the
-// elements of one lane are stored two by two: position of natural index k = b + r*NB0 is
-//     r < 2*(R0/2):  ((r/2)*NB0 + b)*2 + (r & 1)        [R0/2][NB0][2]  -> one 16-byte load per pair, coalesced over b
-//     r = R0-1, R0 odd:  2*(R0/2)*NB0 + b                 [NB0]           -> one 8-byte load
-// Only acq_mix_fft_kernel (writer), pair_codes_kernel (writer) and acq_corr_kernel (reader) know this layout.
-// Plans whose first radix is too large for both arrays' pass-0 elements to sit in registers at once (R0 = 31, 32, 33: the
-// hoisted loads cost Plan16368 20 % at 167 VGPRs) keep the natural order and the element-by-element loads.
-template <class PL> struct PairLayout {
-    static constexpr int R0 = PL::R0, NB0 = PL::NB(0), NPAIR = R0 / 2;
-    static constexpr bool PAIRED = R0 <= 25;
-    static __host__ __device__ __forceinline__ int pos(int k) {
-        if constexpr (!PAIRED) return k;
-        const int r = k / NB0, b = k - r * NB0;
-        return r < 2 * NPAIR ? ((r >> 1) * NB0 + b) * 2 + (r & 1) : 2 * NPAIR * NB0 + b;
-    }
-};
-
-template <class PL> struct CorrLayout { static constexpr bool CODE_PAIRED = PairLayout<PL>::PAIRED; };
-
-// one lane's pass-0 elements of one paired array, in registers: R0/2 16-byte loads (+ one 8-byte load when R0 is odd)
-template <class PL> struct PairLoad {
-    static constexpr int NPAIR = PL::R0 / 2, NB0 = PL::NB(0);
-    static constexpr bool ODD = (PL::R0 & 1) != 0;
-    u32x4 q[NPAIR > 0 ? NPAIR : 1];
-    cf last;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int b, int base_elems) {
-        const int oob = 0x7ffffff0;                         // b >= NB0: out of the descriptor's range -> no request, zeros
-        const int v16 = b < NB0 ? b * 16 : oob, v8 = b < NB0 ? b * 8 : oob;
-#pragma unroll
-        for (int rp = 0; rp < NPAIR; ++rp) q[rp] = __builtin_amdgcn_raw_buffer_load_b128(rs, v16, (base_elems + rp * 2 * NB0) * 8, 0);
-        if constexpr (ODD) last = buf_load_cf(rs, v8, (base_elems + 2 * NPAIR * NB0) * 8);
-    }
-    __device__ __forceinline__ cf get(int r) const {   // r is a compile-time constant after unrolling
-        if (ODD && r == PL::R0 - 1) return last;
-        const u32x4 v = q[r >> 1];
-        return (r & 1) ? cf_make(__uint_as_float(v.z), __uint_as_float(v.w)) : cf_make(__uint_as_float(v.x), __uint_as_float(v.y));
-    }
-};
-
-__device__ __forceinline__ cf load_sample(const void* samples, int fmt, size_t idx) {
-    if (fmt == GM_FMT_C32) return reinterpret_cast<const cf*>(samples)[idx];
-    if (fmt == GM_FMT_I8_IQ) {
-        const char2 v = reinterpret_cast<const char2*>(samples)[idx];
-        return cf_make(float(v.x), float(v.y));
-    }
-    return cf_make(float(reinterpret_cast<const int8_t*>(samples)[idx]), 0.0f);
-}
 
 // ------------------------------------------------------------------------------------ stage F
 template <class PL>
@@ -177,11 +68,6 @@ void set_corr_stamps(long long* d_ptr) {
 }
 
 // ------------------------------------------------------------------------------------ stage C
-// (value, index) reduction: larger value wins, equal values -> lower index (first strict maximum)
-__device__ __forceinline__ void take_better(float& bv, uint32_t& bi, float v, uint32_t i) {
-    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
-}
-
 template <class PL, bool KEEP_CODE, bool STAMPS>
 __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ tw_inv,
@@ -334,8 +220,7 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
             if (tid == 0) {
                 uint32_t* cnt = split_counter + size_t(xcd) * split_items + (slot - split_from);
                 const uint32_t old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = (old == uint32_t(parts - 1)) ? 1 : 0;
-                if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                s_last = (old == uint32_t(parts - 1)) ? 1 : 0;                  // tickets are zeroed by the launcher before every launch
             }
             __syncthreads();
             if (!s_last) return;
@@ -455,34 +340,6 @@ __global__ __launch_bounds__(256) void pair_codes_kernel(const cf* __restrict__ 
         const int k = int(i - c * PL::N);
         paired[c * PL::N + PairLayout<PL>::pos(k)] = nat[i];
     }
-}
-
-// ------------------------------------------------------------------------------------ composite sizes: product + inverse
-// One length-Nb inverse transform of the composite path (acq_composite.hip) with the x conj(code spectrum) product
-// (:184-186, num-complex order, no FMA) fused into its pass-0 loads.  grid = workers * n_dm * Q transforms;
-// spectra [n_dm][Q][Nb], code spectra [P][Q][Nb] (decimated order), z [w][n_dm][Q][Nb].
-template <class PL>
-__global__ __launch_bounds__(PL::T) void comp_corr_fft_kernel(const cf* __restrict__ spectra, const cf* __restrict__ code_fft,
-                                                             const cf* __restrict__ tw_inv, cf* __restrict__ z,
-                                                             const uint32_t* __restrict__ worker_list, uint32_t Q,
-                                                             uint32_t n_dm) {
-    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
-    cf* tw = lds + PL::LDS_ELEMS;
-    const int tid = threadIdx.x;
-    load_twiddles<PL>(tw, tw_inv, tid);
-    const uint32_t k1 = blockIdx.x % Q, dm = (blockIdx.x / Q) % n_dm, w = blockIdx.x / (Q * n_dm);
-    const cf* x = spectra + (size_t(dm) * Q + k1) * PL::N;
-    const cf* c = code_fft + (size_t(worker_list[w]) * Q + k1) * PL::N;
-    cf* dst = z + size_t(blockIdx.x) * PL::N;
-    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
-    lds_transform<PL, true>(
-        [&](int it, int r) {
-            const int idx = (tid + it * PL::T) + r * NB0;
-            const cf a = x[idx], g = c[idx];
-            const float nd = -g.y;
-            return cf_make(a.x * g.x - a.y * nd, a.x * nd + a.y * g.x);
-        },
-        [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
 }
 
 // ------------------------------------------------------------------------------------ plain batched FFT
@@ -707,6 +564,10 @@ template <class PL> struct Launch {
             }
         }
         const int grid = 8 * (split_from + split_items * split_k);
+        // the merge tickets start from zero in EVERY launch (a launch that was aborted, or two host threads on one handle,
+        // must not leave a count behind that makes a later dwell merge early): the whole ticket block, a multiple of 16 bytes
+        // at the start of its allocation (cdna_hip_programming.md G16 "Re-initialise every call")
+        if (split_k > 1) (void)hipMemsetAsync(split_counter, 0, size_t(GM_CORR_SPLIT_MAX_ITEMS) * sizeof(uint32_t), st);
         if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
             hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, true>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
@@ -722,11 +583,6 @@ template <class PL> struct Launch {
     static void pair_codes(hipStream_t st, const cf* nat, cf* paired, int n_codes) {
         hipLaunchKernelGGL(pair_codes_kernel<PL>, dim3(n_codes * 4 < 1024 ? n_codes * 4 : 1024), dim3(256), 0, st, nat, paired, n_codes);
     }
-    static void comp_corr_fft(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, cf* z,
-                              const uint32_t* worker_list, uint32_t Q, uint32_t n_dm, uint32_t n_workers) {
-        hipLaunchKernelGGL(comp_corr_fft_kernel<PL>, dim3(n_workers * n_dm * Q), dim3(PL::T), 0, st, spectra, code_fft, tw_inv,
-                           z, worker_list, Q, n_dm);
-    }
     static void fft_batch(hipStream_t st, cf* data, const cf* tw, int inverse, int batch) {
         if (inverse) hipLaunchKernelGGL((fft_batch_kernel<PL, true>), dim3(batch), dim3(PL::T), 0, st, data, tw);
         else hipLaunchKernelGGL((fft_batch_kernel<PL, false>), dim3(batch), dim3(PL::T), 0, st, data, tw);
@@ -741,7 +597,7 @@ template <class PL> struct Launch {
     static constexpr PlanOps ops() {
         return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL), SPLIT_SLAB,
                        CorrLayout<PL>::CODE_PAIRED ? 1 : 0,
-                       &fill_tw, &mix_fft, &corr, &code_fft, &pair_codes, &fft_batch, &comp_corr_fft,
+                       &fill_tw, &mix_fft, &corr, &code_fft, &pair_codes, &fft_batch,
                        POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr, FineRows<PL>::RT};
     }
 };

@@ -203,8 +203,9 @@ struct gm_acq {
     float* d_split_scratch = nullptr;      // partial power planes of the correlation grid's tail split
     uint32_t* d_split_counter = nullptr;   // arrival tickets, one per split item, zero between launches
     uint32_t Q = 1, Nb = 0;
-    cf* d_comp_y = nullptr;                // [workers][D][M][N] products / inverse transforms
-    size_t comp_y_elems = 0;
+    const gm::CompOps* comp = nullptr;     // Q > 1: the (Q, base plan) kernels
+    cf* d_comp_tmp = nullptr;              // [max(D*M, P)][Q][Nb]: forward sub-transforms before the Q-point DFTs
+    cf* d_comp_twn = nullptr;              // [Q][Nb] inverse twiddles W_N^{-n1 k2}, paired positions
     // fine Doppler (gm_acq_finer_doppler): host copy of the chip rows, lazily built device state
     std::vector<int8_t> chips;             // [P][code_len]
     uint32_t code_len = 1023;
@@ -395,7 +396,7 @@ int gm_rfft_f32(size_t n, const float* in, gm_c32* out) {
 int gm_acq_destroy(gm_acq* a) {
     if (!a) return GM_OK;
     if (a->device >= 0) hipSetDevice(a->device);
-    hipFree(a->d_comp_y); hipFree(a->d_split_scratch); hipFree(a->d_split_counter);
+    hipFree(a->d_comp_tmp); hipFree(a->d_comp_twn); hipFree(a->d_split_scratch); hipFree(a->d_split_counter);
     hipFree(a->fine.d_chips); hipFree(a->fine.d_tw1); hipFree(a->fine.d_tw2); hipFree(a->fine.d_B); hipFree(a->fine.d_mean);
     hipFree(a->fine.d_rowmax); hipFree(a->fine.d_rowarg); hipFree(a->fine.d_sat_worker); hipFree(a->fine.d_sat_cp);
     hipFree(a->fine.d_peak_pow); hipFree(a->fine.d_peak_idx);
@@ -419,15 +420,13 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     if (cfg->tables && !cfg->table_freq) return set_err(GM_ERR_INVALID_ARG, "table_freq required with tables");
     if (cfg->fft_size % 8) return set_err(GM_ERR_ALIGNMENT, "fft_size % 8 != 0");
     const gm::PlanOps* pl = gm::find_plan(int(cfg->fft_size));
+    const gm::CompOps* comp = nullptr;
     uint32_t comp_q = 1;
-    if (!pl) {   // N = Q * Nb with Nb an in-LDS plan (largest Nb first): the composite path
-        for (uint32_t q = 2; q <= 8 && !pl; ++q)
-            if (gm::comp_q_supported(q) && cfg->fft_size % q == 0 && (cfg->fft_size / q) % 8 == 0) {
-                pl = gm::find_plan(int(cfg->fft_size / q));
-                if (pl) comp_q = q;
-            }
+    if (!pl) {   // N = Q * Nb with Nb one of the composite base plans (largest first): acq_composite.hip
+        comp = gm::find_comp(cfg->fft_size);
+        if (comp) { pl = gm::find_plan(comp->nb); comp_q = uint32_t(comp->q); }
     }
-    if (!pl) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this fft_size, nor for fft_size / 2..8");
+    if (!pl) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this fft_size, nor Q x {16000, 8000, 8192, 6000, 5000, 4000} with Q in {2,3,4,5,6,8}");
     if (cfg->strict_sum_order && comp_q > 1)
         return set_err(GM_ERR_INVALID_ARG, "strict_sum_order needs an fft_size with an in-LDS plan (gm_fft_supported_sizes)");
     if (int rc = ensure_device(g_device)) return rc;
@@ -437,7 +436,7 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     a->cfg = *cfg;
     a->plan = pl;
     a->N = cfg->fft_size; a->D = cfg->n_bins; a->M = cfg->n_integrations; a->P = cfg->n_prn;
-    a->Q = comp_q; a->Nb = uint32_t(pl->n);
+    a->Q = comp_q; a->Nb = uint32_t(pl->n); a->comp = comp;
     if (cfg->threshold == 0.0f) a->cfg.threshold = 7.0f;
     a->code_rate = cfg->codes ? (cfg->code_rate > 0 ? cfg->code_rate : CA_RATE) : CA_RATE;
     a->prn_ids.assign(cfg->prn_ids, cfg->prn_ids + a->P);
@@ -517,9 +516,17 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
         pl->code_fft(a->stream, a->d_code_samples, a->d_tw_fwd, a->d_code_fft, int(P));
         HIPA(hipMalloc(&a->d_code_fft_paired, P * N * 8));
         pl->pair_codes(a->stream, a->d_code_fft, a->d_code_fft_paired, int(P));
-    } else {     // same two steps as the signal, so the spectra share its decimated bin order
-        gm::launch_comp_pre(a->stream, nullptr, GM_FMT_C32, nullptr, a->d_code_fft, a->Q, a->Nb, 1, uint32_t(P), a->d_code_samples);
-        pl->fft_batch(a->stream, a->d_code_fft, a->d_tw_fwd, 0, int(P * a->Q));
+    } else {     // the signal's two forward steps on the chips: natural order (the API's view), then every block paired
+        const size_t tmp_items = D * M > P ? D * M : P;
+        HIPA(hipMalloc(&a->d_comp_tmp, tmp_items * N * 8));
+        HIPA(hipMalloc(&a->d_comp_twn, N * 8));
+        HIPA(hipMalloc(&a->d_code_fft_paired, P * N * 8));
+        std::vector<gm::cf> twn(N);
+        comp->fill_twn(twn.data());
+        HIPA(hipMemcpy(a->d_comp_twn, twn.data(), N * 8, hipMemcpyHostToDevice));
+        comp->fwd_sub(a->stream, nullptr, GM_FMT_C32, nullptr, a->d_code_samples, a->d_tw_fwd, a->d_comp_tmp, uint32_t(P), 1);
+        comp->fwd_post(a->stream, a->d_comp_tmp, a->d_code_fft, uint32_t(P), 0);
+        pl->pair_codes(a->stream, a->d_code_fft, a->d_code_fft_paired, int(P * a->Q));
     }
     HIPA(hipGetLastError());
     HIPA(hipStreamSynchronize(a->stream));
@@ -554,21 +561,12 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     const bool t = a->tm.on && (a->tm.calls++ % a->tm.stride == 0);
     a->tm.this_call = t;
     hipEvent_t* ev = t ? &a->tm.ev[size_t(a->tm.count % Timing::CAP) * 4] : nullptr;
-    if (a->Q > 1 && a->n_workers) {    // grow the product buffer before anything is enqueued
-        const size_t need = size_t(a->n_workers) * a->D * a->M * a->N;
-        if (need > a->comp_y_elems) {
-            HIPC(hipStreamSynchronize(a->stream));
-            hipFree(a->d_comp_y); a->d_comp_y = nullptr; a->comp_y_elems = 0;
-            HIPC(hipMalloc(&a->d_comp_y, need * sizeof(cf)));
-            a->comp_y_elems = need;
-        }
-    }
     if (t) HIPC(hipEventRecord(ev[0], a->stream));
     if (a->Q == 1) {
         a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_fwd, a->d_spectra, int(a->D), int(a->M));
     } else {
-        gm::launch_comp_pre(a->stream, d_samples, fmt, a->d_tables, a->d_spectra, a->Q, a->Nb, a->M, a->D * a->M, nullptr);
-        a->plan->fft_batch(a->stream, a->d_spectra, a->d_tw_fwd, 0, int(a->D * a->M * a->Q));
+        a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_fwd, a->d_comp_tmp, a->D * a->M, a->M);
+        a->comp->fwd_post(a->stream, a->d_comp_tmp, a->d_spectra, a->D * a->M, 1);
     }
     if (t) HIPC(hipEventRecord(ev[1], a->stream));
     if (a->Q == 1) {
@@ -576,11 +574,8 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
                       reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M),
                       a->d_split_scratch, a->d_split_counter, a->cfg.strict_sum_order ? 1 : 0);
     } else if (a->n_workers) {
-        const uint32_t n_dm = a->D * a->M;
-        a->plan->comp_corr_fft(a->stream, a->d_spectra, a->d_code_fft, a->d_tw_inv, a->d_comp_y, a->d_worker_list, a->Q, n_dm,
-                               a->n_workers);
-        gm::launch_comp_post(a->stream, a->d_comp_y, a->Q, a->Nb, a->M, a->D, a->d_worker_list, a->n_workers,
-                             reinterpret_cast<float*>(met), met + PD, reinterpret_cast<float*>(met + 2 * PD));
+        a->comp->corr(a->stream, a->d_spectra, a->d_code_fft_paired, a->d_comp_twn, a->d_tw_inv, reinterpret_cast<float*>(met),
+                      met + PD, reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M));
     }
     if (t) { HIPC(hipEventRecord(ev[2], a->stream)); a->tm.count++; a->tm.decide_valid = false; }
     HIPC(hipGetLastError());
@@ -802,15 +797,8 @@ int gm_acq_metrics(gm_acq* a, float* mx, uint32_t* am, float* sm) {
 int gm_acq_code_fft(gm_acq* a, uint32_t worker, gm_c32* out) {
     if (!a || !out || worker >= a->P) return set_err(GM_ERR_INVALID_ARG, "bad worker index");
     if (int rc = ensure_device(a->device)) return rc;
-    if (a->Q == 1) {
-        HIPC(hipMemcpy(out, a->d_code_fft + size_t(worker) * a->N, size_t(a->N) * 8, hipMemcpyDeviceToHost));
-        return GM_OK;
-    }
-    // composite sizes keep the spectrum in decimated order [k1][k2]; hand it out in natural order k = Q*k2 + k1
-    std::vector<gm_c32> tmp(a->N);
-    HIPC(hipMemcpy(tmp.data(), a->d_code_fft + size_t(worker) * a->N, size_t(a->N) * 8, hipMemcpyDeviceToHost));
-    for (uint32_t k1 = 0; k1 < a->Q; ++k1)
-        for (uint32_t k2 = 0; k2 < a->Nb; ++k2) out[size_t(a->Q) * k2 + k1] = tmp[size_t(k1) * a->Nb + k2];
+    // natural order at every size (the composite path keeps blocks k1*Nb + k2 in natural order too)
+    HIPC(hipMemcpy(out, a->d_code_fft + size_t(worker) * a->N, size_t(a->N) * 8, hipMemcpyDeviceToHost));
     return GM_OK;
 }
 

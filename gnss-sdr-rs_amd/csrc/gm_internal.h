@@ -48,9 +48,6 @@ struct PlanOps {
     void (*pair_codes)(hipStream_t, const cf* natural, cf* paired, int n_codes);
     // FFT<T>::execute (fft.rs:21-25) on `batch` contiguous transforms
     void (*fft_batch)(hipStream_t, cf* data, const cf* tw, int inverse, int batch);
-    // composite sizes (N = Q * n): inverse transforms with the x conj(code spectrum) product fused into their loads
-    void (*comp_corr_fft)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, cf* z,
-                          const uint32_t* worker_list, uint32_t Q, uint32_t n_dm, uint32_t n_workers);
     // four-step long FFT passes (power-of-two plans only, else null): this plan as N1 (columns) / as N2 (rows)
     void (*fine_cols)(hipStream_t, const FineArgs&, int n_sats);
     void (*fine_rows)(hipStream_t, const FineArgs&, int n_sats);
@@ -71,12 +68,20 @@ int list_plans(uint32_t* sizes, int cap);
 // diagnostic: device buffer [n_int][8 waves][8 phases] of s_memtime stamps written by workgroup 0 of acq_corr_kernel
 void set_corr_stamps(long long* d_ptr);
 
-// composite transform sizes N = Q * Nb (acq_composite.hip)
-bool comp_q_supported(uint32_t Q);
-void launch_comp_pre(hipStream_t, const void* in, int fmt, const cf* tables, cf* out, uint32_t Q, uint32_t Nb,
-                     uint32_t n_int, uint32_t n_items, const int8_t* code_samples);
-void launch_comp_post(hipStream_t, const cf* z, uint32_t Q, uint32_t Nb, uint32_t n_int, uint32_t n_bins,
-                      const uint32_t* worker_list, uint32_t n_workers, float* mmax, uint32_t* margmax, float* msum);
+// composite transform sizes N = Q * Nb (acq_composite.hip): decimated in time, the inverse fused with the power reduction
+struct CompOps {
+    int nb, q;         // base in-LDS plan length and the factor: N = q * nb
+    // forward step 1: Q in-LDS transforms per item over the decimated inputs (signal: carrier mix fused; codes: int8 chips)
+    void (*fwd_sub)(hipStream_t, const void* samples, int fmt, const cf* tables, const int8_t* code_samples,
+                    const cf* tw_fwd, cf* A, uint32_t n_items, uint32_t n_int);
+    // forward step 2: twiddle + Q-point DFTs -> natural block order; paired != 0 stores each block in the paired layout
+    void (*fwd_post)(hipStream_t, const cf* A, cf* X, uint32_t n_items, int paired);
+    // inverse, fused: {max, first argmax, sum} per (worker, bin) straight from the spectra
+    void (*corr)(hipStream_t, const cf* spectra, const cf* code_paired, const cf* twn, const cf* tw_inv, float* mmax,
+                 uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int);
+    void (*fill_twn)(cf* out);   // host: [q][nb] inverse twiddles W_N^{-n1 k2} in the paired position of k2
+};
+const CompOps* find_comp(uint32_t n);
 
 // elementwise apply_doppler_shift (doppler_shift.rs:25-58)
 void launch_apply_doppler(hipStream_t, const cf* s, const cf* t, cf* out, size_t n);

@@ -103,8 +103,9 @@ typedef struct {
     float fs;                  /* freq_sampling_hz */
     float f_if;                /* used only when `tables` is NULL */
     uint32_t fft_size;         /* samples per code period (do_acquisition.rs:249-251): one of gm_fft_supported_sizes()
-                                  (fused in-LDS kernels), or Q times one of them, Q in {2,3,4,5,6,8} (e.g. 32000 for a
-                                  4 ms code at 8 Msps, 25000 for GPS at 25 Msps: composite path through HBM) */
+                                  (fused in-LDS kernels), or Q x {16000, 8000, 8192, 6000, 5000, 4000}, Q in {2,3,4,5,6,8}
+                                  (e.g. 32000 for a 4 ms code at 8 Msps, 25000 for GPS at 25 Msps: composite path,
+                                  transforms decimated in time, no intermediate plane in HBM) */
     uint32_t n_integrations;   /* LONG_SAMPLES_LENGTH = 10 (:23) */
     uint32_t n_bins;           /* Doppler bins; reference: 14000/500+1 = 29 (:248) */
     const float *doppler_hz;   /* [n_bins] offsets from f_if, ascending as the reference iterates */
