@@ -73,6 +73,7 @@ SIGNATURES = {
     "gm_last_error": (C.c_char_p, []),
     "gm_status_string": (C.c_char_p, [_i]),
     "gm_ca_code_row": (_i, [_i, _vp]),
+    "gm_b1i_code": (_i, [C.c_uint32, _vp, C.c_uint32]),
     "gm_generate_ca_code_samples": (_i, [C.c_uint8, _f, _f, _vp, _sz, C.POINTER(_sz)]),
     "gm_doppler_table_new": (_i, [_f, _f, _f, _sz, C.POINTER(_f), _vp]),
     "gm_apply_doppler_shift": (_i, [_vp, _vp, _vp, _sz]),

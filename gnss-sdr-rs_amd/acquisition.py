@@ -62,6 +62,15 @@ def doppler_grid(span_hz=FREQ_SEARCH_ACQUISITION_HZ, step_hz=FREQ_SEARCH_STEP_HZ
     return np.array([np.float32(-span_hz / 2.0) + np.float32(i) * np.float32(step_hz) for i in range(capacity)], np.float32)
 
 
+def b1i_codes(prns=range(1, 38), n_chips=2046):
+    """BeiDou B1I ranging codes (BDS-SIS-ICD-B1I 11-stage Gold codes) as an int8 [len(prns)][n_chips] table of +-1."""
+    prns = list(prns)
+    t = np.zeros((len(prns), n_chips), np.int8)
+    for i, p in enumerate(prns):
+        check(lib().gm_b1i_code(int(p), _p(t[i]), n_chips), "gm_b1i_code")
+    return t
+
+
 DECIDE_REFERENCE, DECIDE_BEST_BIN = 0, 1   # gm_decision_mode
 
 

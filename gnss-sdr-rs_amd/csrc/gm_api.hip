@@ -75,6 +75,30 @@ const CaTable& ca_table() {
     return t;
 }
 
+// ---- BeiDou B1I ranging codes (BASELINE configs[3]'s third constellation; the reference has no BeiDou code: SURVEY §8c5).
+// BDS-SIS-ICD-B1I: a Gold code of two 11-stage LFSRs, G1(x) = 1 + x + x^7 + x^8 + x^9 + x^10 + x^11 and
+// G2(x) = 1 + x + x^2 + x^3 + x^4 + x^5 + x^8 + x^9 + x^11, both started from 01010101010, truncated by one chip to 2046;
+// satellite i takes G1's output XOR the modulo-2 sum of two G2 stages (phase assignment table below, PRN 1..37).
+const uint8_t kB1iPhase[37][2] = {{1, 3}, {1, 4}, {1, 5}, {1, 6}, {1, 8}, {1, 9}, {1, 10}, {1, 11}, {2, 7}, {3, 4}, {3, 5}, {3, 6},
+                                  {3, 8}, {3, 9}, {3, 10}, {3, 11}, {4, 5}, {4, 6}, {4, 8}, {4, 9}, {4, 10}, {4, 11}, {5, 6}, {5, 8},
+                                  {5, 9}, {5, 10}, {5, 11}, {6, 8}, {6, 9}, {6, 10}, {6, 11}, {8, 9}, {8, 10}, {8, 11}, {9, 10},
+                                  {9, 11}, {10, 11}};
+int b1i_code(uint32_t prn, int8_t* out, uint32_t n_chips) {   // n_chips <= 2047 (2046 = the ICD's truncated code)
+    if (prn < 1 || prn > 37 || n_chips > 2047) return GM_ERR_OUT_OF_RANGE;
+    uint8_t g1[11], g2[11];                      // stage k at index k-1
+    for (int k = 0; k < 11; ++k) g1[k] = g2[k] = uint8_t(k & 1);   // 0 1 0 1 0 1 0 1 0 1 0
+    const int a = kB1iPhase[prn - 1][0] - 1, b = kB1iPhase[prn - 1][1] - 1;
+    for (uint32_t i = 0; i < n_chips; ++i) {
+        const uint8_t chip = g1[10] ^ g2[a] ^ g2[b];
+        out[i] = chip ? -1 : 1;                  // logic 0 -> +1, logic 1 -> -1
+        const uint8_t f1 = g1[0] ^ g1[6] ^ g1[7] ^ g1[8] ^ g1[9] ^ g1[10];
+        const uint8_t f2 = g2[0] ^ g2[1] ^ g2[2] ^ g2[3] ^ g2[4] ^ g2[7] ^ g2[8] ^ g2[10];
+        for (int k = 10; k > 0; --k) { g1[k] = g1[k - 1]; g2[k] = g2[k - 1]; }
+        g1[0] = f1; g2[0] = f2;
+    }
+    return GM_OK;
+}
+
 size_t num_samples_per_code(float code_rate, float fs, float len) {   // ca_code.rs:13-16
     const float v = roundf(fs / (code_rate / len));
     return v > 0.0f ? size_t(v) : 0;
@@ -288,6 +312,12 @@ const char* gm_status_string(int s) {
 }
 
 // ---------------------------------------------------------------- code table / Doppler table (host)
+int gm_b1i_code(uint32_t prn, int8_t* out_chips, uint32_t n_chips) {
+    if (!out_chips) return set_err(GM_ERR_INVALID_ARG, "null out");
+    if (int rc = b1i_code(prn, out_chips, n_chips)) return set_err(rc, "B1I PRN 1..37, at most 2047 chips");
+    return GM_OK;
+}
+
 int gm_ca_code_row(int row, int8_t out[1023]) {
     if (row < 0 || row > 31 || !out) return set_err(GM_ERR_OUT_OF_RANGE, "row must be 0..31");
     memcpy(out, ca_table().rows[row], 1023);

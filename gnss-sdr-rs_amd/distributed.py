@@ -98,3 +98,108 @@ def decide_host(block, prn_ids, table_freq, fft_size, fs, local_tail=0, code_rat
     check(lib().gm_acq_decide_host(p(mx), p(am), p(sm), p(tf), P, D, p(ids), fft_size, fs, code_rate, threshold,
                                    int(local_tail), C.cast(res, C.c_void_p), p(found)), "gm_acq_decide_host")
     return [res[i].as_dict() if found[i] else None for i in range(P)]
+
+
+# ---------------------------------------------------------------------------------------------- mixed-constellation grid
+# BASELINE configs[3]: "GPS + Galileo E1 + BeiDou B1I ~90-PRN acquisition grid sharded 8 x MI355X, RCCL all-gather of
+# peaks".  The codes of all families form ONE list (family-major); ranks take contiguous blocks of it whose sizes differ by at
+# most one (shard_prns: 90 codes on 8 ranks -> 12, 12, 11, ...), so a rank may hold pieces of two families with different
+# transform sizes.  Every rank searches its codes, ONE all-gather of the padded [3][P_max][D] metrics blocks, and every rank
+# replays the reference's decision per family on the gathered grid.
+class GridFamily:
+    def __init__(self, name, fs, f_if, fft_size, n_integrations, doppler_hz, prn_ids, codes=None, code_rate=1.023e6):
+        self.name, self.fs, self.f_if, self.fft_size, self.M = name, float(fs), float(f_if), int(fft_size), int(n_integrations)
+        self.doppler_hz = np.ascontiguousarray(doppler_hz, np.float32)
+        self.prn_ids = list(prn_ids)
+        self.codes = None if codes is None else np.ascontiguousarray(codes, np.int8)
+        self.code_rate = float(code_rate)
+        assert self.codes is None or self.codes.shape[0] == len(self.prn_ids)
+
+    @property
+    def n(self):
+        return len(self.prn_ids)
+
+    def table_freq(self):
+        """DopplerShiftTable.doppler_freq_hz = f_if + doppler (doppler_shift.rs:11,20), f32 like the reference"""
+        return np.array([np.float32(self.f_if) + np.float32(d) for d in self.doppler_hz], np.float32)
+
+
+def shard_grid(families, world, rank):
+    """-> [(family index, first local code, count)] of this rank's contiguous block of the family-major code list."""
+    total = sum(f.n for f in families)
+    mine = shard_prns(list(range(total)), world, rank)
+    out, base = [], 0
+    for fi, f in enumerate(families):
+        loc = [g - base for g in mine if base <= g < base + f.n]
+        if loc:
+            out.append((fi, loc[0], len(loc)))
+        base += f.n
+    return out
+
+
+def grid_pmax(families, world):
+    total = sum(f.n for f in families)
+    return (total + world - 1) // world
+
+
+def grid_assemble(gathered, families, world, D):
+    """gathered: int32 array [world][3][P_max][D] (one padded block per rank) -> {family index: int32 [3][n_family][D]}."""
+    pmax = grid_pmax(families, world)
+    g = np.ascontiguousarray(gathered, np.int32).reshape(world, 3, pmax, D)
+    out = {fi: np.zeros((3, f.n, D), np.int32) for fi, f in enumerate(families)}
+    for r in range(world):
+        row = 0
+        for fi, first, cnt in shard_grid(families, world, r):
+            out[fi][:, first:first + cnt, :] = g[r][:, row:row + cnt, :]
+            row += cnt
+    return out
+
+
+def grid_decide(assembled, families, local_tail=0, threshold=7.0):
+    """The reference's decision (do_acquisition.rs:195-238) per family on the assembled grid -> {family: [result | None]}."""
+    return {f.name: decide_host(assembled[fi], f.prn_ids, f.table_freq(), f.fft_size, f.fs, local_tail, f.code_rate, threshold)
+            for fi, f in enumerate(families)}
+
+
+class MixedGrid:
+    """This rank's engines for its block of the grid (GPU).  search_dev() fills the padded local block; the caller does
+    the all-gather (torch.distributed / gm_comm) and grid_assemble + grid_decide."""
+
+    def __init__(self, families, world, rank):
+        import torch
+        from . import acquisition as A
+        self.families, self.world, self.rank = families, world, rank
+        self.D = int(families[0].doppler_hz.size)
+        assert all(f.doppler_hz.size == self.D for f in families), "one Doppler grid for the whole exchange block"
+        self.pmax = grid_pmax(families, world)
+        self.parts = []
+        row = 0
+        for fi, first, cnt in shard_grid(families, world, rank):
+            f = families[fi]
+            eng = A.AcquisitionEngine(f.fs, f.f_if, f.fft_size, doppler_hz=f.doppler_hz, prn_ids=f.prn_ids[first:first + cnt],
+                                      n_integrations=f.M, codes=None if f.codes is None else f.codes[first:first + cnt],
+                                      code_rate=f.code_rate)
+            met = torch.zeros(3 * cnt * self.D, dtype=torch.int32, device="cuda")
+            self.parts.append(dict(fi=fi, eng=eng, met=met, row=row, cnt=cnt))
+            row += cnt
+        self.block = torch.zeros(3 * self.pmax * self.D, dtype=torch.int32, device="cuda")
+
+    def set_stream(self, stream_ptr):
+        for p in self.parts:
+            p["eng"].set_stream(stream_ptr)
+
+    def search_dev(self, samples_ptr_by_family, fmt):
+        """samples_ptr_by_family: {family index: device pointer to that family's n_integrations * fft_size samples}"""
+        b = self.block.view(3, self.pmax, self.D)
+        for p in self.parts:
+            p["eng"].search_dev(samples_ptr_by_family[p["fi"]], fmt, p["met"].data_ptr())
+            b[:, p["row"]:p["row"] + p["cnt"], :] = p["met"].view(3, p["cnt"], self.D)
+        return self.block
+
+    def cells(self):
+        return sum(f.n * self.D * f.fft_size for f in self.families)
+
+    def close(self):
+        for p in self.parts:
+            p["eng"].close()
+        self.parts = []

@@ -57,6 +57,10 @@ const char *gm_status_string(int status);
 /* ------------------------------------------------------------------ constants / code table
  * GPS_CA_CODE_32_PRN (src/constants/gps_ca_constants.rs:1-1346): row r <-> PRN r+1, chips +-1. */
 int gm_ca_code_row(int row, int8_t out_chips[1023]);
+/* BeiDou B1I ranging code of PRN 1..37 (BDS-SIS-ICD-B1I: 11-stage Gold code, 2046 chips at 2.046 Mcps; +1 <-> logic 0).
+ * Not in the reference (its README names BeiDou, its code has GPS only): provided for BASELINE configs[3]'s grid, to be
+ * passed as gm_acq_cfg.codes.  n_chips = 2046 for the ICD's code; 2047 yields the untruncated period. */
+int gm_b1i_code(uint32_t prn, int8_t *out_chips, uint32_t n_chips);
 /* generate_ca_code_samples(prn, code_rate, f_sampling) (src/utilities/ca_code.rs:12-27).
  * *n_out = round(fs/(code_rate/1023)); writes min(n, cap) samples.  GM_ERR_OUT_OF_RANGE where the
  * reference would panic (prn not in 1..=32, chip index reaching 1023). */

@@ -169,3 +169,41 @@ def test_rust_binding_source_matches_the_abi(gm):
     # and INTEGRATION.md carries the same code
     integ = open(os.path.join(root, "INTEGRATION.md")).read()
     assert "pub decision_mode: i32" in integ and "pub decision_mode: i32" in src
+
+
+def test_beidou_b1i_codes_known_properties(gm):
+    """gm_b1i_code (BDS-SIS-ICD-B1I 11-stage Gold codes; not in the reference): equal to an independent restatement of the
+    generator, and with the published properties of a Gold family of degree 11 — both LFSRs maximal (period 2047), periodic
+    auto- and cross-correlations of the untruncated codes three-valued {-1, -65, 63}, the ICD's code = the first 2046 chips."""
+    from gnss_sdr_rs_amd import acquisition as A
+    full = A.b1i_codes(range(1, 38), 2047).astype(np.int64)
+    code = A.b1i_codes()
+    assert code.shape == (37, 2046) and (full[:, :2046] == code).all() and set(np.unique(code)) == {-1, 1}
+
+    def lfsr(taps):
+        reg = [k & 1 for k in range(11)]                    # 0 1 0 1 0 1 0 1 0 1 0, stage k at index k-1
+        out = []
+        for _ in range(2047):
+            out.append(list(reg))
+            fb = 0
+            for t in taps:
+                fb ^= reg[t - 1]
+            reg = [fb] + reg[:10]
+        return np.array(out, np.uint8)
+    g1, g2 = lfsr([1, 7, 8, 9, 10, 11]), lfsr([1, 2, 3, 4, 5, 8, 9, 11])
+    assert len({tuple(r) for r in g1}) == 2047 and len({tuple(r) for r in g2}) == 2047          # m-sequences
+    phases = [(1, 3), (1, 4), (1, 5), (1, 6), (1, 8), (1, 9), (1, 10), (1, 11), (2, 7), (3, 4), (3, 5), (3, 6), (3, 8), (3, 9), (3, 10),
+              (3, 11), (4, 5), (4, 6), (4, 8), (4, 9), (4, 10), (4, 11), (5, 6), (5, 8), (5, 9), (5, 10), (5, 11), (6, 8), (6, 9), (6, 10),
+              (6, 11), (8, 9), (8, 10), (8, 11), (9, 10), (9, 11), (10, 11)]
+    for p, (a, b) in enumerate(phases):
+        bits = g1[:, 10] ^ g2[:, a - 1] ^ g2[:, b - 1]
+        assert (np.where(bits > 0, -1, 1) == full[p]).all(), p + 1
+    F = np.fft.fft(full, axis=1)
+    vals = set()
+    for i in range(37):
+        for j in (i, (i + 5) % 37, (i + 11) % 37):
+            cc = np.round(np.fft.ifft(F[i] * np.conj(F[j])).real).astype(int)
+            vals |= set(np.unique(cc[1:] if i == j else cc).tolist())
+            if i == j:
+                assert cc[0] == 2047
+    assert vals == {-65, -1, 63}
