@@ -1,10 +1,14 @@
-// mi355x.rs — the ONE module a maintainer adds to kewei/gnss-sdr-rs to put the MI355X path behind the crate's own
-// acquisition / tracking API.  Mirror of include/gnss_mi355x.h (raw bindings) + safe wrappers with the
-// reference's names.  Shipped as source: the build image has no Rust toolchain, so this file was NOT compiled here; the
-// same ABI is exercised end to end by gnss-sdr-rs_amd/host/gnss_sdr.hpp + tests/cpp/test_host_api.cpp (C++) and by the
-// ctypes mirror used in tests/ (Python).  Generated from the code blocks of INTEGRATION.md (keep the two in step).
+// mi355x.rs — raw bindings of include/gnss_mi355x.h for kewei/gnss-sdr-rs: the `extern "C"` block and
+// the #[repr(C)] mirrors.  The wrappers that carry the reference's own names and signatures live next to it:
+//   doppler_shift.rs   DopplerShiftTable::new, apply_doppler_shift                       (src/acquisition/doppler_shift.rs:5-40)
+//   do_acquisition.rs  AcquisitionWorker::{new, search_satellite}, AcquisitionEngine     (src/acquisition/do_acquisition.rs:130-226, 268-313)
+//   do_tracking.rs     TrackingChannel::{new, start, is_active, update, early_late_correlation, get_ca_chip,
+//                      run_loop_filters, reset}, TrackingManager::{new, process_channels} (src/tracking/do_tracking.rs:88-382)
+//   fft.rs             FFT<f32>, RealFFT<f32>                                            (src/fft.rs:5-56)
+// Shipped as source: the build image has no Rust toolchain, so these files were NOT compiled here; the same ABI is
+// exercised end to end by gnss-sdr-rs_amd/host/gnss_sdr.hpp + tests/cpp/test_host_api.cpp (C++) and by the ctypes mirror
+// used in tests/ (Python); tests/test_abi_and_host.py checks struct layouts, extern names and wrapper signatures.
 #![allow(non_camel_case_types, dead_code)]
-use crate::acquisition::do_acquisition::{AcqError, AcquisitionResult};
 
 // ------------------------------------------------------------------ raw bindings
 use num_complex::Complex32;
@@ -69,12 +73,18 @@ extern "C" {
     pub fn gm_ring_create(buf_size: usize, out: *mut *mut GmRing) -> c_int;
     pub fn gm_ring_destroy(r: *mut GmRing) -> c_int;
     pub fn gm_ring_write_samples(r: *mut GmRing, s: *const Complex32, n: usize) -> c_int;
+    pub fn gm_ring_get_head(r: *mut GmRing, head: *mut u64) -> c_int;
     // do_tracking.rs:118-158, 311-327
     pub fn gm_trk_create(cfg: *const GmTrkCfg, out: *mut *mut GmTrk) -> c_int;
     pub fn gm_trk_destroy(t: *mut GmTrk) -> c_int;
     pub fn gm_trk_start(t: *mut GmTrk, ch: u32, r: *const GmAcqResult) -> c_int;
     pub fn gm_trk_reset(t: *mut GmTrk, ch: u32) -> c_int;
     pub fn gm_trk_get_state(t: *mut GmTrk, ch: u32, out: *mut GmTrkState) -> c_int;
+    pub fn gm_trk_set_state(t: *mut GmTrk, ch: u32, state: *const GmTrkState) -> c_int;
+    // do_tracking.rs:274-277, :52-71
+    pub fn gm_trk_get_ca_chip(t: *mut GmTrk, ch: u32, phase: f32, chip: *mut f32) -> c_int;
+    pub fn gm_loop_filter_new(noise_bw: f32, damping: f32, gain: f32, tau1: *mut f32, tau2: *mut f32) -> c_int;
+    pub fn gm_loop_filter_update(tau1: f32, tau2: f32, d_err: f32, err: f32, dt: f32) -> f32;
     // do_tracking.rs:231-272, :183-210 on caller samples; :351-371 batched over the ring
     pub fn gm_trk_correlate(t: *mut GmTrk, ch: u32, s: *const Complex32, n: usize, out: *mut GmTrkOut) -> c_int;
     pub fn gm_trk_do_work(t: *mut GmTrk, ch: u32, s: *const Complex32, n: usize, out: *mut GmTrkOut,
@@ -83,6 +93,7 @@ extern "C" {
                              processed: *mut u8, lost: *mut u8, epochs_done: *mut u32) -> c_int;
     // fft.rs:5-56
     pub fn gm_fft_c2c_f32(n: usize, dir: c_int, inout: *mut Complex32, batch: usize) -> c_int;
+    pub fn gm_fft_power_spectrum_f32(n: usize, inout: *mut Complex32, power: *mut f32) -> c_int;
     pub fn gm_rfft_f32(n: usize, input: *const f32, out: *mut Complex32) -> c_int;
     // multi-GPU (nothing to replace in the reference; rayon's fan-out :302-313 becomes one process per GPU)
     pub fn gm_acq_search_dev(a: *mut GmAcq, d_samples: *const c_void, fmt: c_int, d_metrics: *mut c_void) -> c_int;
@@ -94,44 +105,7 @@ extern "C" {
     pub fn gm_acq_fetch_results(a: *mut GmAcq, n_prn: u32, results: *mut GmAcqResult, found: *mut u8) -> c_int;
 }
 
-// ------------------------------------------------------------------ safe wrappers
-pub struct AcquisitionEngine { h: *mut GmAcq, n_prn: usize }   // replaces Vec<AcquisitionWorker> in run() (:268-271)
-unsafe impl Send for AcquisitionEngine {}
-
-impl AcquisitionEngine {
-    /// what run() builds at :248-271: the Doppler grid and the 32 workers
-    pub fn new(fs: f32, f_if: f32, fft_size: usize, doppler_hz: &[f32], prn_ids: &[u8], n_int: usize) -> Result<Self, AcqError> {
-        let cfg = GmAcqCfg { fs, f_if, fft_size: fft_size as u32, n_integrations: n_int as u32,
-            n_bins: doppler_hz.len() as u32, doppler_hz: doppler_hz.as_ptr(), tables: std::ptr::null(),
-            table_freq: std::ptr::null(), n_prn: prn_ids.len() as u32, prn_ids: prn_ids.as_ptr(),
-            codes: std::ptr::null(), code_len: 0, code_rate: 0.0, threshold: 7.0, decision_mode: 0, strict_sum_order: 0 };
-        let mut h = std::ptr::null_mut();
-        if unsafe { gm_acq_create(&cfg, &mut h) } != 0 { return Err(AcqError); }
-        Ok(Self { h, n_prn: prn_ids.len() })
-    }
-    /// the body of `workers.par_iter_mut().enumerate().filter_map(..search_satellite..)` (:302-313)
-    pub fn search(&mut self, chunk: &[Complex32], local_tail: usize, mask: u32) -> Vec<AcquisitionResult> {
-        let mut raw = vec![GmAcqResult::default(); self.n_prn];
-        let mut found = vec![0u8; self.n_prn];
-        let st = unsafe { gm_acq_search_c32(self.h, chunk.as_ptr(), chunk.len(), local_tail as u64, mask as u64,
-                                            raw.as_mut_ptr(), found.as_mut_ptr()) };
-        assert_eq!(st, 0, "gm_acq_search_c32");      // the reference panics on a short chunk (:176)
-        raw.iter().zip(found).filter(|(_, f)| *f != 0).map(|(r, _)| AcquisitionResult {
-            prn: r.prn, code_phase_samples: r.code_phase_samples as usize, code_phase_chips: r.code_phase_chips,
-            carrier_freq: r.carrier_freq, fs: r.fs, mag_relative: r.mag_relative,
-            sample_global_index: r.sample_global_index as usize }).collect()
-    }
+/// status -> the last error text of the library (for panics that mirror the reference's)
+pub fn last_error() -> String {
+    unsafe { std::ffi::CStr::from_ptr(gm_last_error()).to_string_lossy().into_owned() }
 }
-impl Drop for AcquisitionEngine { fn drop(&mut self) { unsafe { gm_acq_destroy(self.h); } } }
-
-// ------------------------------------------------------------------ TrackingManager::process_channels (do_tracking.rs:351-371)
-// the body that replaces the par_iter_mut fan-out (shown as it would sit inside `impl TrackingManager`):
-/*
-while let Ok(msg) = self.acq_to_trk.try_recv() {                       // unchanged (:352-362)
-    if let Some(ch) = self.idle_channel() { let _ = self.trk_to_acq.send(TrackingMessage::SatelliteLocked(msg.prn));
-        unsafe { gm_trk_start(self.h, ch, &to_raw(&msg)); } } }
-let mut lost = vec![0u8; LOOP_MS * self.n]; let mut done = 0u32;
-unsafe { gm_trk_update_all(self.h, self.ring, LOOP_MS as u32, std::ptr::null_mut(), std::ptr::null_mut(),
-                           lost.as_mut_ptr(), &mut done); }            // replaces par_iter_mut().for_each(update) (:364-371)
-for (i, l) in lost.iter().enumerate() { if *l != 0 { let _ = self.trk_to_acq.send(TrackingMessage::SatelliteLost(0)); } }
-*/

@@ -145,30 +145,74 @@ def test_device_atanf_restatement_matches_host_libm_bit_for_bit():
 
 
 def test_rust_binding_source_matches_the_abi(gm):
-    """rust/src/mi355x.rs (the reference-side binding shipped as source) cannot be compiled here, so its
-    layout is checked structurally: every #[repr(C)] struct lists the same fields in the same order as the ctypes mirror
-    the test suite exercises, and every extern fn it declares exists in include/gnss_mi355x.h."""
+    """rust/src/*.rs (the reference-side binding shipped as source) cannot be compiled here, so it is
+    checked structurally: every #[repr(C)] struct lists the same fields in the same order as the ctypes mirror the test
+    suite exercises; every extern fn exists in include/gnss_mi355x.h; every gm_* call made by a wrapper file is declared
+    in mi355x.rs; and every wrapper carries the reference's own signature (do_acquisition.rs:130-226,
+    doppler_shift.rs:5-40, do_tracking.rs:88-382, fft.rs:5-56)."""
     from gnss_sdr_rs_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "rust", "src", "mi355x.rs")).read()
+    rs = {n: open(os.path.join(root, "rust", "src", n)).read()
+          for n in ("mi355x.rs", "doppler_shift.rs", "do_acquisition.rs", "do_tracking.rs", "fft.rs")}
+    src = rs["mi355x.rs"]
     hdr = open(os.path.join(root, "include", "gnss_mi355x.h")).read()
 
-    def rust_fields(name):
-        body = re.search(r"pub struct %s\s*\{([^}]*)\}" % name, src, re.S).group(1)
+    def rust_fields(text, name):
+        body = re.search(r"pub struct %s\s*\{([^}]*)\}" % name, text, re.S).group(1)
         body = re.sub(r"//[^\n]*", "", body)
         return re.findall(r"pub\s+(\w+)\s*:", body)
 
     pairs = {"GmAcqResult": _lib.AcqResult, "GmAcqCfg": _lib.AcqCfg, "GmTrkState": _lib.TrkState, "GmTrkOut": _lib.TrkOut,
              "GmTrkCfg": _lib.TrkCfg}
     for rname, ct in pairs.items():
-        assert rust_fields(rname) == [f[0] for f in ct._fields_], rname
+        assert rust_fields(src, rname) == [f[0] for f in ct._fields_], rname
     fns = set(re.findall(r"pub fn (gm_\w+)\s*\(", src))
-    assert len(fns) >= 25
+    assert len(fns) >= 30
     declared = set(re.findall(r"\b(gm_[a-z0-9_]+)\s*\(", hdr))
     assert fns <= declared, sorted(fns - declared)
-    # and INTEGRATION.md carries the same code
+    # every library call of a wrapper file is bound in mi355x.rs
+    for name, text in rs.items():
+        if name == "mi355x.rs":
+            continue
+        code = re.sub(r"//[^\n]*", "", text)
+        used = set(re.findall(r"\b(gm_[a-z0-9_]+)\s*\(", code))
+        assert used and used <= fns, (name, sorted(used - fns))
+
+    def flat(t):
+        return re.sub(r"\s+", " ", re.sub(r"//[^\n]*", "", t))
+    sigs = {
+        "doppler_shift.rs": ["pub struct DopplerShiftTable { pub doppler_freq_hz: f32, pub table: Vec<Complex32>, }",
+                             "pub fn new(f_if: f32, doppler_freq_hz: f32, fs: f32, num_samples: usize) -> Self",
+                             "pub fn apply_doppler_shift(samples: &[Complex32], doppler_table: &DopplerShiftTable, output: &mut [Complex32])"],
+        "do_acquisition.rs": ["pub fn new(prn: u8, fft_size: usize, freq_sampling_hz: f32) -> Self",
+                              "pub fn search_satellite( &mut self, samples_chunk: &[Complex32], doppler_table: &[DopplerShiftTable], "
+                              "local_tail: usize, num_integrations: usize, ) -> Option<AcquisitionResult>"],
+        "do_tracking.rs": ["pub fn new(id: u8, fs: f32) -> Self", "pub fn start(&mut self, result: AcquisitionResult)",
+                           "pub fn is_active(&self) -> bool",
+                           "pub fn update(&mut self, buff: Arc<MulticastRingBuffer>) -> Option<TrackingMessage>",
+                           "pub fn early_late_correlation(&mut self) -> (f32, f32, f32, f32, f32, f32)",
+                           "pub fn get_ca_chip(&self, phase: f32) -> f32",
+                           "pub fn run_loop_filters(&mut self, i_p: f32, q_p: f32, i_e: f32, q_e: f32, i_l: f32, q_l: f32)",
+                           "pub fn reset(&mut self)",
+                           "pub fn new( acq_to_trk: Receiver<AcquisitionResult>, trk_to_acq: Sender<TrackingMessage>, fs: f32, ) -> Self",
+                           "pub fn process_channels(&mut self, multi_ring_buf: Arc<MulticastRingBuffer>)"],
+        "fft.rs": ["pub fn new(len: usize) -> Self", "pub fn execute(&self, input: &mut [Complex<T>]) -> Vec<Complex<T>>",
+                   "pub fn power_spectrum(&self, input: &mut [Complex<T>]) -> Vec<T>",
+                   "pub fn execute(&self, input: &mut [T]) -> Vec<Complex<T>>", "pub fn power_spectrum(&self, input: &mut [T]) -> Vec<T>"],
+    }
+    for name, want in sigs.items():
+        f = flat(rs[name])
+        for w in want:
+            assert flat(w) in f, (name, w)
+    # TrackingChannel keeps the reference's 22 pub fields, in order (do_tracking.rs:88-116)
+    assert rust_fields(rs["do_tracking.rs"], "TrackingChannel") == [
+        "id", "prn", "state", "lost_counter", "fs", "next_sample_index", "num_samples_per_code", "ca_code_samples", "data_samples",
+        "carrier_freq", "carrier_phase", "carrier_error", "carrier_nco", "code_phase", "code_error", "code_nco", "code_rate",
+        "cos_p", "sin_p", "i_prompt", "q_prompt", "pll_filter", "dll_filter"]
+    assert rust_fields(rs["do_tracking.rs"], "TrackingManager") == ["channels", "acq_to_trk", "trk_to_acq"]
+    # and INTEGRATION.md carries the same bindings
     integ = open(os.path.join(root, "INTEGRATION.md")).read()
-    assert "pub decision_mode: i32" in integ and "pub decision_mode: i32" in src
+    assert "pub strict_sum_order: i32" in integ and "pub fn search_satellite(" in integ and "pub fn process_channels(" in integ
 
 
 def test_beidou_b1i_codes_known_properties(gm):
