@@ -382,10 +382,57 @@ static int fft_run(size_t n, int dir, cf* d_data, size_t batch, hipStream_t st) 
     return GM_OK;
 }
 
+// FFT<T>::new is generic over the length (src/fft.rs:10-19: rustfft plans any N).  Lengths without an in-LDS plan go
+// through Bluestein's chirp-z identity on the smallest power-of-two plan L >= 2N - 1:
+//   X[k] = c[k] * sum_n (x[n] c[n]) conj(c[k - n]),   c[n] = exp(-j pi n^2 / N)   (phase from n^2 mod 2N: exact in integers)
+// i.e. one length-L circular convolution = two forward transforms (the chirp's is cached per N) and one inverse on the
+// device; the three O(N) chirp products are host loops (this entry takes and returns host buffers).  N <= 8192.
+static int fft_bluestein(size_t n, int dir, gm_c32* inout, size_t batch) {
+    size_t L = 256;
+    while (L < 2 * n - 1) L *= 2;
+    if (L > 16384 || !gm::find_plan(int(L))) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this length, and 2N-1 > 16384 (Bluestein)");
+    std::vector<cf> c(n), b(L, gm::cf_make(0.f, 0.f));
+    for (size_t i = 0; i < n; ++i) {
+        const double a = M_PI * double((uint64_t(i) * i) % (2 * n)) / double(n);
+        c[i] = gm::cf_make(float(cos(a)), float(-sin(a)));
+    }
+    b[0] = gm::cf_make(1.f, 0.f);
+    for (size_t i = 1; i < n; ++i) b[i] = b[L - i] = gm::cf_make(c[i].x, -c[i].y);
+    cf *d_b = nullptr, *d_a = nullptr, *d_y = nullptr;
+    int rc = GM_OK;
+    auto done = [&](int code) { hipFree(d_b); hipFree(d_a); hipFree(d_y); return code; };
+    if (hipMalloc(&d_b, L * 8) != hipSuccess || hipMalloc(&d_a, L * 8) != hipSuccess || hipMalloc(&d_y, L * 8) != hipSuccess)
+        return done(set_err(GM_ERR_HIP, "hipMalloc"));
+    if (hipMemcpy(d_b, b.data(), L * 8, hipMemcpyHostToDevice) != hipSuccess) return done(set_err(GM_ERR_HIP, "hipMemcpy"));
+    if ((rc = fft_run(L, 0, d_b, 1, nullptr))) return done(rc);
+    std::vector<cf> a(L), y(L);
+    const float inv_l = 1.0f / float(L);
+    for (size_t it = 0; it < batch; ++it) {
+        gm_c32* x = inout + it * n;
+        for (size_t i = 0; i < L; ++i) a[i] = gm::cf_make(0.f, 0.f);
+        for (size_t i = 0; i < n; ++i) {       // inverse transform: conj(FFT(conj(x)))
+            const cf xi = gm::cf_make(x[i].re, dir ? -x[i].im : x[i].im);
+            a[i] = gm::cf_make(xi.x * c[i].x - xi.y * c[i].y, xi.x * c[i].y + xi.y * c[i].x);
+        }
+        if (hipMemcpy(d_a, a.data(), L * 8, hipMemcpyHostToDevice) != hipSuccess) return done(set_err(GM_ERR_HIP, "hipMemcpy"));
+        if ((rc = fft_run(L, 0, d_a, 1, nullptr))) return done(rc);
+        gm::launch_apply_doppler(nullptr, d_a, d_b, d_y, L);                    // elementwise complex product (L % 4 == 0)
+        if (hipGetLastError() != hipSuccess) return done(set_err(GM_ERR_HIP, "product kernel"));
+        if ((rc = fft_run(L, 1, d_y, 1, nullptr))) return done(rc);
+        if (hipMemcpy(y.data(), d_y, L * 8, hipMemcpyDeviceToHost) != hipSuccess) return done(set_err(GM_ERR_HIP, "hipMemcpy"));
+        for (size_t k = 0; k < n; ++k) {
+            const float yr = y[k].x * inv_l, yi = y[k].y * inv_l;
+            const float re = yr * c[k].x - yi * c[k].y, im = yr * c[k].y + yi * c[k].x;
+            x[k].re = re; x[k].im = dir ? -im : im;
+        }
+    }
+    return done(GM_OK);
+}
+
 int gm_fft_c2c_f32(size_t n, int dir, gm_c32* inout, size_t batch) {
     if (!inout || !n || !batch) return set_err(GM_ERR_INVALID_ARG, "null or empty");
     if (int rc = ensure_device(g_device)) return rc;
-    if (!gm::find_plan(int(n))) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this length");
+    if (!gm::find_plan(int(n))) return fft_bluestein(n, dir, inout, batch);
     cf* d = nullptr;
     HIPC(hipMalloc(&d, n * batch * 8));
     HIPC(hipMemcpy(d, inout, n * batch * 8, hipMemcpyHostToDevice));
@@ -398,7 +445,11 @@ int gm_fft_c2c_f32(size_t n, int dir, gm_c32* inout, size_t batch) {
 int gm_fft_power_spectrum_f32(size_t n, gm_c32* inout, float* power) {
     if (!inout || !power || !n) return set_err(GM_ERR_INVALID_ARG, "null or empty");
     if (int rc = ensure_device(g_device)) return rc;
-    if (!gm::find_plan(int(n))) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this length");
+    if (!gm::find_plan(int(n))) {            // any other length: Bluestein, then |X|^2 on the host
+        if (int rc = fft_bluestein(n, 0, inout, 1)) return rc;
+        for (size_t i = 0; i < n; ++i) power[i] = inout[i].re * inout[i].re + inout[i].im * inout[i].im;   // norm_sqr (fft.rs:28)
+        return GM_OK;
+    }
     cf* d = nullptr; float* dp = nullptr;
     HIPC(hipMalloc(&d, n * 8)); HIPC(hipMalloc(&dp, n * 4));
     HIPC(hipMemcpy(d, inout, n * 8, hipMemcpyHostToDevice));

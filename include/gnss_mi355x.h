@@ -79,7 +79,8 @@ int gm_apply_doppler_shift(const gm_c32 *samples, const gm_c32 *table, gm_c32 *o
 
 /* ------------------------------------------------------------------ FFT<T> / RealFFT<T> (src/fft.rs:5-56)
  * Unnormalised complex FFT, in place, `batch` contiguous transforms of length n.
- * dir: 0 forward (FFT::execute), 1 inverse. */
+ * dir: 0 forward (FFT::execute), 1 inverse.  n: one of gm_fft_supported_sizes() (one in-LDS transform), or ANY other
+ * length up to 8192 (Bluestein on the smallest power-of-two plan >= 2n - 1; the reference's FFT<T> is generic over n). */
 int gm_fft_c2c_f32(size_t n, int dir, gm_c32 *inout, size_t batch);
 /* FFT::power_spectrum (src/fft.rs:27-29): transforms `inout` in place and writes |X|^2. */
 int gm_fft_power_spectrum_f32(size_t n, gm_c32 *inout, float *power);

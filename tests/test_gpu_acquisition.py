@@ -40,10 +40,31 @@ def test_fft_all_plans_vs_float64_and_oracle(gpu, oracle):
     assert np.allclose(ps, np.abs(np.fft.fft(xs.astype(np.complex128))) ** 2, rtol=1e-4)
 
 
+def test_fft_arbitrary_lengths_bluestein(gpu, oracle):
+    """FFT<T>::new(len) is generic over len (src/fft.rs:10-19): lengths without an in-LDS plan run Bluestein's identity on
+    a power-of-two plan.  Primes, prime powers, odd / even composites, 1 and 2, forward and inverse, batch, power spectrum,
+    real input — against float64 (the oracle's mixed-radix FFT covers only smooth lengths)."""
+    from gnss_sdr_rs_amd import fft
+    rng = np.random.default_rng(17)
+    for n in (1, 2, 3, 7, 127, 1000, 1023, 2046, 4093, 6138, 8191):
+        assert n not in fft.supported_sizes()
+        x = (rng.standard_normal(2 * n) + 1j * rng.standard_normal(2 * n)).astype(np.complex64)
+        for inv in (False, True):
+            y = fft.FFT(n).execute(x.copy(), inverse=inv).reshape(2, n)
+            for b in range(2):
+                xb = x[b * n:(b + 1) * n].astype(np.complex128)
+                ref = np.fft.ifft(xb) * n if inv else np.fft.fft(xb)
+                assert np.linalg.norm(y[b] - ref) / np.linalg.norm(ref) < 3e-6, (n, inv)
+    xs = (rng.standard_normal(1023) + 1j * rng.standard_normal(1023)).astype(np.complex64)
+    assert np.allclose(fft.FFT(1023).power_spectrum(xs.copy()), np.abs(np.fft.fft(xs.astype(np.complex128))) ** 2, rtol=2e-4, atol=1e-2)
+    r = rng.standard_normal(1000).astype(np.float32)
+    assert np.allclose(fft.RealFFT(1000).execute(r), np.fft.rfft(r.astype(np.float64)), rtol=0, atol=2e-3)
+
+
 def test_fft_unsupported_size(gpu):
     from gnss_sdr_rs_amd import fft, GmError
     with pytest.raises(GmError) as e:
-        fft.FFT(1000).execute(np.zeros(1000, np.complex64))
+        fft.FFT(8200).execute(np.zeros(8200, np.complex64))     # no plan, and 2n - 1 > 16384
     assert e.value.status == -2
 
 
