@@ -1164,6 +1164,7 @@ struct gm_trk {
     int G = 1;
     unsigned long long* d_xchg = nullptr;
     int* d_error = nullptr;             // host-pinned, device-visible: written by the kernel only when an exchange times out
+    int* d_error_dev = nullptr;         // its device-memory twin, read by every later launch (trk_persistent_kernel)
     uint32_t launch_seq = 0;
     long long* d_stamps = nullptr; uint32_t stamps_cap = 0;   // diagnostic phase stamps (gm_trk_debug_stamps)
 };
@@ -1195,7 +1196,7 @@ int gm_trk_destroy(gm_trk* t) {
     if (t->device >= 0) hipSetDevice(t->device);
     hipFree(t->d_codes); hipFree(t->d_states); hipFree(t->d_partials); hipFree(t->d_ready); hipFree(t->d_scratch);
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
-    hipFree(t->d_xchg); if (t->d_error) hipHostFree(t->d_error); hipFree(t->d_stamps);
+    hipFree(t->d_xchg); if (t->d_error) hipHostFree(t->d_error); hipFree(t->d_error_dev); hipFree(t->d_stamps);
     if (t->ev0) hipEventDestroy(t->ev0);
     if (t->ev1) hipEventDestroy(t->ev1);
     if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
@@ -1287,6 +1288,8 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
         HIPT(hipMemset(t->d_xchg, 0, xb));
         HIPT(hipHostMalloc(reinterpret_cast<void**>(&t->d_error), sizeof(int), hipHostMallocDefault));   // read on the host after a stream sync: no copy
         *t->d_error = 0;
+        HIPT(hipMalloc(&t->d_error_dev, sizeof(int)));
+        HIPT(hipMemset(t->d_error_dev, 0, sizeof(int)));
     }
     if (int rc = trk_reserve_epochs(t, 1)) return fail(rc);
 #undef HIPT
@@ -1443,7 +1446,7 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
         if (t->launch_seq == 0) t->launch_seq = 1;
         gm::launch_trk_persistent(t->stream, t->dc, t->d_codes, t->d_states, ring->d_buf, ring->mask, ring->head.load(std::memory_order_acquire), t->G,
                                   int(ne), t->launch_seq << 12, t->d_xchg, t->d_outs + o, t->d_proc + o, t->d_lost + o,
-                                  t->d_lostprn + o, t->d_error, (t->d_stamps && e0 == 0 && ne <= t->stamps_cap) ? t->d_stamps : nullptr);
+                                  t->d_lostprn + o, t->d_error, t->d_error_dev, (t->d_stamps && e0 == 0 && ne <= t->stamps_cap) ? t->d_stamps : nullptr);
     }
     if (t->timing) { HIPC(hipEventRecord(t->ev1, t->stream)); t->timed_launches = epochs; }
     HIPC(hipEventRecord(chain.ev, t->stream));
@@ -1479,6 +1482,7 @@ static int trk_check_error(gm_trk* t) {
     const int err = *static_cast<volatile int*>(t->d_error);      // the stream has been synchronised by the caller
     if (err) {
         *t->d_error = 0;
+        (void)hipMemset(t->d_error_dev, 0, sizeof(int));
         return set_err(GM_ERR_HIP, "tracking: inter-workgroup exchange timed out (workgroups of a channel not co-resident?)");
     }
     return GM_OK;

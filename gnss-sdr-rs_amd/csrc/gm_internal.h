@@ -150,7 +150,7 @@ int trk_persistent_blocks_per_cu(const TrkDevCfg&);   // resident workgroups per
 void launch_trk_persistent(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_trk_state* d_states,
                            const cf* ring, uint64_t mask, uint64_t head, int G, int epochs, uint32_t tag_base,
                            unsigned long long* d_xchg, gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost,
-                           uint8_t* d_lost_prn, int* d_error, long long* d_stamps);
+                           uint8_t* d_lost_prn, int* d_error, int* d_error_dev, long long* d_stamps);
 
 // ---------------------------------------------------------------- digital front-end (fe_kernels.hip)
 struct FeState { float phase_accumulator; float bias_re[8]; float bias_im[8]; };   // NcoLut.phase_accumulator, DcRemoverSimd.bias_*

@@ -442,7 +442,8 @@ struct TrkPersistArgs {
     uint32_t tag_base;               // unique per launch: tag = tag_base + epoch + 1
     unsigned long long* xchg;        // [2][n_channels][G][NV] granules
     gm_trk_out* outs; uint8_t *processed, *lost, *lost_prn;   // [epochs][n_channels] (may be null)
-    int* error_flag;                 // set to 1 if an exchange wait timed out
+    int* error_flag;                 // set to 1 if an exchange wait timed out (pinned host memory)
+    int* error_flag_dev;             // the same in device memory: checked at the start of every launch
     long long* stamps;               // diagnostic only (may be null): [epochs][48] s_memtime stamps of workgroup 0 (8 phases, 16 waves x compute end, 16 x barrier arrival)
 };
 
@@ -512,8 +513,20 @@ template <int ARMS, int MODE_T, int BOC_T, int T>
 __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persistent_kernel(TrkPersistArgs a) {
     constexpr int NV = 2 * ARMS, NW = T / 64, KPF = 4;
     const TrkDevCfg& cfg = a.cfg;
-    const int ch = blockIdx.x / a.G, g = blockIdx.x % a.G, tid = threadIdx.x;
+    // workgroup -> (channel, slice).  Blocks b and b + 8 share an XCD (round-robin dispatch; speed only, never correctness):
+    // when the channels divide over the eight XCDs, all G workgroups of a channel are placed on ONE XCD, so the partial sums
+    // they exchange every epoch travel through that XCD's L2 / one fabric stop instead of across the chip.
     const int C = cfg.n_channels;
+    int ch, g;
+    if ((C & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;       // j-th workgroup of this XCD: C/8 channels x G slices
+        ch = xcd * (C >> 3) + j / a.G;
+        g = j % a.G;
+    } else {
+        ch = blockIdx.x / a.G;
+        g = blockIdx.x % a.G;
+    }
+    const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     __shared__ float wsum[NW][NV];
     __shared__ EpochShared sh;          // wave 0 -> everyone, once per epoch
@@ -522,8 +535,13 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     extern __shared__ int8_t chips[];   // the channel's chip row
 
     // an earlier launch of the same call (more than 4095 passes are several launches) has timed out: do nothing, the host
-    // reports the error after it synchronises (the flag lives in pinned host memory: one read per launch)
-    if (__hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+    // reports the error after it synchronises
+    // (a device-memory twin of the flag, one lane per workgroup: reading the pinned host word itself cost 0.4 us per epoch
+    // even from one lane per workgroup, 0.7 ms per launch from every lane)
+    __shared__ int s_abort;
+    if (threadIdx.x == 0) s_abort = __hip_atomic_load(a.error_flag_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_abort != 0) return;
     gm_trk_state s0 = a.states[ch];
     const int row = code_row(cfg, s0);
     const bool leader = (g == 0 && tid == 0);
@@ -659,7 +677,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (pending[q] && uint32_t(gr[q] >> 32) == tag) pending[q] = false;
-                    __builtin_amdgcn_s_sleep(2);   // a straggler is being waited for: leave the issue slots to whoever shares the SIMD
+                    // (no s_sleep here: measured +0.5 us per epoch at 32 channels — the poll IS the critical path)
                     if ((++rounds & 63u) == 0u && wall_clock64() - t0 > 20000000ll) to = true;   // 0.2 s at 100 MHz
                 }
 #pragma unroll
@@ -753,7 +771,10 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             // `sh` only after the next epoch's first barrier, which no wave reaches before reading it above
             if (st_on) stp[7] = stamp_now();
         }
-        if (tid == 0 && timed_out) *a.error_flag = 1;
+        if (tid == 0 && timed_out) {
+            *a.error_flag = 1;                                                                       // host's copy (pinned)
+            __hip_atomic_store(a.error_flag_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // later launches' copy
+        }
     }
     if (leader) {
         if (ran) a.states[ch] = st;         // (the leader is lane 0 of wave 0) an idle channel's state is left as it was
@@ -772,8 +793,9 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
 void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_codes, gm_trk_state* d_states,
                            const cf* ring, uint64_t mask, uint64_t head, int G, int epochs, uint32_t tag_base,
                            unsigned long long* d_xchg, gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost,
-                           uint8_t* d_lost_prn, int* d_error, long long* d_stamps) {
+                           uint8_t* d_lost_prn, int* d_error, int* d_error_dev, long long* d_stamps) {
     TrkPersistArgs a;
+    a.error_flag_dev = d_error_dev;
     a.stamps = d_stamps;
     a.cfg = cfg; a.codes = d_codes; a.states = d_states; a.ring = ring; a.mask = mask; a.head = head;
     a.G = G; a.epochs = epochs; a.tag_base = tag_base;
