@@ -118,12 +118,12 @@ struct TrkDevCfg {
     // per-launch constants of the scalar epilogue, computed once on the host with IEEE f32 / f64 division
     // (fill_trk_derived): quotients of configuration constants and correctly rounded reciprocals for the
     // constant-divisor divisions
-    float inv_fs, inv_len;
+    float inv_fs, inv_len, inv_2pi;
     float pll_dt_tau1, pll_tau2_tau1, dll_dt_tau1, dll_tau2_tau1;   // dt/tau1, tau2/tau1 (LoopFilter::update :68-70)
     int div_fs_ok;            // fs significand not all ones: div_const(x, fs) is the correctly rounded quotient
 };
 inline void fill_trk_derived(TrkDevCfg& d) {
-    d.inv_fs = 1.0f / d.fs; d.inv_len = 1.0f / d.code_len_f;
+    d.inv_fs = 1.0f / d.fs; d.inv_len = 1.0f / d.code_len_f; d.inv_2pi = 1.0f / (2.0f * 3.14159265358979323846f);
     d.pll_dt_tau1 = d.pll_dt / d.pll_tau1; d.pll_tau2_tau1 = d.pll_tau2 / d.pll_tau1;
     d.dll_dt_tau1 = d.dll_dt / d.dll_tau1; d.dll_tau2_tau1 = d.dll_tau2 / d.dll_tau1;
     uint32_t bits; __builtin_memcpy(&bits, &d.fs, 4);

@@ -325,7 +325,10 @@ __device__ __forceinline__ CarrierHalf carrier_half(const TrkDevCfg& cfg, const 
     if (locked) {
         o.lost_counter = 0;
         // run_loop_filters (:279-302), carrier part
-        const float pll_err = __fdiv_rn(atanf_glibc(__fdiv_rn(v[1], v[0])), 2.0f * GM_PI_F);   // f32::atan = the host libm's atanf (gm_libm.h)
+        // f32::atan = the host libm's atanf (gm_libm.h); / (2*PI): constant divisor, correctly rounded through its reciprocal
+        // (Markstein form, equal to IEEE division on 8e6 arguments spanning atan's range — the division was ~12 dependent
+        // instructions of the serial section)
+        const float pll_err = div_const(atanf_glibc(__fdiv_rn(v[1], v[0])), 2.0f * GM_PI_F, cfg.inv_2pi);
         o.carrier_nco = loop_filter_update(cfg.pll_dt_tau1, cfg.pll_tau2_tau1, pll_err, s.carrier_error);
         o.carrier_error = pll_err;
         o.carrier_freq = s.carrier_freq + o.carrier_nco;
@@ -644,8 +647,12 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 const uint32_t tag = a.tag_base + uint32_t(e) + 1u;
                 unsigned long long* slot = a.xchg + (size_t(e & 1) * C + ch) * a.G * NV;
                 if (lane < NV) {
-                    float p = wsum[0][lane];
-                    for (int w = 1; w < NW; ++w) p += wsum[w][lane];
+                    float pw[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) pw[w] = wsum[w][lane];      // all reads in flight, then the fixed-order sum
+                    float p = pw[0];
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) p += pw[w];
                     const unsigned long long gran =
                         (unsigned long long)__float_as_uint(p) | ((unsigned long long)tag << 32);
                     __hip_atomic_store(&slot[lane * a.G + g], gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // arm-major: [k][g]
