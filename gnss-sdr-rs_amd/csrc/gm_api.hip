@@ -1282,6 +1282,10 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
         int g = 1;
         const int per_cu = gm::trk_persistent_blocks_per_cu(d);      // occupancy of this instantiation, capped at the design's 2
         while (g * 2 <= 32 && size_t(g) * 2 * t->C <= size_t(cus) * per_cu && g * 2 * nv <= 256) g *= 2;
+        if (const char* e = getenv("GM_TRK_G")) {   // diagnostic override (power of two; must keep n_channels * G resident)
+            const int f = atoi(e);
+            if (f >= 1 && f <= 32 && (f & (f - 1)) == 0 && size_t(f) * t->C <= size_t(cus) * per_cu && f * nv <= 256) g = f;
+        }
         t->G = g;
         const size_t xb = size_t(2) * t->C * g * nv * sizeof(unsigned long long);
         HIPT(hipMalloc(&t->d_xchg, xb));

@@ -24,6 +24,7 @@
 // and lanes/waves/slices combine as a fixed tree (deterministic; closer to the exact sum).
 #include "gm_internal.h"
 #include "gm_libm.h"
+#include <cstdlib>
 
 namespace gm {
 

@@ -2,8 +2,8 @@ import sys, ctypes as C, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnss_sdr_rs_amd import _lib, acquisition as A, synth, tracking as T
 _lib.init(0)
-ca=A.ca_code_table(); fs=25e6; Cn=32; E=40; n=25000
-sc=synth.tracking_scene(ca, fs, 0.0, list(range(1,33)), E+2, config_id=3, cn0=47.0)
+ca=A.ca_code_table(); fs=25e6; Cn=int(os.environ.get('TRK_C','32')); E=40; n=25000
+sc=synth.tracking_scene(ca, fs, 0.0, list(range(1,Cn+1)), E+2, config_id=3, cn0=47.0)
 ring=T.MulticastRingBuffer(1<<21); ring.write_samples(synth.to_c32(sc['x']))
 mgr=T.TrackingManager(fs, n_channels=Cn, code_index_mode=1)
 for i,s in enumerate(sc['sats']):
