@@ -1281,13 +1281,14 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
         const int nv = 2 * d.n_arms;
         int g = 1;
         const int per_cu = gm::trk_persistent_blocks_per_cu(d);      // occupancy of this instantiation, capped at the design's 2
-        while (g * 2 <= 32 && size_t(g) * 2 * t->C <= size_t(cus) * per_cu && g * 2 * nv <= 256) g *= 2;
+        const size_t slots = size_t(gm::trk_persistent_slots(t->C));   // the grid is slots * G workgroups (empty ones leave at once)
+        while (g * 2 <= 32 && size_t(g) * 2 * slots <= size_t(cus) * per_cu && g * 2 * nv <= 256) g *= 2;
         if (const char* e = getenv("GM_TRK_G")) {   // diagnostic override (power of two; must keep n_channels * G resident)
             const int f = atoi(e);
-            if (f >= 1 && f <= 32 && (f & (f - 1)) == 0 && size_t(f) * t->C <= size_t(cus) * per_cu && f * nv <= 256) g = f;
+            if (f >= 1 && f <= 32 && (f & (f - 1)) == 0 && size_t(f) * slots <= size_t(cus) * per_cu && f * nv <= 256) g = f;
         }
         t->G = g;
-        const size_t xb = size_t(2) * t->C * g * nv * sizeof(unsigned long long);
+        const size_t xb = (size_t(2) * t->C * g * nv + size_t(t->C) * g) * sizeof(unsigned long long);   // partials + XCC_ID granules
         HIPT(hipMalloc(&t->d_xchg, xb));
         HIPT(hipMemset(t->d_xchg, 0, xb));
         HIPT(hipHostMalloc(reinterpret_cast<void**>(&t->d_error), sizeof(int), hipHostMallocDefault));   // read on the host after a stream sync: no copy

@@ -145,6 +145,7 @@ void launch_trk_epoch(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_t
 constexpr int TRK_PERSIST_THREADS = 512;
 constexpr int TRK_PERSIST_WG_PER_CU = 2;
 
+inline int trk_persistent_slots(int n_channels) { return (n_channels + 7) / 8 * 8; }   // grid = slots * G workgroups
 int trk_persistent_blocks_per_cu(const TrkDevCfg&);   // resident workgroups per CU of the instantiation this config selects
 // persistent multi-epoch tracking (one launch = `epochs` passes over all channels); G workgroups per channel
 void launch_trk_persistent(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_trk_state* d_states,

@@ -444,7 +444,7 @@ struct TrkPersistArgs {
     int G, epochs;
     uint32_t per;                    // samples per workgroup slice (multiple of 64), fixed for the launch
     uint32_t tag_base;               // unique per launch: tag = tag_base + epoch + 1
-    unsigned long long* xchg;        // [2][n_channels][G][NV] granules
+    unsigned long long* xchg;        // [2][n_channels][G][NV] granules of partials, then [n_channels][G] of XCC_IDs
     gm_trk_out* outs; uint8_t *processed, *lost, *lost_prn;   // [epochs][n_channels] (may be null)
     int* error_flag;                 // set to 1 if an exchange wait timed out (pinned host memory)
     int* error_flag_dev;             // the same in device memory: checked at the start of every launch
@@ -517,19 +517,15 @@ template <int ARMS, int MODE_T, int BOC_T, int T>
 __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persistent_kernel(TrkPersistArgs a) {
     constexpr int NV = 2 * ARMS, NW = T / 64, KPF = 4;
     const TrkDevCfg& cfg = a.cfg;
-    // workgroup -> (channel, slice).  Blocks b and b + 8 share an XCD (round-robin dispatch; speed only, never correctness):
-    // when the channels divide over the eight XCDs, all G workgroups of a channel are placed on ONE XCD, so the partial sums
-    // they exchange every epoch travel through that XCD's L2 / one fabric stop instead of across the chip.
+    // workgroup -> (channel, slice).  Blocks b and b + 8 share an XCD (round-robin dispatch), so the grid is laid out as
+    // ceil(C/8)*8 channel slots x G slices with slot = 8*(j/G) + xcd: all G workgroups of a channel sit on ONE XCD and the
+    // partial sums they exchange every epoch can travel through that XCD's L2.  Slots beyond C are empty workgroups (they
+    // leave at once).  The placement is only the expectation: what the exchange does is decided from the XCC_ID each
+    // workgroup reads from the hardware (see the exchange below), never from this arithmetic.
     const int C = cfg.n_channels;
-    int ch, g;
-    if ((C & 7) == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;       // j-th workgroup of this XCD: C/8 channels x G slices
-        ch = xcd * (C >> 3) + j / a.G;
-        g = j % a.G;
-    } else {
-        ch = blockIdx.x / a.G;
-        g = blockIdx.x % a.G;
-    }
+    const int ch = (int(blockIdx.x >> 3) / a.G) * 8 + int(blockIdx.x & 7);
+    const int g = int(blockIdx.x >> 3) % a.G;
+    if (ch >= C) return;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     __shared__ float wsum[NW][NV];
@@ -553,7 +549,19 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     bool timed_out = false;
     const bool ran = s0.active && row >= 0 && row < cfg.n_codes;
     gm_trk_state st = s0;               // the channel state: updated by wave 0 only, epoch after epoch, in registers
+    // Same-XCD hand-shake, once per launch: every workgroup publishes the XCC_ID it runs on (write-through, like the first
+    // epoch's partials); after the first epoch's exchange each one has read all G of them and, when they agree, later epochs
+    // publish with PLAIN stores, which stay in the XCD's L2 where the partners' L1-bypassing polls find them (a write-through
+    // store drops the line, so the poll goes out to the fabric: 2050 -> 550 cycles of waiting per epoch at 32 channels).
+    unsigned long long* const xcc_slot = a.xchg + size_t(2) * C * a.G * NV + size_t(ch) * a.G;
+    uint32_t my_xcc = 0;
+    bool same_xcd = false;
     if (ran) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+        my_xcc &= 0xfu;
+        if (tid == 0)
+            __hip_atomic_store(&xcc_slot[g], (unsigned long long)my_xcc | ((unsigned long long)(a.tag_base + 1u) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int8_t* crow = a.codes + size_t(row) * cfg.code_len;
         for (int i = tid; i < cfg.code_len; i += T) chips[i] = crow[i];
         if (tid == 0) { ctl = 0; prepare_epoch(cfg, a.head, s0, sh, false, true); }
@@ -587,37 +595,52 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
 #pragma unroll
             for (int k = 0; k < NV; ++k) { acc[k] = 0.0f; acc2[k] = 0.0f; }
             if (sh.fast) {
-                // whole passes run unpredicated and two at a time, so the scheduler interleaves two independent
-                // samples (division, f64 reduction, LDS look-ups are long dependent chains)
+                // A lane's samples are b0 + j*T, j < tot (tot = full, or full + 1 on the lanes of the ragged last pass).  They
+                // are processed FOUR at a time as one straight-line block with four accumulator sets, so the scheduler
+                // interleaves four independent dependent chains (division, f64 reduction, LDS look-ups): the phase is bound by
+                // the latency of one wave's instruction stream, not by issue slots (one workgroup alone on a CU takes as long
+                // as two).  A slot without a sample takes a zero sample, which adds exactly nothing to the sums; blocks are
+                // sized per wave (a wave whose lanes all have three samples runs a block of three).
                 const uint32_t b0 = i0 + tid;
-                if (full >= 2) {
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf0, b0, acc);
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf1, b0 + T, acc2);
-                } else if (full == 1) {
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf0, b0, acc);
+                const uint32_t tot = full + ((b0 + full * T) < i1 ? 1u : 0u);
+                const uint32_t wtot = full + (__any((b0 + full * T) < i1) ? 1u : 0u);       // wave-uniform
+                float acc3[NV], acc4[NV];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) { acc3[k] = 0.0f; acc4[k] = 0.0f; }
+                const cf zero = cf_make(0.0f, 0.0f);
+                for (uint32_t j = 0; j < wtot; j += 4) {                 // the first block comes from the prefetched registers
+                    const uint32_t left = wtot - j;
+                    cf d0 = zero, d1 = zero, d2 = zero, d3 = zero;
+                    if (j == 0) {
+                        if (tot > 0) d0 = pf0;
+                        if (tot > 1) d1 = pf1;
+                        if (tot > 2) d2 = pf2;
+                        if (tot > 3) d3 = pf3;
+                    } else {
+                        if (j < tot) d0 = a.ring[(win + b0 + j * T) & a.mask];
+                        if (j + 1 < tot) d1 = a.ring[(win + b0 + (j + 1) * T) & a.mask];
+                        if (j + 2 < tot) d2 = a.ring[(win + b0 + (j + 2) * T) & a.mask];
+                        if (j + 3 < tot) d3 = a.ring[(win + b0 + (j + 3) * T) & a.mask];
+                    }
+                    // one basic block per block size, so that the chains really are interleaved
+                    if (left >= 4) {
+                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d0, b0 + j * T, acc);
+                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d1, b0 + (j + 1) * T, acc2);
+                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d2, b0 + (j + 2) * T, acc3);
+                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d3, b0 + (j + 3) * T, acc4);
+                    } else if (left == 3) {
+                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d0, b0 + j * T, acc);
+                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d1, b0 + (j + 1) * T, acc2);
+                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d2, b0 + (j + 2) * T, acc3);
+                    } else if (left == 2) {
+                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d0, b0 + j * T, acc);
+                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d1, b0 + (j + 1) * T, acc2);
+                    } else {
+                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d0, b0 + j * T, acc);
+                    }
                 }
-                if (full >= 4) {
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf2, b0 + 2 * T, acc);
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf3, b0 + 3 * T, acc2);
-                } else if (full == 3) {
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, pf2, b0 + 2 * T, acc);
-                }
-                uint32_t j = KPF;
-                for (; j + 1 < full; j += 2) {
-                    const cf d0 = a.ring[(win + b0 + j * T) & a.mask], d1 = a.ring[(win + b0 + (j + 1) * T) & a.mask];
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d0, b0 + j * T, acc);
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d1, b0 + (j + 1) * T, acc2);
-                }
-                if (j < full) correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, a.ring[(win + b0 + j * T) & a.mask], b0 + j * T, acc);
-                // ragged last pass
-                const uint32_t it = b0 + full * T;
-                if (it < i1) {
-                    // component-wise selects: a ternary over the structs is a select of ADDRESSES and pins all four in scratch
-                    cf d = cf_make(full == 0 ? pf0.x : (full == 1 ? pf1.x : (full == 2 ? pf2.x : pf3.x)),
-                                   full == 0 ? pf0.y : (full == 1 ? pf1.y : (full == 2 ? pf2.y : pf3.y)));
-                    if (full >= uint32_t(KPF)) d = a.ring[(win + it) & a.mask];
-                    correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d, it, acc2);
-                }
+#pragma unroll
+                for (int k = 0; k < NV; ++k) { acc[k] = acc[k] + acc3[k]; acc2[k] = acc2[k] + acc4[k]; }
             } else {   // out-of-family state (e.g. set by the caller): general fmodf, no prefetch use
                 for (uint32_t i = i0 + tid; i < i1; i += T)
                     correlate_sample<ARMS, false, MODE_T, BOC_T>(ec, chips, a.ring[(win + i) & a.mask], i, acc);
@@ -656,7 +679,10 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     for (int w = 1; w < NW; ++w) p += pw[w];
                     const unsigned long long gran =
                         (unsigned long long)__float_as_uint(p) | ((unsigned long long)tag << 32);
-                    __hip_atomic_store(&slot[lane * a.G + g], gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // arm-major: [k][g]
+                    if (same_xcd)      // plain: the line stays in this XCD's L2 (see the hand-shake above)
+                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(&slot[lane * a.G + g]), "v"(gran) : "memory");
+                    else
+                        __hip_atomic_store(&slot[lane * a.G + g], gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // arm-major: [k][g]
                 }
                 if (st_on) stp[3] = stamp_now();
                 // gather the G partials: lane l polls granules l, l+64, ... (G*NV <= 256)
@@ -691,6 +717,17 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (lane + q * 64 < ng) val[q] = __uint_as_float(uint32_t(gr[q]));
+                if (e == 0) {   // the hand-shake: the partners' XCC_IDs (published before their first partials were)
+                    const unsigned long long want = (unsigned long long)(a.tag_base + 1u);
+                    unsigned long long xg = want << 32 | my_xcc;
+                    bool pend = lane < a.G;
+                    while (pend && !to) {
+                        xg = __hip_atomic_load(&xcc_slot[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pend = (xg >> 32) != want;
+                        if ((++rounds & 63u) == 0u && wall_clock64() - t0 > 20000000ll) to = true;
+                    }
+                    same_xcd = __all(!pend && uint32_t(xg) == my_xcc) != 0;
+                }
                 to = __any(to);
                 if (st_on) stp[4] = stamp_now();
                 // totals of the G partials of every arm, identical in all lanes and in all workgroups of the channel.
@@ -815,7 +852,7 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     a.processed = d_processed; a.lost = d_lost; a.lost_prn = d_lost_prn; a.error_flag = d_error;
     // dynamic LDS: chip row (padded to 16 B) + the gathered G*NV partials
     const size_t lds = size_t((cfg.code_len + 15) & ~15);
-    const dim3 grid(cfg.n_channels * G);
+    const dim3 grid(trk_persistent_slots(cfg.n_channels) * G);     // channel slots: n_channels rounded up to the eight XCDs
     // compile-time arms / code-index mode / BOC: straight-line sample code
     const int key = (cfg.n_arms == 5 ? 4 : 0) | (cfg.code_index_mode == GM_CODE_INDEX_FIXED ? 2 : 0) | (cfg.boc11 ? 1 : 0);
     constexpr int T = TRK_PERSIST_THREADS;
