@@ -66,6 +66,21 @@ template <bool FAST> __device__ __forceinline__ float fmod_code(float t, float l
     } else return fmodf(t, len);
 }
 
+// fmodf(x, y) for a positive constant y with inv = RN(1/y); exact, as fmodf is (the remainder is representable, so every
+// correct algorithm returns the same bits).  For y <= |x| < 4096 y: q = rint(|x| * inv) is the integer quotient or one
+// more, r = fma(-q, y, |x|) is exact (a multiple of ulp(y) of magnitude below y), one conditional + y brings it into [0, y),
+// and the sign is x's.  Outside that range (and for inf / NaN): the library's fmodf.  (The library form is ~35 instructions
+// with frexp/ldexp and three branches; this is 9.)
+__device__ __forceinline__ float fmod_bounded(float x, float y, float inv) {
+    const float ax = fabsf(x);
+    if (!(ax < 4096.0f * y)) return fmodf(x, y);
+    const float q = rintf(ax * inv);
+    float r = __builtin_fmaf(-q, y, ax);
+    r = r < 0.0f ? r + y : r;
+    r = ax < y ? ax : r;
+    return copysignf(r, x);
+}
+
 // get_ca_chip's index (:275): `(phase.floor() as usize) % 1023` — the cast saturates, so a negative
 // phase (late arm just after the code wraps) reads chip 0 in FAITHFUL mode; FIXED mode wraps.
 // phase = chip_idx +- spacing with |chip_idx| < len and spacing < len (checked at gm_trk_create), so
@@ -141,13 +156,16 @@ __device__ __forceinline__ EpochConsts epoch_consts(const TrkDevCfg& cfg, const 
 //    unless fs's significand is all ones or the quotient leaves the normal range — excluded here.  Checked against IEEE
 //    division on 1.3e9 operands for 21 sample rates (tools/ubench note in DESIGN.md); only the sign of a zero quotient can
 //    differ, which cannot change a sample's products.
-__device__ __forceinline__ bool fast_code_range(const EpochConsts& c, uint64_t n) {
+__device__ __forceinline__ bool fast_code_ok(const EpochConsts& c, uint64_t n) {     // the code replica's share
     const bool code_ok = c.code_phase >= 0.0f && c.code_phase < c.lenf && c.step >= 0.0f && float(n) * c.step < 1.99f * c.lenf;
     const bool arms_ok = c.el > 0.0f && c.el <= 1.0f && c.vel > 0.0f && c.vel <= 1.0f;
-    const bool div_ok = (__float_as_uint(c.fs) & 0x7fffffu) != 0x7fffffu && c.fs > 1.0f && c.fs < 1.0e12f &&
-                        (c.two_pi_f == 0.0f || (fabsf(c.two_pi_f) > 1.0e-12f && fabsf(c.two_pi_f) < 1.0e12f));
-    return code_ok && arms_ok && div_ok;
+    return code_ok && arms_ok;
 }
+__device__ __forceinline__ bool fast_car_ok(const EpochConsts& c) {                   // the carrier's share
+    return (__float_as_uint(c.fs) & 0x7fffffu) != 0x7fffffu && c.fs > 1.0f && c.fs < 1.0e12f &&
+           (c.two_pi_f == 0.0f || (fabsf(c.two_pi_f) > 1.0e-12f && fabsf(c.two_pi_f) < 1.0e12f));
+}
+__device__ __forceinline__ bool fast_code_range(const EpochConsts& c, uint64_t n) { return fast_code_ok(c, n) && fast_car_ok(c); }
 
 // x / fs, correctly rounded (see fast_code_range)
 __device__ __forceinline__ float div_by_fs(float x, float fs, float inv_fs) {
@@ -293,6 +311,16 @@ __global__ __launch_bounds__(256) void trk_correlate_kernel(TrkDevCfg cfg, const
 //   carrier half: prn, active, lost_counter, next_sample_index, carrier_{freq,phase,error,nco}, i/q_prompt, messages
 //   code half   : code_{phase,error,nco,rate}, num_samples_per_code
 // Both evaluate the lock test and the give-up rule (:183-210) from the same inputs, so they agree.
+// carrier_phase = (carrier_phase + 2*PI*carrier_freq*(n as f32 / fs)) % (2*PI)          (:240-242); two_pi_f = (2*PI)*carrier_freq
+__device__ __forceinline__ float advance_carrier_phase(const TrkDevCfg& cfg, float phase, float two_pi_f, float nf) {
+    return fmod_bounded(phase + two_pi_f * (cfg.div_fs_ok ? div_const(nf, cfg.fs, cfg.inv_fs) : __fdiv_rn(nf, cfg.fs)),
+                        2.0f * GM_PI_F, cfg.inv_2pi);
+}
+// code_phase = (code_phase + (code_rate/fs) * n as f32) % len                               (:265-267); step = code_rate/fs
+__device__ __forceinline__ float advance_code_phase(const TrkDevCfg& cfg, float phase, float step, float nf) {
+    return fmod_bounded(phase + step * nf, cfg.code_len_f, cfg.inv_len);
+}
+
 struct CarrierHalf {
     uint8_t prn, active, lst, lprn;
     uint32_t lost_counter;
@@ -308,18 +336,17 @@ __device__ __forceinline__ bool trk_give_up(const TrkDevCfg& cfg, const gm_trk_s
     return !locked && s.lost_counter + 1u >= cfg.max_lost_epochs;
 }
 
+// pre_phase: the advanced carrier phase if the caller has it already (it depends on the old state and n only), else null
 template <int ARMS>
 __device__ __forceinline__ CarrierHalf carrier_half(const TrkDevCfg& cfg, const gm_trk_state& s, const float (&v)[2 * ARMS],
-                                                    uint64_t n, int mode) {
+                                                    uint64_t n, int mode, const float* pre_phase = nullptr) {
     CarrierHalf o;
     o.prn = s.prn; o.active = s.active; o.lst = 0; o.lprn = 0; o.lost_counter = s.lost_counter;
     o.next_sample_index = s.next_sample_index;
     o.carrier_freq = s.carrier_freq; o.carrier_error = s.carrier_error; o.carrier_nco = s.carrier_nco;
     const float nf = float(n);
     // carrier_phase = (carrier_phase + 2*PI*carrier_freq*(n as f32 / fs)) % (2*PI)      (:240-242)
-    o.carrier_phase = fmodf(s.carrier_phase + 2.0f * GM_PI_F * s.carrier_freq *
-                                (cfg.div_fs_ok ? div_const(nf, cfg.fs, cfg.inv_fs) : __fdiv_rn(nf, cfg.fs)),
-                            2.0f * GM_PI_F);
+    o.carrier_phase = pre_phase ? *pre_phase : advance_carrier_phase(cfg, s.carrier_phase, 2.0f * GM_PI_F * s.carrier_freq, nf);
     o.i_prompt = v[0]; o.q_prompt = v[1];
     if (mode != TRK_MODE_DO_WORK) return o;
     const bool locked = trk_locked(cfg, v[0], v[1]);     // do_work (:183-210)
@@ -349,13 +376,14 @@ __device__ __forceinline__ CarrierHalf carrier_half(const TrkDevCfg& cfg, const 
 
 template <int ARMS>
 __device__ __forceinline__ CodeHalf code_half(const TrkDevCfg& cfg, const gm_trk_state& s, const float (&v)[2 * ARMS], uint64_t n,
-                                              uint64_t n_stored, int mode) {
+                                              uint64_t n_stored, int mode, const float* pre_phase = nullptr) {
     CodeHalf o;
     o.num_samples_per_code = n_stored; o.code_error = s.code_error; o.code_nco = s.code_nco; o.code_rate = s.code_rate;
     const float nf = float(n);
     // code_phase = (code_phase + (code_rate/fs) * n as f32) % 1023.0                     (:265-267)
-    o.code_phase = fmodf(s.code_phase + (cfg.div_fs_ok ? div_const(s.code_rate, cfg.fs, cfg.inv_fs) : __fdiv_rn(s.code_rate, cfg.fs)) * nf,
-                         cfg.code_len_f);
+    o.code_phase = pre_phase ? *pre_phase
+                             : advance_code_phase(cfg, s.code_phase,
+                                                  cfg.div_fs_ok ? div_const(s.code_rate, cfg.fs, cfg.inv_fs) : __fdiv_rn(s.code_rate, cfg.fs), nf);
     if (mode != TRK_MODE_DO_WORK) return o;
     const bool locked = trk_locked(cfg, v[0], v[1]);
     if (locked) {                                        // run_loop_filters (:279-302), code part
@@ -370,6 +398,20 @@ __device__ __forceinline__ CodeHalf code_half(const TrkDevCfg& cfg, const gm_trk
         return o;
     }
     o.num_samples_per_code = samples_per_code(cfg, o.code_rate);
+    return o;
+}
+
+// The bookkeeping both halves agree on (do_work :183-210): the wave that runs the code half in the persistent kernel keeps
+// its own copy of these fields; same rules as carrier_half, which owns them in the state that is stored.
+struct CommonHalf { uint8_t prn, active; uint32_t lost_counter; uint64_t next_sample_index; };
+__device__ __forceinline__ CommonHalf common_half(const TrkDevCfg& cfg, const gm_trk_state& s, float ip, float qp, uint64_t n, int mode) {
+    CommonHalf o;
+    o.prn = s.prn; o.active = s.active; o.lost_counter = s.lost_counter; o.next_sample_index = s.next_sample_index + n;
+    if (mode != TRK_MODE_DO_WORK) return o;
+    const bool locked = trk_locked(cfg, ip, qp);
+    if (locked) o.lost_counter = 0;
+    else if (trk_give_up(cfg, s, locked)) { o.prn = 0; o.active = 0; o.lost_counter = 0; o.next_sample_index = 0; }
+    else o.lost_counter = s.lost_counter + 1u;
     return o;
 }
 
@@ -479,6 +521,47 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return ((r0 + r1) + r2) + r3;
 }
 
+// Sums over the 64 lanes of a wavefront of NV values at once (NV = 6 or 10), as a reduce-scatter: at each step a lane keeps
+// half of the values it holds and hands the other half to its partner (DPP), so the work halves as the span doubles —
+// 23 VALU instructions for six values (35 for ten) where six (ten) independent wave sums took ~100 (~170), and this runs on
+// every wave of the workgroup right before the barrier the serial section waits behind.
+// Returns X with: lane l (l & 15 < NV) holds the wave total of value l & 15.  Fixed order, deterministic.
+template <int CTRL> __device__ __forceinline__ float dpp_take(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// lanes with `sel` keep hi and hand over lo, the others keep lo and hand over hi; result = kept + the partner's hand-over
+template <int CTRL> __device__ __forceinline__ float keep_add(bool sel, float lo, float hi) {
+    const float k = sel ? hi : lo, t = sel ? lo : hi;
+    return k + dpp_take<CTRL>(t);
+}
+template <int NV> __device__ __forceinline__ float wave_sums_scatter(const float (&a)[NV], int lane) {
+    static_assert(NV == 6 || NV == 10, "three or five arms");
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    constexpr int XOR1 = 0xB1, XOR2 = 0x4E, ROR4 = 0x124, ROR8 = 0x128;     // quad_perm [1,0,3,2], [2,3,0,1]; row_ror:4, :8
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float x;
+    if constexpr (NV == 6) {
+        const float r01 = keep_add<XOR1>(b0, a[0], a[1]), r23 = keep_add<XOR1>(b0, a[2], a[3]), r45 = keep_add<XOR1>(b0, a[4], a[5]);
+        const float q = keep_add<XOR2>(b1, r01, r23);            // value l & 3 over four lanes
+        const float p = r45 + dpp_take<XOR2>(r45);               // value 4 + (l & 1) over four lanes
+        x = keep_add<ROR4>(b2, q, p);                            // value l & 7 (6, 7 repeat 4, 5) over eight lanes
+        x += dpp_take<ROR8>(x);                                  // ... over the row of sixteen
+    } else {
+        const float r01 = keep_add<XOR1>(b0, a[0], a[1]), r23 = keep_add<XOR1>(b0, a[2], a[3]), r45 = keep_add<XOR1>(b0, a[4], a[5]);
+        const float r67 = keep_add<XOR1>(b0, a[6], a[7]), r89 = keep_add<XOR1>(b0, a[8], a[9]);
+        const float q0 = keep_add<XOR2>(b1, r01, r23), q1 = keep_add<XOR2>(b1, r45, r67);
+        float p = r89 + dpp_take<XOR2>(r89);
+        const float o = keep_add<ROR4>(b2, q0, q1);              // value l & 7 over eight lanes
+        p += dpp_take<ROR4>(p);                                  // value 8 + (l & 1) over eight lanes
+        x = keep_add<ROR8>(b3, o, p);                            // value l & 15 (10.. repeat 8, 9) over the row
+    }
+    // the four rows: gfx950's lane swaps pair rows 0/1 and 2/3, then the two halves
+    u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r.x) + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
 // workgroup barrier that orders LDS traffic only: pending global loads (the sample prefetch) stay in flight
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -492,7 +575,7 @@ __device__ __forceinline__ void lds_barrier() {
 struct EpochShared {
     uint64_t win;      // next_sample_index: first sample of the coming epoch's window
     uint32_t n;        // samples of the coming epoch (0: channel cannot run)
-    int fast;          // fast_code_range(...) for the coming epoch
+    int fast_car, fast_code;   // fast_car_ok / fast_code_ok for the coming epoch (both: the exact fast forms may be used)
     EpochConsts ec;
 };
 
@@ -508,7 +591,8 @@ __device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t hea
     const EpochConsts ec = epoch_consts(cfg, s);
     if (first) sh.ec = ec;
     else { sh.ec.carrier_phase = ec.carrier_phase; sh.ec.two_pi_f = ec.two_pi_f; sh.ec.code_phase = ec.code_phase; sh.ec.step = ec.step; }
-    sh.fast = fast_code_range(ec, n) ? 1 : 0;
+    sh.fast_car = fast_car_ok(ec) ? 1 : 0;
+    sh.fast_code = fast_code_ok(ec, n) ? 1 : 0;
 }
 
 template <int ARMS, int MODE_T, int BOC_T, int T>
@@ -531,6 +615,9 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     __shared__ float wsum[NW][NV];
     __shared__ EpochShared sh;          // wave 0 -> everyone, once per epoch
     __shared__ int ctl;                 // 0 continue, 1 exchange timed out
+    __shared__ float pre_phase[2];      // the carrier / code phase the coming state will hold (waves 2 / 3, every epoch)
+    __shared__ CodeHalf fin_code;       // wave 1's share of the channel state, handed to the leader at the end
+    static_assert(NW >= 4, "waves 0/1 run the two halves of the serial section, waves 2/3 the phase advances");
     __shared__ float gathered[256];     // the G*NV partials of one epoch (wave 0 only)
     extern __shared__ int8_t chips[];   // the channel's chip row
 
@@ -594,7 +681,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             float acc[NV], acc2[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) { acc[k] = 0.0f; acc2[k] = 0.0f; }
-            if (sh.fast) {
+            if (sh.fast_car & sh.fast_code) {
                 // A lane's samples are b0 + j*T, j < tot (tot = full, or full + 1 on the lanes of the ragged last pass).  They
                 // are processed FOUR at a time as one straight-line block with four accumulator sets, so the scheduler
                 // interleaves four independent dependent chains (division, f64 reduction, LDS look-ups): the phase is bound by
@@ -654,23 +741,34 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 pf2 = a.ring[(nb + i0 + tid + 2 * T) & a.mask];
                 pf3 = a.ring[(nb + i0 + tid + 3 * T) & a.mask];
             }
-#pragma unroll
-            for (int k = 0; k < NV; ++k) acc[k] = wave_sum_dpp(acc[k] + acc2[k]);
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < NV; ++k) wsum[wave][k] = acc[k];
+            // the phases the coming state will hold are functions of the OLD state and n alone (:240-242, :265-267): waves 2
+            // and 3 work them out here, off the serial chain that follows the exchange
+            if (wave == 2) {
+                const float ph = advance_carrier_phase(cfg, ec.carrier_phase, ec.two_pi_f, float(n));
+                if (lane == 0) pre_phase[0] = ph;
+            } else if (wave == 3) {
+                const float ph = advance_code_phase(cfg, ec.code_phase, ec.step, float(n));
+                if (lane == 0) pre_phase[1] = ph;
             }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[k] += acc2[k];
+            const float wtotal = wave_sums_scatter<NV>(acc, lane);     // lane k < NV: this wave's total of value k
+            if (lane < NV) wsum[wave][lane] = wtotal;
             if (a.stamps && blockIdx.x == 0 && lane == 0) stp[24 + wave] = stamp_now();       // per-wave barrier arrival
             lds_barrier();    // NOT __syncthreads(): its fence would wait for the prefetch loads (vmcnt(0))
             if (st_on) stp[2] = stamp_now();
-            if (wave == 0) {
-                // the serial section is a chain of dependent instructions of ONE wave; the other workgroup of this CU is
-                // usually correlating on the same SIMD: raise this wave's issue priority so the chain is not queued behind it
+            if (wave < 2) {
+                // The serial section: wave 0 publishes this workgroup's partial; waves 0 AND 1 each gather the G partials and
+                // form the totals (same loads, same order: identical values), then wave 0 runs the carrier half of the scalar
+                // update and wave 1 the code half, side by side (a lone wave issues one instruction per ~5 cycles whatever
+                // the dependencies, so two waves halve the section).  The other workgroup of this CU is usually correlating
+                // on the same SIMDs: raised issue priority keeps the chains from queueing behind it.
                 __builtin_amdgcn_s_setprio(3);
+                const bool st1_on = a.stamps && blockIdx.x == 0 && tid == 64;
                 // this workgroup's partial (waves added in a fixed order), published as {value, tag} granules
                 const uint32_t tag = a.tag_base + uint32_t(e) + 1u;
                 unsigned long long* slot = a.xchg + (size_t(e & 1) * C + ch) * a.G * NV;
-                if (lane < NV) {
+                if (wave == 0 && lane < NV) {
                     float pw[NW];
 #pragma unroll
                     for (int w = 0; w < NW; ++w) pw[w] = wsum[w][lane];      // all reads in flight, then the fixed-order sum
@@ -717,7 +815,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (lane + q * 64 < ng) val[q] = __uint_as_float(uint32_t(gr[q]));
-                if (e == 0) {   // the hand-shake: the partners' XCC_IDs (published before their first partials were)
+                if (e == 0 && wave == 0) {   // the hand-shake: the partners' XCC_IDs (published before their first partials were)
                     const unsigned long long want = (unsigned long long)(a.tag_base + 1u);
                     unsigned long long xg = want << 32 | my_xcc;
                     bool pend = lane < a.G;
@@ -730,6 +828,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 }
                 to = __any(to);
                 if (st_on) stp[4] = stamp_now();
+                if (st1_on) stp[40] = stamp_now();
                 // totals of the G partials of every arm, identical in all lanes and in all workgroups of the channel.
                 // Granules are arm-major ([k][g]).  G == 16: arm k's partials sit in one DPP row of 16 lanes (arms 0-3 in
                 // the first sweep's registers, 4.. in the next), so four row_shr adds leave the arm total in the row's last
@@ -791,22 +890,52 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     for (int k = 0; k < NV; ++k) v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tk), k));
                 }
                 if (st_on) stp[5] = stamp_now();
-                uint8_t lst = 0, lprn = 0;
-                if (!to) {
-                    st.num_samples_per_code = n;                 // update() stores the length it used (:166)
-                    epoch_epilogue<ARMS>(cfg, st, v, n, TRK_MODE_DO_WORK, lst, lprn);
-                }
-                if (st_on) stp[6] = stamp_now();
-                if (lane == 0) {
-                    prepare_epoch(cfg, a.head, st, sh, !to, false);     // n / constants / gate of the NEXT epoch, once
-                    ctl = to ? 1 : 0;
-                    if (g == 0 && !to) {
-                        const size_t o = size_t(e) * C + ch;
-                        if (a.outs) a.outs[o] = make_out<ARMS>(v);
-                        if (a.processed) a.processed[o] = 1;
-                        if (a.lost) a.lost[o] = lst;
-                        if (a.lost_prn) a.lost_prn[o] = lprn;
+                if (wave == 0) {          // ---- carrier half + the bookkeeping (do_work :183-210, run_loop_filters' PLL :279-290)
+                    uint8_t lst = 0, lprn = 0;
+                    if (!to) {
+                        const CarrierHalf h = carrier_half<ARMS>(cfg, st, v, n, TRK_MODE_DO_WORK, &pre_phase[0]);
+                        st.prn = h.prn; st.active = h.active; st.lost_counter = h.lost_counter; st.next_sample_index = h.next_sample_index;
+                        st.carrier_freq = h.carrier_freq; st.carrier_phase = h.carrier_phase; st.carrier_error = h.carrier_error;
+                        st.carrier_nco = h.carrier_nco; st.i_prompt = h.i_prompt; st.q_prompt = h.q_prompt;
+                        lst = h.lst; lprn = h.lprn;
                     }
+                    if (st_on) stp[6] = stamp_now();
+                    if (lane == 0) {      // the carrier's share of the NEXT epoch's constants
+                        const EpochConsts nx = epoch_consts(cfg, st);
+                        sh.ec.carrier_phase = nx.carrier_phase; sh.ec.two_pi_f = nx.two_pi_f;
+                        sh.fast_car = fast_car_ok(nx) ? 1 : 0;
+                        if (to) ctl = 1;
+                        if (g == 0 && !to) {
+                            const size_t o = size_t(e) * C + ch;
+                            if (a.outs) a.outs[o] = make_out<ARMS>(v);
+                            if (a.processed) a.processed[o] = 1;
+                            if (a.lost) a.lost[o] = lst;
+                            if (a.lost_prn) a.lost_prn[o] = lprn;
+                        }
+                    }
+                } else {                  // ---- code half (DLL :291-302, :265-270) + the gate and length of the next epoch
+                    if (!to) {
+                        st.num_samples_per_code = n;                 // update() stores the length it used (:166)
+                        const CommonHalf c = common_half(cfg, st, v[0], v[1], n, TRK_MODE_DO_WORK);
+                        const CodeHalf h = code_half<ARMS>(cfg, st, v, n, n, TRK_MODE_DO_WORK, &pre_phase[1]);
+                        st.prn = c.prn; st.active = c.active; st.lost_counter = c.lost_counter; st.next_sample_index = c.next_sample_index;
+                        st.num_samples_per_code = h.num_samples_per_code; st.code_phase = h.code_phase; st.code_error = h.code_error;
+                        st.code_nco = h.code_nco; st.code_rate = h.code_rate;
+                    }
+                    if (st1_on) stp[41] = stamp_now();
+                    if (lane == 0) {
+                        // the epilogue has just stored round(fs/(code_rate/len)) for the new code_rate (update() :165-166)
+                        const uint64_t nn = st.num_samples_per_code;
+                        bool run = st.active && nn > 0 && nn < (1ull << 31);
+                        if (run) run = (int64_t)(a.head - (st.next_sample_index + nn)) >= 0;              // :170-172
+                        const EpochConsts nx = epoch_consts(cfg, st);
+                        sh.win = st.next_sample_index;
+                        sh.n = run ? uint32_t(nn) : 0u;
+                        sh.ec.code_phase = nx.code_phase; sh.ec.step = nx.step;
+                        sh.fast_code = fast_code_ok(nx, nn) ? 1 : 0;
+                        if (to) ctl = 1;
+                    }
+                    if (st1_on) stp[42] = stamp_now();
                 }
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -819,6 +948,17 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
         if (tid == 0 && timed_out) {
             *a.error_flag = 1;                                                                       // host's copy (pinned)
             __hip_atomic_store(a.error_flag_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // later launches' copy
+        }
+    }
+    if (ran) {      // the code half of the state lives in wave 1's registers
+        if (tid == 64) {
+            fin_code.num_samples_per_code = st.num_samples_per_code; fin_code.code_phase = st.code_phase;
+            fin_code.code_error = st.code_error; fin_code.code_nco = st.code_nco; fin_code.code_rate = st.code_rate;
+        }
+        __syncthreads();
+        if (leader) {
+            st.num_samples_per_code = fin_code.num_samples_per_code; st.code_phase = fin_code.code_phase;
+            st.code_error = fin_code.code_error; st.code_nco = fin_code.code_nco; st.code_rate = fin_code.code_rate;
         }
     }
     if (leader) {

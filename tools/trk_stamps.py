@@ -22,3 +22,7 @@ print('epoch total (stamp0->stamp0 next):', np.median(np.diff(buf[5:,0])))
 ce=buf[5:,8:24]-buf[5:,0:1]; ba=buf[5:,24:40]-buf[5:,0:1]
 print('per-wave compute end (cycles after wave0 epoch start), median:', np.median(ce,axis=0).astype(int))
 print('per-wave barrier arrival, median:', np.median(ba,axis=0).astype(int))
+w1 = buf[5:, 40:43] - buf[5:, 2:3]      # wave 1 of the serial section, relative to the reduce barrier's release (stamp 2)
+print('wave 1 (code half) after the barrier: gathered %d, half done %d, next-epoch constants %d   | wave 0: gathered %d, half done %d, constants+outs %d' % (
+    np.median(w1[:, 0]), np.median(w1[:, 1]), np.median(w1[:, 2]),
+    np.median(buf[5:, 4] - buf[5:, 2]), np.median(buf[5:, 6] - buf[5:, 2]), np.median(buf[5:, 7] - buf[5:, 2])))
