@@ -82,4 +82,36 @@ GM_LIBM_HD float atanf_glibc(float x) {
     return neg ? -r : r;
 }
 
+
+// sin and cos of an f32 phase of moderate size (|x| < 8192 rad: k = rint(x * 2/pi) < 2^13), for the carrier wipe-off of the
+// tracking correlators (do_tracking.rs:243-246 calls f32::cos / f32::sin = glibc's cosf / sinf, < 1 ulp, not correctly
+// rounded).  Cody-Waite reduction in f32 with the first product split exactly: k*c1 = ph + pl (one multiply, one fma),
+// x - ph is exact (Sterbenz: ph is within a factor two of x whenever k != 0), and the small terms pl + k*c2 are gathered
+// before the single rounding that forms r — the reduced argument is as good as one rounded from f64 (pi/2 = c1 + c2 to 48
+// bits; k*c3 < 1e-11 is dropped).  Then the Cephes sinf / cosf minimax cores on |r| <= pi/4, which set the accuracy:
+// tests/cpu/test_libm.cpp measures max |error| = 1.56 * 2^-24 against the f64 functions on 6.7e7 arguments (the same as with
+// the argument reduced in f64, which this replaces: 99.999 % of results are identical) and a last-bit difference from the
+// host's sinf / cosf on 25 % of arguments.
+// The correlator sums these values enter are compared with the reference's under a tolerance; the loop state
+// downstream is where a bit-exact libm matters, and that uses atanf_glibc above.
+GM_LIBM_HD void sincos_cw(float x, float& s, float& c) {
+    const float c1 = f32_from_bits(0x3fc90fdbu), c2 = f32_from_bits(0xb33bbd2eu);   // pi/2 = 1.5707963705 - 4.3711388e-8 - ...
+    const float k = __builtin_rintf(x * 0.636619747f);
+    const float ph = k * c1;
+    const float pl = __builtin_fmaf(k, c1, -ph);          // k*c1 = ph + pl exactly
+    const float r1 = x - ph;                              // exact
+    const float r = r1 - __builtin_fmaf(k, c2, pl);
+    const float z = r * r;
+    float sp = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    sp = __builtin_fmaf(sp, z, -1.6666654611e-1f);
+    const float sr = __builtin_fmaf(sp * z, r, r);
+    float cp = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);
+    const float cr = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    const int q = int(k) & 3;
+    const float sv = (q & 1) ? cr : sr, cv = (q & 1) ? sr : cr;
+    s = (q & 2) ? -sv : sv;
+    c = ((q + 1) & 2) ? -cv : cv;
+}
+
 }  // namespace gm

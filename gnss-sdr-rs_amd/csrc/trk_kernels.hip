@@ -30,10 +30,19 @@ namespace gm {
 
 #define GM_PI_F 3.14159265358979323846f
 
+// a wave-uniform float, moved to a scalar register.  Also used to keep loop-invariant set-up code next to its (rare) use:
+// hoisted out of the epoch loop such values sat in VGPRs for the whole launch and were what the register allocator spilled.
+__device__ __forceinline__ float uniform_f32(float x) {
+    uint32_t u = __builtin_amdgcn_readfirstlane(__float_as_uint(x));
+    asm volatile("" : "+s"(u));       // opaque and pinned to this point of the program (not hoisted, not folded)
+    return __uint_as_float(u);
+}
+
 // sin/cos of an f32 argument up to ~1e5 rad in magnitude: the f32 value is reduced EXACTLY in f64
 // (r = x - k*pi/2 with a two-term pi/2, |r| <= pi/4, error < 1e-11), then evaluated with f32 minimax
-// polynomials (Cephes sinf/cosf cores, < 1 ulp).  glibc's cosf/sinf, which the reference calls, are
-// likewise < 1 ulp; the two agree to the last bit for almost every sample and to 1 ulp otherwise.
+// polynomials (Cephes sinf/cosf cores; max error 1.56 * 2^-24, measured in tests/cpu/test_libm.cpp).  glibc's cosf/sinf,
+// which the reference calls, are < 1 ulp; the two differ in the last bit on a quarter of the samples, never by more than 2 ulp.
+// Used where the phase may be large (the general path); the fast path uses gm_libm.h's sincos_cw (f32 reduction).
 __device__ __forceinline__ void sincos_f32_via_f64(float x, float& s, float& c) {
     const double xd = double(x);
     const double kd = __builtin_rint(xd * 0.63661977236758134308);   // 2/pi
@@ -73,7 +82,7 @@ template <bool FAST> __device__ __forceinline__ float fmod_code(float t, float l
 // with frexp/ldexp and three branches; this is 9.)
 __device__ __forceinline__ float fmod_bounded(float x, float y, float inv) {
     const float ax = fabsf(x);
-    if (!(ax < 4096.0f * y)) return fmodf(x, y);
+    if (!(ax < 4096.0f * y)) return fmodf(x, uniform_f32(y));   // (y through a scalar register: keeps the library form's set-up in this branch)
     const float q = rintf(ax * inv);
     float r = __builtin_fmaf(-q, y, ax);
     r = r < 0.0f ? r + y : r;
@@ -157,15 +166,20 @@ __device__ __forceinline__ EpochConsts epoch_consts(const TrkDevCfg& cfg, const 
 //    division on 1.3e9 operands for 21 sample rates (tools/ubench note in DESIGN.md); only the sign of a zero quotient can
 //    differ, which cannot change a sample's products.
 __device__ __forceinline__ bool fast_code_ok(const EpochConsts& c, uint64_t n) {     // the code replica's share
-    const bool code_ok = c.code_phase >= 0.0f && c.code_phase < c.lenf && c.step >= 0.0f && float(n) * c.step < 1.99f * c.lenf;
+    const bool code_ok = n < (1ull << 24) && c.code_phase >= 0.0f && c.code_phase < c.lenf && c.step >= 0.0f &&
+                         float(uint32_t(n)) * c.step < 1.99f * uniform_f32(c.lenf);    // n < 2^24: sample indices are exact as floats
     const bool arms_ok = c.el > 0.0f && c.el <= 1.0f && c.vel > 0.0f && c.vel <= 1.0f;
     return code_ok && arms_ok;
 }
-__device__ __forceinline__ bool fast_car_ok(const EpochConsts& c) {                   // the carrier's share
+// n_cap: an upper bound of the epoch's sample count (the phase must stay below 8000 rad for sincos_cw)
+__device__ __forceinline__ bool fast_car_ok(const EpochConsts& c, float n_cap) {      // the carrier's share
     return (__float_as_uint(c.fs) & 0x7fffffu) != 0x7fffffu && c.fs > 1.0f && c.fs < 1.0e12f &&
-           (c.two_pi_f == 0.0f || (fabsf(c.two_pi_f) > 1.0e-12f && fabsf(c.two_pi_f) < 1.0e12f));
+           (c.two_pi_f == 0.0f || (fabsf(c.two_pi_f) > 1.0e-12f && fabsf(c.two_pi_f) < 1.0e12f)) &&
+           fabsf(c.carrier_phase) + fabsf(c.two_pi_f) * (uniform_f32(n_cap) * c.inv_fs) < 8000.0f;
 }
-__device__ __forceinline__ bool fast_code_range(const EpochConsts& c, uint64_t n) { return fast_code_ok(c, n) && fast_car_ok(c); }
+__device__ __forceinline__ bool fast_code_range(const EpochConsts& c, uint64_t n) {
+    return fast_code_ok(c, n) && fast_car_ok(c, float(uint32_t(n)));
+}
 
 // x / fs, correctly rounded (see fast_code_range)
 __device__ __forceinline__ float div_by_fs(float x, float fs, float inv_fs) {
@@ -184,8 +198,13 @@ __device__ __forceinline__ int chip_index_arm(float phase, int len, int mode) {
 // one sample: carrier wipe-off fused with the replica multiplies (early_late_correlation :231-263)
 // MODE_T / BOC_T: compile-time code-index mode and BOC flag (straight-line code the scheduler can interleave
 // across samples), or -1 to read them from the epoch constants at run time (unit-entry kernels).
-template <int ARMS, bool FAST, int MODE_T = -1, int BOC_T = -1>
-__device__ __forceinline__ void correlate_sample(const EpochConsts& c, const int8_t* chips, cf d, uint32_t i,
+// CT: int8_t — the chip row as stored (unit-entry kernels); float — the persistent kernel's padded row (chip k at [k + 1])
+template <class CT> __device__ __forceinline__ float chip_at(const CT* t, int k);
+template <> __device__ __forceinline__ float chip_at<int8_t>(const int8_t* t, int k) { return float(t[k]); }
+template <> __device__ __forceinline__ float chip_at<float>(const float* t, int k) { return t[k + 1]; }
+
+template <int ARMS, bool FAST, int MODE_T = -1, int BOC_T = -1, class CT = int8_t>
+__device__ __forceinline__ void correlate_sample(const EpochConsts& c, const CT* chips, cf d, uint32_t i,
                                                  float (&acc)[2 * ARMS]) {
     const int mode = MODE_T >= 0 ? MODE_T : c.mode;
     const bool boc = BOC_T >= 0 ? (BOC_T != 0) : (c.boc11 != 0);
@@ -200,13 +219,13 @@ __device__ __forceinline__ void correlate_sample(const EpochConsts& c, const int
     const float chip_idx = fmod_code<FAST>(c.code_phase + fi * c.step, c.lenf);
     float pc, ec, lc;
     if (FAST) {   // chip_idx in [0, len): the prompt index needs no reduction, the arms one select each
-        pc = float(chips[int(floorf(chip_idx))]);
-        ec = float(chips[chip_index_arm(chip_idx + c.el, c.len, mode)]);
-        lc = float(chips[chip_index_arm(chip_idx - c.el, c.len, mode)]);
+        pc = chip_at(chips, int(floorf(chip_idx)));
+        ec = chip_at(chips, chip_index_arm(chip_idx + c.el, c.len, mode));
+        lc = chip_at(chips, chip_index_arm(chip_idx - c.el, c.len, mode));
     } else {
-        pc = float(chips[chip_index(chip_idx, c.len, mode)]);
-        ec = float(chips[chip_index(chip_idx + c.el, c.len, mode)]);
-        lc = float(chips[chip_index(chip_idx - c.el, c.len, mode)]);
+        pc = chip_at(chips, chip_index(chip_idx, c.len, mode));
+        ec = chip_at(chips, chip_index(chip_idx + c.el, c.len, mode));
+        lc = chip_at(chips, chip_index(chip_idx - c.el, c.len, mode));
     }
     if (boc) {   // BOC(1,1): sub-carrier sign = +1 on the first half chip, -1 on the second
         const float a = chip_idx, b = chip_idx + c.el, e = chip_idx - c.el;
@@ -220,11 +239,62 @@ __device__ __forceinline__ void correlate_sample(const EpochConsts& c, const int
     acc[4] = __builtin_fmaf(xr, lc, acc[4]); acc[5] = __builtin_fmaf(xi, lc, acc[5]);
     if constexpr (ARMS == 5) {
         const float ve = chip_idx + c.vel, vl = chip_idx - c.vel;
-        float vec = float(chips[FAST ? chip_index_arm(ve, c.len, mode) : chip_index(ve, c.len, mode)]);
-        float vlc = float(chips[FAST ? chip_index_arm(vl, c.len, mode) : chip_index(vl, c.len, mode)]);
+        float vec = chip_at(chips, FAST ? chip_index_arm(ve, c.len, mode) : chip_index(ve, c.len, mode));
+        float vlc = chip_at(chips, FAST ? chip_index_arm(vl, c.len, mode) : chip_index(vl, c.len, mode));
         if (boc) {
             vec = (ve - floorf(ve)) < 0.5f ? vec : -vec;
             vlc = (vl - floorf(vl)) < 0.5f ? vlc : -vlc;
+        }
+        acc[6] = __builtin_fmaf(xr, vec, acc[6]); acc[7] = __builtin_fmaf(xi, vec, acc[7]);
+        acc[8] = __builtin_fmaf(xr, vlc, acc[8]); acc[9] = __builtin_fmaf(xi, vlc, acc[9]);
+    }
+}
+
+// ---- the persistent kernel's sample, for epochs that passed fast_car_ok / fast_code_ok.  Same arithmetic as
+// correlate_sample<.., FAST = true> on the values that reach the sums, with the instruction count of the hot loop cut
+// (it is bound by VALU issue slots: ~115 -> ~80 issue units per sample):
+//  * the chip row is a float table padded by one entry at each end — tab[0] is what floor = -1 reads (chip 0 in
+//    FAITHFUL mode, the last chip in FIXED mode), tab[len + 1] = chip 0 is what floor = len reads (`% len`) — so an arm
+//    is floor -> load, with no selects and no int -> float conversion;
+//  * the code phase's conditional subtractions are one unsigned minimum: t >= 0, so of {t, t - len, t - 2 len} the
+//    non-negative ones order like their bit patterns and the negative ones (sign bit set) compare above all of them —
+//    the minimum is the reduced phase, the same value fmod_code<true> selects;
+//  * the sample index arrives as a float (exact: n < 2^24 is part of fast_code_ok), formed by additions;
+//  * sin/cos by gm_libm.h's sincos_cw (f32 Cody-Waite reduction; |phase| < 8000 rad is part of fast_car_ok): the same
+//    values as the f64-reduced form on 99.999 % of arguments, the same polynomial cores.
+__device__ __forceinline__ int floor_i32(float x) {      // int(floorf(x)) in one instruction
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+template <int ARMS, int BOC_T>
+__device__ __forceinline__ void correlate_sample_fast(const EpochConsts& c, const float* tab, cf d, float fi, float (&acc)[2 * ARMS]) {
+    const float w = c.two_pi_f * fi;
+    const float phase = c.carrier_phase + div_by_fs(w, c.fs, c.inv_fs);
+    float sn, cs;
+    sincos_cw(phase, sn, cs);
+    const float wc = cs, ws = -sn;                          // Complex32::new(cos_p, -sin)
+    const float xr = d.x * wc - d.y * ws;                   // num-complex Mul
+    const float xi = d.x * ws + d.y * wc;
+    const float t = c.code_phase + fi * c.step;
+    const uint32_t ua = __float_as_uint(t), ub = __float_as_uint(t - c.lenf), uc = __float_as_uint(t - 2.0f * c.lenf);
+    const float chip_idx = __uint_as_float(min(min(ua, ub), uc));
+    const float ea = chip_idx + c.el, la = chip_idx - c.el;
+    float pc = tab[floor_i32(chip_idx) + 1], ec = tab[floor_i32(ea) + 1], lc = tab[floor_i32(la) + 1];
+    if (BOC_T) {   // BOC(1,1): sub-carrier sign = +1 on the first half chip, -1 on the second (fract = x - floor(x))
+        pc = __builtin_amdgcn_fractf(chip_idx) < 0.5f ? pc : -pc;
+        ec = __builtin_amdgcn_fractf(ea) < 0.5f ? ec : -ec;
+        lc = __builtin_amdgcn_fractf(la) < 0.5f ? lc : -lc;
+    }
+    acc[0] = __builtin_fmaf(xr, pc, acc[0]); acc[1] = __builtin_fmaf(xi, pc, acc[1]);
+    acc[2] = __builtin_fmaf(xr, ec, acc[2]); acc[3] = __builtin_fmaf(xi, ec, acc[3]);
+    acc[4] = __builtin_fmaf(xr, lc, acc[4]); acc[5] = __builtin_fmaf(xi, lc, acc[5]);
+    if constexpr (ARMS == 5) {
+        const float ve = chip_idx + c.vel, vl = chip_idx - c.vel;
+        float vec = tab[floor_i32(ve) + 1], vlc = tab[floor_i32(vl) + 1];
+        if (BOC_T) {
+            vec = __builtin_amdgcn_fractf(ve) < 0.5f ? vec : -vec;
+            vlc = __builtin_amdgcn_fractf(vl) < 0.5f ? vlc : -vlc;
         }
         acc[6] = __builtin_fmaf(xr, vec, acc[6]); acc[7] = __builtin_fmaf(xi, vec, acc[7]);
         acc[8] = __builtin_fmaf(xr, vlc, acc[8]); acc[9] = __builtin_fmaf(xi, vlc, acc[9]);
@@ -582,7 +652,7 @@ struct EpochShared {
 // n_known: the epilogue has just stored round(fs/(code_rate/len)) for the CURRENT code_rate in num_samples_per_code
 // first: write every constant (launch start); later calls write the four per-epoch ones
 __device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t head, const gm_trk_state& s, EpochShared& sh,
-                                              bool n_known, bool first) {
+                                              bool n_known, bool first, float n_cap) {
     const uint64_t n = n_known ? s.num_samples_per_code : samples_per_code(cfg, s.code_rate);     // update() :165-166
     bool run = s.active && n > 0 && n < (1ull << 31);
     if (run) run = (int64_t)(head - (s.next_sample_index + n)) >= 0;              // :170-172
@@ -591,8 +661,8 @@ __device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t hea
     const EpochConsts ec = epoch_consts(cfg, s);
     if (first) sh.ec = ec;
     else { sh.ec.carrier_phase = ec.carrier_phase; sh.ec.two_pi_f = ec.two_pi_f; sh.ec.code_phase = ec.code_phase; sh.ec.step = ec.step; }
-    sh.fast_car = fast_car_ok(ec) ? 1 : 0;
-    sh.fast_code = fast_code_ok(ec, n) ? 1 : 0;
+    sh.fast_car = fast_car_ok(ec, n_cap) ? 1 : 0;
+    sh.fast_code = (fast_code_ok(ec, n) && float(uint32_t(n)) <= n_cap) ? 1 : 0;
 }
 
 template <int ARMS, int MODE_T, int BOC_T, int T>
@@ -616,10 +686,15 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     __shared__ EpochShared sh;          // wave 0 -> everyone, once per epoch
     __shared__ int ctl;                 // 0 continue, 1 exchange timed out
     __shared__ float pre_phase[2];      // the carrier / code phase the coming state will hold (waves 2 / 3, every epoch)
-    __shared__ CodeHalf fin_code;       // wave 1's share of the channel state, handed to the leader at the end
+    // The channel state between epochs: wave 0's copy (it owns the carrier fields and the bookkeeping) and wave 1's (code
+    // fields).  Parked in LDS rather than in registers while the workgroup correlates: held in registers it put the hot loop
+    // over the 128-VGPR budget of two workgroups per CU, and the spilled values came back through scratch memory in the
+    // middle of the serial section.
+    __shared__ gm_trk_state st_sh[2];
     static_assert(NW >= 4, "waves 0/1 run the two halves of the serial section, waves 2/3 the phase advances");
     __shared__ float gathered[256];     // the G*NV partials of one epoch (wave 0 only)
-    extern __shared__ int8_t chips[];   // the channel's chip row
+    extern __shared__ float chips_pad[];   // the channel's chip row as floats, one guard entry at each end (correlate_sample_fast)
+    float* const chips = chips_pad;
 
     // an earlier launch of the same call (more than 4095 passes are several launches) has timed out: do nothing, the host
     // reports the error after it synchronises
@@ -635,7 +710,6 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     int e = 0;
     bool timed_out = false;
     const bool ran = s0.active && row >= 0 && row < cfg.n_codes;
-    gm_trk_state st = s0;               // the channel state: updated by wave 0 only, epoch after epoch, in registers
     // Same-XCD hand-shake, once per launch: every workgroup publishes the XCC_ID it runs on (write-through, like the first
     // epoch's partials); after the first epoch's exchange each one has read all G of them and, when they agree, later epochs
     // publish with PLAIN stores, which stay in the XCD's L2 where the partners' L1-bypassing polls find them (a write-through
@@ -650,8 +724,17 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             __hip_atomic_store(&xcc_slot[g], (unsigned long long)my_xcc | ((unsigned long long)(a.tag_base + 1u) << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int8_t* crow = a.codes + size_t(row) * cfg.code_len;
-        for (int i = tid; i < cfg.code_len; i += T) chips[i] = crow[i];
-        if (tid == 0) { ctl = 0; prepare_epoch(cfg, a.head, s0, sh, false, true); }
+        for (int i = tid; i < cfg.code_len; i += T) chips[i + 1] = float(crow[i]);
+        if (tid == 0) {   // what floor(phase) = -1 and = len read (get_ca_chip :275: `as usize` saturates / FIXED wraps; `% len`)
+            chips[0] = float(crow[cfg.code_index_mode == GM_CODE_INDEX_FAITHFUL ? 0 : cfg.code_len - 1]);
+            chips[cfg.code_len + 1] = float(crow[0]);
+        }
+        // an upper bound of any epoch's sample count in this launch, for the fast forms' range checks
+        // (wave-uniform floats that live for the whole launch are pinned to scalar registers: left in VGPRs they were the
+        // values the register allocator spilled, and their reloads from scratch sat in the middle of the serial section)
+        const float n_cap = uniform_f32(2.0f * float(a.per) * float(a.G));
+        if (tid == 0) { ctl = 0; prepare_epoch(cfg, a.head, s0, sh, false, true, n_cap); }
+        if (lane == 0 && wave < 2) st_sh[wave] = s0;
         __syncthreads();
         // slice geometry, fixed for the launch: `per` samples per workgroup (multiple of 64 lanes); the last
         // workgroup also takes whatever a longer code period adds beyond G*per
@@ -691,46 +774,75 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 const uint32_t b0 = i0 + tid;
                 const uint32_t tot = full + ((b0 + full * T) < i1 ? 1u : 0u);
                 const uint32_t wtot = full + (__any((b0 + full * T) < i1) ? 1u : 0u);       // wave-uniform
-                float acc3[NV], acc4[NV];
-#pragma unroll
-                for (int k = 0; k < NV; ++k) { acc3[k] = 0.0f; acc4[k] = 0.0f; }
                 const cf zero = cf_make(0.0f, 0.0f);
-                for (uint32_t j = 0; j < wtot; j += 4) {                 // the first block comes from the prefetched registers
-                    const uint32_t left = wtot - j;
-                    cf d0 = zero, d1 = zero, d2 = zero, d3 = zero;
-                    if (j == 0) {
-                        if (tot > 0) d0 = pf0;
-                        if (tot > 1) d1 = pf1;
-                        if (tot > 2) d2 = pf2;
-                        if (tot > 3) d3 = pf3;
-                    } else {
-                        if (j < tot) d0 = a.ring[(win + b0 + j * T) & a.mask];
-                        if (j + 1 < tot) d1 = a.ring[(win + b0 + (j + 1) * T) & a.mask];
-                        if (j + 2 < tot) d2 = a.ring[(win + b0 + (j + 2) * T) & a.mask];
-                        if (j + 3 < tot) d3 = a.ring[(win + b0 + (j + 3) * T) & a.mask];
+                const float fb0 = float(b0);                             // sample indices as floats: exact below 2^24
+                constexpr float TF = float(T);
+                // interleave width: four chains with three arms; two with five (ten accumulators per chain: four chains spill)
+                constexpr uint32_t IL = ARMS == 3 ? 4 : 2;
+                if constexpr (IL == 4) {
+                    float acc3[NV], acc4[NV];
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) { acc3[k] = 0.0f; acc4[k] = 0.0f; }
+                    for (uint32_t j = 0; j < wtot; j += 4) {             // the first block comes from the prefetched registers
+                        const uint32_t left = wtot - j;
+                        cf d0 = zero, d1 = zero, d2 = zero, d3 = zero;
+                        if (j == 0) {
+                            if (tot > 0) d0 = pf0;
+                            if (tot > 1) d1 = pf1;
+                            if (tot > 2) d2 = pf2;
+                            if (tot > 3) d3 = pf3;
+                        } else {
+                            if (j < tot) d0 = a.ring[(win + b0 + j * T) & a.mask];
+                            if (j + 1 < tot) d1 = a.ring[(win + b0 + (j + 1) * T) & a.mask];
+                            if (j + 2 < tot) d2 = a.ring[(win + b0 + (j + 2) * T) & a.mask];
+                            if (j + 3 < tot) d3 = a.ring[(win + b0 + (j + 3) * T) & a.mask];
+                        }
+                        const float f0 = fb0 + float(j * T), f1 = f0 + TF, f2 = f0 + 2.0f * TF, f3 = f0 + 3.0f * TF;
+                        // one basic block per block size, so that the chains really are interleaved
+                        if (left >= 4) {
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d1, f1, acc2);
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d2, f2, acc3);
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d3, f3, acc4);
+                        } else if (left == 3) {
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d1, f1, acc2);
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d2, f2, acc3);
+                        } else if (left == 2) {
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d1, f1, acc2);
+                        } else {
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
+                        }
                     }
-                    // one basic block per block size, so that the chains really are interleaved
-                    if (left >= 4) {
-                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d0, b0 + j * T, acc);
-                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d1, b0 + (j + 1) * T, acc2);
-                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d2, b0 + (j + 2) * T, acc3);
-                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d3, b0 + (j + 3) * T, acc4);
-                    } else if (left == 3) {
-                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d0, b0 + j * T, acc);
-                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d1, b0 + (j + 1) * T, acc2);
-                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d2, b0 + (j + 2) * T, acc3);
-                    } else if (left == 2) {
-                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d0, b0 + j * T, acc);
-                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d1, b0 + (j + 1) * T, acc2);
-                    } else {
-                        correlate_sample<ARMS, true, MODE_T, BOC_T>(ec, chips, d0, b0 + j * T, acc);
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) { acc[k] = acc[k] + acc3[k]; acc2[k] = acc2[k] + acc4[k]; }
+                } else {
+                    for (uint32_t j = 0; j < wtot; j += 2) {
+                        const uint32_t left = wtot - j;
+                        cf d0 = zero, d1 = zero;
+                        if (j == 0) {
+                            if (tot > 0) d0 = pf0;
+                            if (tot > 1) d1 = pf1;
+                        } else if (j == 2) {
+                            if (tot > 2) d0 = pf2;
+                            if (tot > 3) d1 = pf3;
+                        } else {
+                            if (j < tot) d0 = a.ring[(win + b0 + j * T) & a.mask];
+                            if (j + 1 < tot) d1 = a.ring[(win + b0 + (j + 1) * T) & a.mask];
+                        }
+                        const float f0 = fb0 + float(j * T), f1 = f0 + TF;
+                        if (left >= 2) {
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d1, f1, acc2);
+                        } else {
+                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
+                        }
                     }
                 }
-#pragma unroll
-                for (int k = 0; k < NV; ++k) { acc[k] = acc[k] + acc3[k]; acc2[k] = acc2[k] + acc4[k]; }
             } else {   // out-of-family state (e.g. set by the caller): general fmodf, no prefetch use
                 for (uint32_t i = i0 + tid; i < i1; i += T)
-                    correlate_sample<ARMS, false, MODE_T, BOC_T>(ec, chips, a.ring[(win + i) & a.mask], i, acc);
+                    correlate_sample<ARMS, false, MODE_T, BOC_T, float>(ec, chips, a.ring[(win + i) & a.mask], i, acc);
             }
             if (st_on) stp[1] = stamp_now();
             if (a.stamps && blockIdx.x == 0 && lane == 0) stp[8 + wave] = stamp_now();        // per-wave compute end
@@ -757,7 +869,9 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             if (a.stamps && blockIdx.x == 0 && lane == 0) stp[24 + wave] = stamp_now();       // per-wave barrier arrival
             lds_barrier();    // NOT __syncthreads(): its fence would wait for the prefetch loads (vmcnt(0))
             if (st_on) stp[2] = stamp_now();
+            gm_trk_state st;      // waves 0 / 1: this wave's copy of the channel state, from LDS and back (after the barrier below)
             if (wave < 2) {
+                st = st_sh[wave];
                 // The serial section: wave 0 publishes this workgroup's partial; waves 0 AND 1 each gather the G partials and
                 // form the totals (same loads, same order: identical values), then wave 0 runs the carrier half of the scalar
                 // update and wave 1 the code half, side by side (a lone wave issues one instruction per ~5 cycles whatever
@@ -903,7 +1017,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     if (lane == 0) {      // the carrier's share of the NEXT epoch's constants
                         const EpochConsts nx = epoch_consts(cfg, st);
                         sh.ec.carrier_phase = nx.carrier_phase; sh.ec.two_pi_f = nx.two_pi_f;
-                        sh.fast_car = fast_car_ok(nx) ? 1 : 0;
+                        sh.fast_car = fast_car_ok(nx, n_cap) ? 1 : 0;
                         if (to) ctl = 1;
                         if (g == 0 && !to) {
                             const size_t o = size_t(e) * C + ch;
@@ -932,7 +1046,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                         sh.win = st.next_sample_index;
                         sh.n = run ? uint32_t(nn) : 0u;
                         sh.ec.code_phase = nx.code_phase; sh.ec.step = nx.step;
-                        sh.fast_code = fast_code_ok(nx, nn) ? 1 : 0;
+                        sh.fast_code = (fast_code_ok(nx, nn) && float(uint32_t(nn)) <= n_cap) ? 1 : 0;
                         if (to) ctl = 1;
                     }
                     if (st1_on) stp[42] = stamp_now();
@@ -941,6 +1055,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             }
             lds_barrier();
             if (ctl) { timed_out = true; break; }
+            if (wave < 2 && lane == 0) st_sh[wave] = st;      // off the serial chain: the other waves are already correlating
             // no third barrier: wsum is rewritten only after every wave has passed the NEXT epoch's compute, and
             // `sh` only after the next epoch's first barrier, which no wave reaches before reading it above
             if (st_on) stp[7] = stamp_now();
@@ -950,19 +1065,16 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             __hip_atomic_store(a.error_flag_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // later launches' copy
         }
     }
-    if (ran) {      // the code half of the state lives in wave 1's registers
-        if (tid == 64) {
-            fin_code.num_samples_per_code = st.num_samples_per_code; fin_code.code_phase = st.code_phase;
-            fin_code.code_error = st.code_error; fin_code.code_nco = st.code_nco; fin_code.code_rate = st.code_rate;
-        }
+    if (ran) {      // carrier fields and bookkeeping from wave 0's copy, code fields from wave 1's
         __syncthreads();
-        if (leader) {
-            st.num_samples_per_code = fin_code.num_samples_per_code; st.code_phase = fin_code.code_phase;
-            st.code_error = fin_code.code_error; st.code_nco = fin_code.code_nco; st.code_rate = fin_code.code_rate;
+        if (leader) {   // (the leader is lane 0 of wave 0) an idle channel's state is left as it was
+            gm_trk_state st = st_sh[0];
+            st.num_samples_per_code = st_sh[1].num_samples_per_code; st.code_phase = st_sh[1].code_phase;
+            st.code_error = st_sh[1].code_error; st.code_nco = st_sh[1].code_nco; st.code_rate = st_sh[1].code_rate;
+            a.states[ch] = st;
         }
     }
     if (leader) {
-        if (ran) a.states[ch] = st;         // (the leader is lane 0 of wave 0) an idle channel's state is left as it was
         gm_trk_out z;
         z.ip = z.qp = z.ie = z.qe = z.il = z.ql = z.ive = z.qve = z.ivl = z.qvl = 0.0f;
         for (int r = e; r < a.epochs; ++r) {   // passes in which this channel did not run
@@ -974,6 +1086,9 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
         }
     }
 }
+
+// dynamic LDS of the persistent kernel: the chip row as floats with one guard entry at each end, rounded up to 16 B
+static size_t trk_persistent_lds(const TrkDevCfg& cfg) { return (size_t(cfg.code_len + 2) * sizeof(float) + 15) & ~size_t(15); }
 
 void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_codes, gm_trk_state* d_states,
                            const cf* ring, uint64_t mask, uint64_t head, int G, int epochs, uint32_t tag_base,
@@ -990,8 +1105,7 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
         a.per = uint32_t(((n_nom + G - 1) / G + 63) / 64 * 64);
     } a.xchg = d_xchg; a.outs = d_outs;
     a.processed = d_processed; a.lost = d_lost; a.lost_prn = d_lost_prn; a.error_flag = d_error;
-    // dynamic LDS: chip row (padded to 16 B) + the gathered G*NV partials
-    const size_t lds = size_t((cfg.code_len + 15) & ~15);
+    const size_t lds = trk_persistent_lds(cfg);
     const dim3 grid(trk_persistent_slots(cfg.n_channels) * G);     // channel slots: n_channels rounded up to the eight XCDs
     // compile-time arms / code-index mode / BOC: straight-line sample code
     const int key = (cfg.n_arms == 5 ? 4 : 0) | (cfg.code_index_mode == GM_CODE_INDEX_FIXED ? 2 : 0) | (cfg.boc11 ? 1 : 0);
@@ -1012,7 +1126,7 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
 // capped by the design's TRK_PERSIST_WG_PER_CU): the exchange between the G workgroups of a channel needs all
 // n_channels * G of them resident together.
 int trk_persistent_blocks_per_cu(const TrkDevCfg& cfg) {
-    const size_t lds = size_t((cfg.code_len + 15) & ~15);
+    const size_t lds = trk_persistent_lds(cfg);
     const int key = (cfg.n_arms == 5 ? 4 : 0) | (cfg.code_index_mode == GM_CODE_INDEX_FIXED ? 2 : 0) | (cfg.boc11 ? 1 : 0);
     constexpr int T = TRK_PERSIST_THREADS;
     int n = 0;

@@ -23,5 +23,23 @@ int main() {
         ++n;
     }
     printf("atanf_glibc: %llu arguments, %llu mismatches\n", n, bad);
+    // sincos_cw against the f64 functions of the same f32 argument: |x| <= 8192, 2^25 arguments + every small-k boundary
+    double worst = 0.0;
+    unsigned long long ns = 0, lastbit = 0;
+    for (unsigned i = 0; i <= (1u << 25); ++i) {
+        const float x = -8192.0f + 16384.0f * float(i) / float(1u << 25);
+        float sv, cv;
+        gm::sincos_cw(x, sv, cv);
+        const double es = fabs(double(sv) - sin(double(x))), ec = fabs(double(cv) - cos(double(x)));
+        if (es > worst) worst = es;
+        if (ec > worst) worst = ec;
+        if (gm::f32_bits(sv) != gm::f32_bits(sinf(x))) ++lastbit;
+        if (gm::f32_bits(cv) != gm::f32_bits(cosf(x))) ++lastbit;
+        ns += 2;
+    }
+    const double ulp1 = 5.9604644775390625e-08;   // 2^-24: ulp of results in [0.5, 1)
+    printf("sincos_cw: %llu values, max |error| = %.3g = %.2f ulp(1); differs from the host's sinf/cosf in the last bit on %.2f %%\n",
+           ns, worst, worst / ulp1, 100.0 * double(lastbit) / double(ns));
+    if (worst > 1.6 * ulp1) { printf("sincos_cw: error bound exceeded\n"); bad++; }
     return bad ? 1 : 0;
 }
