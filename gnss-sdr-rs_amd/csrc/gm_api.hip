@@ -1175,6 +1175,7 @@ static int trk_reserve_epochs(gm_trk* t, uint32_t e) {
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
     const size_t n = size_t(e) * t->C;
     HIPC(hipMalloc(&t->d_outs, n * sizeof(gm_trk_out)));
+    HIPC(hipMemset(t->d_outs, 0, n * sizeof(gm_trk_out)));   // with three arms the persistent kernel writes the six live sums only: ive..qvl stay 0
     HIPC(hipMalloc(&t->d_proc, n)); HIPC(hipMalloc(&t->d_lost, n)); HIPC(hipMalloc(&t->d_lostprn, n));
     t->epochs_cap = e;
     return GM_OK;

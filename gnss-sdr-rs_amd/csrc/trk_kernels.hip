@@ -1021,7 +1021,15 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                         if (to) ctl = 1;
                         if (g == 0 && !to) {
                             const size_t o = size_t(e) * C + ch;
-                            if (a.outs) a.outs[o] = make_out<ARMS>(v);
+                            if (a.outs) {
+                                if constexpr (ARMS == 5) a.outs[o] = make_out<ARMS>(v);
+                                else {   // ive..qvl are zero since the buffer was allocated (gm_api.hip trk_reserve_epochs): the six
+                                         // live sums only — the four zeros were values the register allocator kept (and spilled)
+                                    float* po = reinterpret_cast<float*>(&a.outs[o]);
+#pragma unroll
+                                    for (int k = 0; k < NV; ++k) po[k] = v[k];
+                                }
+                            }
                             if (a.processed) a.processed[o] = 1;
                             if (a.lost) a.lost[o] = lst;
                             if (a.lost_prn) a.lost_prn[o] = lprn;
