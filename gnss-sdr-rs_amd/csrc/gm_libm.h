@@ -83,13 +83,13 @@ GM_LIBM_HD float atanf_glibc(float x) {
 }
 
 
-// sin and cos of an f32 phase of moderate size (|x| < 8192 rad: k = rint(x * 2/pi) < 2^13), for the carrier wipe-off of the
+// sin and cos of an f32 phase of moderate size (|x| < 1.3e5 rad: k = rint(x * 2/pi) < 2^17), for the carrier wipe-off of the
 // tracking correlators (do_tracking.rs:243-246 calls f32::cos / f32::sin = glibc's cosf / sinf, < 1 ulp, not correctly
 // rounded).  Cody-Waite reduction in f32 with the first product split exactly: k*c1 = ph + pl (one multiply, one fma),
 // x - ph is exact (Sterbenz: ph is within a factor two of x whenever k != 0), and the small terms pl + k*c2 are gathered
 // before the single rounding that forms r — the reduced argument is as good as one rounded from f64 (pi/2 = c1 + c2 to 48
-// bits; k*c3 < 1e-11 is dropped).  Then the Cephes sinf / cosf minimax cores on |r| <= pi/4, which set the accuracy:
-// tests/cpu/test_libm.cpp measures max |error| = 1.56 * 2^-24 against the f64 functions on 6.7e7 arguments (the same as with
+// bits; k*c3 < 2e-10 is dropped).  Then the Cephes sinf / cosf minimax cores on |r| <= pi/4, which set the accuracy:
+// tests/cpu/test_libm.cpp measures max |error| = 1.56 * 2^-24 against the f64 functions on 6.7e7 arguments in |x| <= 131072 (the same as with
 // the argument reduced in f64, which this replaces: 99.999 % of results are identical) and a last-bit difference from the
 // host's sinf / cosf on 25 % of arguments.
 // The correlator sums these values enter are compared with the reference's under a tolerance; the loop state

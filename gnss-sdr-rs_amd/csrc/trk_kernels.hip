@@ -171,11 +171,12 @@ __device__ __forceinline__ bool fast_code_ok(const EpochConsts& c, uint64_t n) {
     const bool arms_ok = c.el > 0.0f && c.el <= 1.0f && c.vel > 0.0f && c.vel <= 1.0f;
     return code_ok && arms_ok;
 }
-// n_cap: an upper bound of the epoch's sample count (the phase must stay below 8000 rad for sincos_cw)
+// n_cap: an upper bound of the epoch's sample count (the phase must stay below 1e5 rad for sincos_cw: an IF of a few MHz
+// over a 1 ms epoch is ~3e4 rad)
 __device__ __forceinline__ bool fast_car_ok(const EpochConsts& c, float n_cap) {      // the carrier's share
     return (__float_as_uint(c.fs) & 0x7fffffu) != 0x7fffffu && c.fs > 1.0f && c.fs < 1.0e12f &&
            (c.two_pi_f == 0.0f || (fabsf(c.two_pi_f) > 1.0e-12f && fabsf(c.two_pi_f) < 1.0e12f)) &&
-           fabsf(c.carrier_phase) + fabsf(c.two_pi_f) * (uniform_f32(n_cap) * c.inv_fs) < 8000.0f;
+           fabsf(c.carrier_phase) + fabsf(c.two_pi_f) * (uniform_f32(n_cap) * c.inv_fs) < 1.0e5f;
 }
 __device__ __forceinline__ bool fast_code_range(const EpochConsts& c, uint64_t n) {
     return fast_code_ok(c, n) && fast_car_ok(c, float(uint32_t(n)));
@@ -260,7 +261,7 @@ __device__ __forceinline__ void correlate_sample(const EpochConsts& c, const CT*
 //    non-negative ones order like their bit patterns and the negative ones (sign bit set) compare above all of them —
 //    the minimum is the reduced phase, the same value fmod_code<true> selects;
 //  * the sample index arrives as a float (exact: n < 2^24 is part of fast_code_ok), formed by additions;
-//  * sin/cos by gm_libm.h's sincos_cw (f32 Cody-Waite reduction; |phase| < 8000 rad is part of fast_car_ok): the same
+//  * sin/cos by gm_libm.h's sincos_cw (f32 Cody-Waite reduction; |phase| < 1e5 rad is part of fast_car_ok): the same
 //    values as the f64-reduced form on 99.999 % of arguments, the same polynomial cores.
 __device__ __forceinline__ int floor_i32(float x) {      // int(floorf(x)) in one instruction
     int r;
