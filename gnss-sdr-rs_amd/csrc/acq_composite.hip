@@ -89,6 +89,24 @@ __global__ __launch_bounds__(CT) void comp_fwd_post_kernel(const cf* __restrict_
     }
 }
 
+// The code-side factor of sub-transform n1, once per handle (codes are static): comb[p][n1][k1][pos] =
+// conj(C[p][k1][pos]) * W_Q^{-n1 k1} * W_N^{-n1 k2(pos)} — elementwise on the paired layout, so positions carry over.
+template <class PL, uint32_t Q>
+__global__ __launch_bounds__(256) void comp_code_comb_kernel(const cf* __restrict__ code_paired, const cf* __restrict__ twn,
+                                                             cf* __restrict__ comb) {
+    constexpr uint32_t Nb = PL::N;
+    const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos >= Nb) return;
+    const uint32_t p = blockIdx.y / Q, n1 = blockIdx.y % Q;
+    const cf t = twn[size_t(n1) * Nb + pos];
+#pragma unroll
+    for (uint32_t k1 = 0; k1 < Q; ++k1) {
+        const cf c = code_paired[(size_t(p) * Q + k1) * Nb + pos];
+        const cf g = cf_mul(cf_mul(cf_make(c.x, -c.y), unit_root((n1 * k1) % Q, Q, true)), t);
+        comb[((size_t(p) * Q + n1) * Q + k1) * Nb + pos] = g;
+    }
+}
+
 // ------------------------------------------------------------------------------------ inverse, fused
 // One workgroup per (worker, bin).  spectra [d][m][k1][paired k2], code [p][k1][paired k2], twn [n1][paired k2] =
 // W_N^{-n1 k2} (e^{+...}: inverse).
@@ -113,56 +131,49 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void comp_corr_kernel(
     constexpr bool ODD0 = (PL::R0 & 1) != 0;
     constexpr uint32_t N = Q * uint32_t(Nb);
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(spectra + size_t(d) * n_int * N, unsigned(n_int) * N * 8u);
-    const __amdgpu_buffer_rsrc_t crs = make_rsrc(code_fft + size_t(p) * N, N * 8u);
-    const __amdgpu_buffer_rsrc_t trs = make_rsrc(twn, N * 8u);
+    // code_fft: the combined tables [code][n1][k1][pos] of comp_code_comb_kernel
     const int oob = 0x7ffffff0;                              // lanes without a pass-0 butterfly: dropped by the range check
     const int v16 = tid < NB0 ? tid * 16 : oob, v8 = tid < NB0 ? tid * 8 : oob;
     auto lo = [](u32x4 v) { return cf_make(__uint_as_float(v.x), __uint_as_float(v.y)); };
     auto hi = [](u32x4 v) { return cf_make(__uint_as_float(v.z), __uint_as_float(v.w)); };
-    auto prod = [](cf a, cf g) {                             // result_buf[i] *= conj(code[i]) (:184-186), num-complex Mul, no FMA
-        const float cx = g.x, cy = -g.y;
-        return cf_make(a.x * cx - a.y * cy, a.x * cy + a.y * cx);
-    };
 
     float bv = 0.0f, sum = 0.0f;
     uint32_t bi = 0xffffffffu;
     for (uint32_t n1 = 0; n1 < Q; ++n1) {
-        cf wq[Q];                                            // row n1 of the Q-point inverse DFT: W_Q^{-n1 k1}
-#pragma unroll
-        for (uint32_t k1 = 0; k1 < Q; ++k1) wq[k1] = unit_root((n1 * k1) % Q, Q, true);
+        const __amdgpu_buffer_rsrc_t crs = make_rsrc(code_fft + (size_t(p) * Q + n1) * N, N * 8u);
         float acc[PL::ITL][PL::RL];
 #pragma unroll
         for (int it = 0; it < PL::ITL; ++it)
 #pragma unroll
             for (int r = 0; r < PL::RL; ++r) acc[it][r] = 0.0f;
         for (int m = 0; m < n_int; ++m) {
+            // vals[r] = sum over k1 of X[m][k1][k] * comb[n1][k1][k]: the Q-point inverse DFT row, the inverse twiddle and
+            // conj(code) (:184-186) are all inside the table
             cf vals[PL::R0];
 #pragma unroll
             for (int rp = 0; rp < NPAIR; ++rp) {
-                const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(trs, v16, (int(n1) * Nb + rp * 2 * NB0) * 8, 0);
                 cf s0 = cf_make(0.f, 0.f), s1 = s0;
 #pragma unroll
                 for (uint32_t k1 = 0; k1 < Q; ++k1) {
                     const u32x4 x4 = __builtin_amdgcn_raw_buffer_load_b128(xrs, v16, ((m * int(Q) + int(k1)) * Nb + rp * 2 * NB0) * 8, 0);
                     const u32x4 c4 = __builtin_amdgcn_raw_buffer_load_b128(crs, v16, (int(k1) * Nb + rp * 2 * NB0) * 8, 0);
-                    const cf p0 = prod(lo(x4), lo(c4)), p1 = prod(hi(x4), hi(c4));
+                    const cf p0 = cf_mul(lo(x4), lo(c4)), p1 = cf_mul(hi(x4), hi(c4));
                     if (k1 == 0) { s0 = p0; s1 = p1; }
-                    else { s0 = cf_add(s0, cf_mul(p0, wq[k1])); s1 = cf_add(s1, cf_mul(p1, wq[k1])); }
+                    else { s0 = cf_add(s0, p0); s1 = cf_add(s1, p1); }
                 }
-                vals[2 * rp] = cf_mul(s0, lo(t4));
-                vals[2 * rp + 1] = cf_mul(s1, hi(t4));
+                vals[2 * rp] = s0;
+                vals[2 * rp + 1] = s1;
             }
             if constexpr (ODD0) {
-                const cf t1 = buf_load_cf(trs, v8, (int(n1) * Nb + 2 * NPAIR * NB0) * 8);
                 cf s0 = cf_make(0.f, 0.f);
 #pragma unroll
                 for (uint32_t k1 = 0; k1 < Q; ++k1) {
                     const cf x1 = buf_load_cf(xrs, v8, ((m * int(Q) + int(k1)) * Nb + 2 * NPAIR * NB0) * 8);
                     const cf c1 = buf_load_cf(crs, v8, (int(k1) * Nb + 2 * NPAIR * NB0) * 8);
-                    const cf p0 = prod(x1, c1);
-                    s0 = k1 == 0 ? p0 : cf_add(s0, cf_mul(p0, wq[k1]));
+                    const cf p0 = cf_mul(x1, c1);
+                    s0 = k1 == 0 ? p0 : cf_add(s0, p0);
                 }
-                vals[PL::R0 - 1] = cf_mul(s0, t1);
+                vals[PL::R0 - 1] = s0;
             }
             lds_transform<PL, true>([&](int, int r) { return vals[r]; },
                                     [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y); },   // += norm_sqr() (:190-192)
@@ -232,7 +243,10 @@ template <class PL, uint32_t Q> struct CompLaunch {
                 out[size_t(n1) * Nb + PairLayout<PL>::pos(int(k2))] = cf_make(float(::cos(a)), float(::sin(a)));
             }
     }
-    static constexpr CompOps ops() { return CompOps{PL::N, int(Q), &fwd_sub, &fwd_post, &corr, &fill_twn}; }
+    static void comb(hipStream_t st, const cf* code_paired, const cf* twn, cf* out, uint32_t n_codes) {
+        hipLaunchKernelGGL((comp_code_comb_kernel<PL, Q>), dim3((PL::N + 255) / 256, n_codes * Q), dim3(256), 0, st, code_paired, twn, out);
+    }
+    static constexpr CompOps ops() { return CompOps{PL::N, int(Q), &fwd_sub, &fwd_post, &corr, &fill_twn, &comb}; }
 };
 }  // namespace
 

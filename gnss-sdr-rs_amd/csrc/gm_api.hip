@@ -230,6 +230,7 @@ struct gm_acq {
     const gm::CompOps* comp = nullptr;     // Q > 1: the (Q, base plan) kernels
     cf* d_comp_tmp = nullptr;              // [max(D*M, P)][Q][Nb]: forward sub-transforms before the Q-point DFTs
     cf* d_comp_twn = nullptr;              // [Q][Nb] inverse twiddles W_N^{-n1 k2}, paired positions
+    cf* d_code_comb = nullptr;             // Q > 1: [P][Q][Q][Nb] conj(code) x W_Q^{-n1 k1} x W_N^{-n1 k2}, what comp corr multiplies the spectra by
     // fine Doppler (gm_acq_finer_doppler): host copy of the chip rows, lazily built device state
     std::vector<int8_t> chips;             // [P][code_len]
     uint32_t code_len = 1023;
@@ -477,7 +478,7 @@ int gm_rfft_f32(size_t n, const float* in, gm_c32* out) {
 int gm_acq_destroy(gm_acq* a) {
     if (!a) return GM_OK;
     if (a->device >= 0) hipSetDevice(a->device);
-    hipFree(a->d_comp_tmp); hipFree(a->d_comp_twn); hipFree(a->d_split_scratch); hipFree(a->d_split_counter);
+    hipFree(a->d_comp_tmp); hipFree(a->d_comp_twn); hipFree(a->d_code_comb); hipFree(a->d_split_scratch); hipFree(a->d_split_counter);
     hipFree(a->fine.d_chips); hipFree(a->fine.d_tw1); hipFree(a->fine.d_tw2); hipFree(a->fine.d_B); hipFree(a->fine.d_mean);
     hipFree(a->fine.d_rowmax); hipFree(a->fine.d_rowarg); hipFree(a->fine.d_sat_worker); hipFree(a->fine.d_sat_cp);
     hipFree(a->fine.d_peak_pow); hipFree(a->fine.d_peak_idx);
@@ -608,6 +609,8 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
         comp->fwd_sub(a->stream, nullptr, GM_FMT_C32, nullptr, a->d_code_samples, a->d_tw_fwd, a->d_comp_tmp, uint32_t(P), 1);
         comp->fwd_post(a->stream, a->d_comp_tmp, a->d_code_fft, uint32_t(P), 0);
         pl->pair_codes(a->stream, a->d_code_fft, a->d_code_fft_paired, int(P * a->Q));
+        HIPA(hipMalloc(&a->d_code_comb, P * a->Q * N * 8));      // [code][n1][k1][pos]: the whole code-side factor per sub-transform
+        comp->comb(a->stream, a->d_code_fft_paired, a->d_comp_twn, a->d_code_comb, uint32_t(P));
     }
     HIPA(hipGetLastError());
     HIPA(hipStreamSynchronize(a->stream));
@@ -655,7 +658,7 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
                       reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M),
                       a->d_split_scratch, a->d_split_counter, a->cfg.strict_sum_order ? 1 : 0);
     } else if (a->n_workers) {
-        a->comp->corr(a->stream, a->d_spectra, a->d_code_fft_paired, a->d_comp_twn, a->d_tw_inv, reinterpret_cast<float*>(met),
+        a->comp->corr(a->stream, a->d_spectra, a->d_code_comb, a->d_comp_twn, a->d_tw_inv, reinterpret_cast<float*>(met),
                       met + PD, reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M));
     }
     if (t) { HIPC(hipEventRecord(ev[2], a->stream)); a->tm.count++; a->tm.decide_valid = false; }

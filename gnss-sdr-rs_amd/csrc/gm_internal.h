@@ -80,6 +80,9 @@ struct CompOps {
     void (*corr)(hipStream_t, const cf* spectra, const cf* code_paired, const cf* twn, const cf* tw_inv, float* mmax,
                  uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int);
     void (*fill_twn)(cf* out);   // host: [q][nb] inverse twiddles W_N^{-n1 k2} in the paired position of k2
+    // once per handle: comb[p][n1][k1][pos] = conj(code_paired[p][k1][pos]) * W_Q^{-n1 k1} * twn[n1][pos], the whole code-side
+    // factor of sub-transform n1 (the codes are static, so corr multiplies a spectrum value by ONE table entry)
+    void (*comb)(hipStream_t, const cf* code_paired, const cf* twn, cf* comb, uint32_t n_codes);
 };
 const CompOps* find_comp(uint32_t n);
 
