@@ -83,6 +83,41 @@ GM_LIBM_HD float atanf_glibc(float x) {
 }
 
 
+// x / y for a divisor whose correctly rounded reciprocal inv = RN(1/y) is known: q0 = x*inv,
+// q = fma(fma(-q0, y, x), inv, q0) is the correctly rounded quotient (Markstein) while the quotient stays in the normal
+// range and y's significand is not all ones.  Used where the divisor is a configuration constant (fs, the code length,
+// 2*pi) and the dividend a sample count, a code rate or an angle; tests/cpu/test_libm.cpp compares it with IEEE division
+// on 2.6e8 operands (21 sample rates, 5 code lengths, 2*pi), bit for bit.
+GM_LIBM_HD float div_const(float x, float y, float inv) {
+    const float q0 = x * inv;
+    return __builtin_fmaf(__builtin_fmaf(-q0, y, x), inv, q0);
+}
+
+// fmodf(x, y) for a positive constant y with inv = RN(1/y); exact, as fmodf is (the remainder is representable, so every
+// correct algorithm returns the same bits).  For y <= |x| < 4096 y: q = rint(|x| * inv) is the integer quotient or one
+// more, r = fma(-q, y, |x|) is exact (a multiple of ulp(y) of magnitude below y), one conditional + y brings it into [0, y),
+// and the sign is x's.  Outside that range (and for inf / NaN): the library's fmodf.  (The library form is ~35 instructions
+// with frexp/ldexp and three branches on the device; this is 9.)  tests/cpu/test_libm.cpp: equal to fmodf on 1.6e8 operands.
+GM_LIBM_HD float fmod_bounded(float x, float y, float inv) {
+    const float ax = __builtin_fabsf(x);
+    if (!(ax < 4096.0f * y)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // y through a scalar register, opaque: keeps the library form's loop-invariant set-up inside this (rare) branch
+        // instead of in VGPRs for the whole kernel
+        uint32_t u = __builtin_amdgcn_readfirstlane(f32_bits(y));
+        asm volatile("" : "+s"(u));
+        return fmodf(x, f32_from_bits(u));
+#else
+        return __builtin_fmodf(x, y);
+#endif
+    }
+    const float q = __builtin_rintf(ax * inv);
+    float r = __builtin_fmaf(-q, y, ax);
+    r = r < 0.0f ? r + y : r;
+    r = ax < y ? ax : r;
+    return __builtin_copysignf(r, x);
+}
+
 // sin and cos of an f32 phase of moderate size (|x| < 1.3e5 rad: k = rint(x * 2/pi) < 2^17), for the carrier wipe-off of the
 // tracking correlators (do_tracking.rs:243-246 calls f32::cos / f32::sin = glibc's cosf / sinf, < 1 ulp, not correctly
 // rounded).  Cody-Waite reduction in f32 with the first product split exactly: k*c1 = ph + pl (one multiply, one fma),

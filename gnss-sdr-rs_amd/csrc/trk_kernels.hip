@@ -75,21 +75,6 @@ template <bool FAST> __device__ __forceinline__ float fmod_code(float t, float l
     } else return fmodf(t, len);
 }
 
-// fmodf(x, y) for a positive constant y with inv = RN(1/y); exact, as fmodf is (the remainder is representable, so every
-// correct algorithm returns the same bits).  For y <= |x| < 4096 y: q = rint(|x| * inv) is the integer quotient or one
-// more, r = fma(-q, y, |x|) is exact (a multiple of ulp(y) of magnitude below y), one conditional + y brings it into [0, y),
-// and the sign is x's.  Outside that range (and for inf / NaN): the library's fmodf.  (The library form is ~35 instructions
-// with frexp/ldexp and three branches; this is 9.)
-__device__ __forceinline__ float fmod_bounded(float x, float y, float inv) {
-    const float ax = fabsf(x);
-    if (!(ax < 4096.0f * y)) return fmodf(x, uniform_f32(y));   // (y through a scalar register: keeps the library form's set-up in this branch)
-    const float q = rintf(ax * inv);
-    float r = __builtin_fmaf(-q, y, ax);
-    r = r < 0.0f ? r + y : r;
-    r = ax < y ? ax : r;
-    return copysignf(r, x);
-}
-
 // get_ca_chip's index (:275): `(phase.floor() as usize) % 1023` — the cast saturates, so a negative
 // phase (late arm just after the code wraps) reads chip 0 in FAITHFUL mode; FIXED mode wraps.
 // phase = chip_idx +- spacing with |chip_idx| < len and spacing < len (checked at gm_trk_create), so
@@ -113,14 +98,7 @@ __device__ __forceinline__ float loop_filter_update(float dt_over_tau1, float ta
     return d_err * dt_over_tau1 + (d_err - err) * tau2_over_tau1;
 }
 
-// x / y for a divisor whose correctly rounded reciprocal inv = RN(1/y) is known: q0 = x*inv,
-// q = fma(fma(-q0, y, x), inv, q0) is the correctly rounded quotient (Markstein) while the quotient stays in the normal
-// range and y's significand is not all ones — checked against IEEE division on 3.6e8 operands per divisor (code
-// lengths, 21 sample rates).  Used only where the dividend is a sample count or a code rate (0 or ~1e3..1e8).
-__device__ __forceinline__ float div_const(float x, float y, float inv) {
-    const float q0 = x * inv;
-    return __builtin_fmaf(__builtin_fmaf(-q0, y, x), inv, q0);
-}
+// (div_const and fmod_bounded: gm_libm.h, host/device portable and checked on the CPU by tests/cpu/test_libm.cpp)
 
 // generate_ca_code_samples(..).len() = round(fs / (code_rate / len))  (ca_code.rs:13-16)
 __device__ __forceinline__ uint64_t samples_per_code(float fs, float code_rate, float lenf) {

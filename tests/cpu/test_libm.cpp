@@ -23,6 +23,61 @@ int main() {
         ++n;
     }
     printf("atanf_glibc: %llu arguments, %llu mismatches\n", n, bad);
+    // div_const against IEEE division: divisors = the sample rates / code lengths / 2*pi the library divides by; dividends =
+    // sample counts, code rates, angles (a deterministic LCG walk over their ranges)
+    {
+        const float divisors[] = {2.0e6f, 2.046e6f, 2.048e6f, 4.0e6f, 4.092e6f, 4.096e6f, 5.0e6f, 5.456e6f, 6.0e6f, 8.0e6f, 8.184e6f,
+                                  8.192e6f, 1.0e7f, 1.2e7f, 1.5e7f, 1.6e7f, 1.6368e7f, 1.63676e7f, 2.5e7f, 3.8192e7f, 5.0e7f,
+                                  1023.0f, 2046.0f, 4092.0f, 10230.0f, 511.0f, 6.28318530717958647692f};
+        unsigned long long nd = 0, badd = 0;
+        unsigned long long st = 0x9E3779B97F4A7C15ull;
+        for (float y : divisors) {
+            const float inv = 1.0f / y;
+            for (int i = 0; i < 10000000; ++i) {
+                st = st * 6364136223846793005ull + 1442695040888963407ull;
+                const unsigned r = unsigned(st >> 33);
+                float x;
+                switch (i & 3) {
+                    case 0: x = float(r % 300001u); break;                                  // sample counts
+                    case 1: x = 1.0e6f + float(r % 100000u) * 0.5f; break;                  // code rates around 1.023 / 2.046 / 10.23 Mcps
+                    case 2: x = gm::f32_from_bits(0x3f800000u + (r % 0x0c000000u)); break;  // 1 .. 1e7, every exponent
+                    default: x = -3.2f + float(r % 6400001u) * 1.0e-6f; break;              // angles (atan's range, both signs)
+                }
+                const float a = gm::div_const(x, y, inv), b = x / y;
+                const bool same = gm::f32_bits(a) == gm::f32_bits(b) || (a == 0.0f && b == 0.0f);   // only a zero's sign may differ
+                if (!same && badd++ < 10) printf("div_const MISMATCH x=%a y=%a ours=%a ieee=%a\n", x, y, a, b);
+                ++nd;
+            }
+        }
+        printf("div_const: %llu operands, %llu mismatches\n", nd, badd);
+        bad += badd;
+    }
+    // fmod_bounded against fmodf: y in {2*pi, code lengths}, x over (-4200 y, 4200 y) incl. the fallback range, both signs
+    {
+        const float ys[] = {6.28318530717958647692f, 1023.0f, 2046.0f, 4092.0f, 10230.0f, 511.0f};
+        unsigned long long nf = 0, badf = 0;
+        unsigned long long st = 0xD1B54A32D192ED03ull;
+        for (float y : ys) {
+            const float inv = 1.0f / y;
+            for (int i = 0; i < 26000000; ++i) {
+                st = st * 6364136223846793005ull + 1442695040888963407ull;
+                const unsigned r = unsigned(st >> 32);
+                float x;
+                switch (i & 3) {
+                    case 0: x = (float(r) * (1.0f / 4294967296.0f) * 2.0f - 1.0f) * 4200.0f * y; break;    // the whole admitted range and a little beyond
+                    case 1: x = (float(r) * (1.0f / 4294967296.0f) * 2.0f - 1.0f) * 3.0f * y; break;       // the operating range (a few periods)
+                    case 2: x = float(int(r % 8001u) - 4000) * y + (float(r >> 13) * (1.0f / 524288.0f) - 0.5f) * 1.0e-3f * y; break;   // around multiples of y
+                    default: x = gm::f32_from_bits(r); break;                                             // any bit pattern (inf, NaN, denormals)
+                }
+                const float a = gm::fmod_bounded(x, y, inv), b = fmodf(x, y);
+                const bool same = gm::f32_bits(a) == gm::f32_bits(b) || (a != a && b != b);
+                if (!same && badf++ < 10) printf("fmod_bounded MISMATCH x=%a y=%a ours=%a libm=%a\n", x, y, a, b);
+                ++nf;
+            }
+        }
+        printf("fmod_bounded: %llu operands, %llu mismatches\n", nf, badf);
+        bad += badf;
+    }
     // sincos_cw against the f64 functions of the same f32 argument: |x| <= 131072 (the fast path admits 1e5), 2^25 arguments
     double worst = 0.0;
     unsigned long long ns = 0, lastbit = 0;
