@@ -143,10 +143,12 @@ GM_LIBM_HD void sincos_cw(float x, float& s, float& c) {
     float cp = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
     cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);
     const float cr = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
-    const int q = int(k) & 3;
-    const float sv = (q & 1) ? cr : sr, cv = (q & 1) ? sr : cr;
-    s = (q & 2) ? -sv : sv;
-    c = ((q + 1) & 2) ? -cv : cv;
+    // quadrant: swap on odd k, then the signs as bit flips (bit 1 of k for sin, of k + 1 for cos) — integer operations
+    // issue at the full rate on gfx950, compares and selects at half
+    const uint32_t q = uint32_t(int(k));
+    const float sv = (q & 1u) ? cr : sr, cv = (q & 1u) ? sr : cr;
+    s = f32_from_bits(f32_bits(sv) ^ ((q << 30) & 0x80000000u));
+    c = f32_from_bits(f32_bits(cv) ^ (((q + 1u) << 30) & 0x80000000u));
 }
 
 }  // namespace gm

@@ -280,6 +280,110 @@ __device__ __forceinline__ void correlate_sample_fast(const EpochConsts& c, cons
     }
 }
 
+// NB samples of one lane at once, written "structure of arrays": every step of correlate_sample_fast is applied to all NB
+// samples before the next step, in three stages fenced against the instruction scheduler — (1) code phases -> chip
+// addresses -> ALL the LDS look-ups issued; (2) the carrier phases and their sin/cos (gm_libm.h's sincos_cw, the same
+// operations in the same order per sample), whose ~40 dependent instructions per sample now interleave NB ways and cover
+// the look-ups' latency; (3) products into the sums.  Calling correlate_sample_fast NB times in a row left it to the
+// scheduler, which kept the samples one after another (least registers): a wave then issued one DEPENDENT instruction per
+// ~8 cycles and sat out an LDS round trip per sample.  Values are bit-identical to the one-sample form.
+template <int ARMS, int BOC_T, int NB>
+__device__ __forceinline__ void correlate_block_fast(const EpochConsts& c, const float* tab, const cf (&d)[NB], const float (&f)[NB],
+                                                     float (&acc0)[2 * ARMS], float (&acc1)[2 * ARMS]) {
+    // ---- stage 1: chips
+    float chip_idx[NB], pc[NB], ec[NB], lc[NB], vec[NB], vlc[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const float t = c.code_phase + f[k] * c.step;
+        const uint32_t ua = __float_as_uint(t), ub = __float_as_uint(t - c.lenf), uc = __float_as_uint(t - 2.0f * c.lenf);
+        chip_idx[k] = __uint_as_float(min(min(ua, ub), uc));
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        pc[k] = tab[floor_i32(chip_idx[k]) + 1];
+        ec[k] = tab[floor_i32(chip_idx[k] + c.el) + 1];
+        lc[k] = tab[floor_i32(chip_idx[k] - c.el) + 1];
+        if constexpr (ARMS == 5) {
+            vec[k] = tab[floor_i32(chip_idx[k] + c.vel) + 1];
+            vlc[k] = tab[floor_i32(chip_idx[k] - c.vel) + 1];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- stage 2: carrier wipe-off.  phase = carrier_phase + ((2 pi f) * i) / fs (:233); sincos_cw step by step
+    float r[NB], kq[NB], xr[NB], xi[NB];
+    {
+        const float c1 = f32_from_bits(0x3fc90fdbu), c2 = f32_from_bits(0xb33bbd2eu);
+        float w[NB], q0[NB], ph[NB], pl[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) w[k] = c.two_pi_f * f[k];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) q0[k] = w[k] * c.inv_fs;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) w[k] = __builtin_fmaf(-q0[k], c.fs, w[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) q0[k] = __builtin_fmaf(w[k], c.inv_fs, q0[k]);       // div_by_fs
+#pragma unroll
+        for (int k = 0; k < NB; ++k) w[k] = c.carrier_phase + q0[k];                        // the phase x
+#pragma unroll
+        for (int k = 0; k < NB; ++k) kq[k] = __builtin_rintf(w[k] * 0.636619747f);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) ph[k] = kq[k] * c1;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) pl[k] = __builtin_fmaf(kq[k], c1, -ph[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) w[k] = w[k] - ph[k];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) pl[k] = __builtin_fmaf(kq[k], c2, pl[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) r[k] = w[k] - pl[k];
+    }
+    {
+        float z[NB], sp[NB], cp[NB], sr[NB], cr[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) z[k] = r[k] * r[k];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { sp[k] = __builtin_fmaf(-1.9515295891e-4f, z[k], 8.3321608736e-3f); cp[k] = __builtin_fmaf(2.443315711809948e-5f, z[k], -1.388731625493765e-3f); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { sp[k] = __builtin_fmaf(sp[k], z[k], -1.6666654611e-1f); cp[k] = __builtin_fmaf(cp[k], z[k], 4.166664568298827e-2f); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { sp[k] = sp[k] * z[k]; cp[k] = cp[k] * z[k]; cr[k] = __builtin_fmaf(-0.5f, z[k], 1.0f); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { sr[k] = __builtin_fmaf(sp[k], r[k], r[k]); cr[k] = __builtin_fmaf(cp[k], z[k], cr[k]); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const uint32_t q = uint32_t(int(kq[k]));
+            const float sv = (q & 1u) ? cr[k] : sr[k], cv = (q & 1u) ? sr[k] : cr[k];
+            const float sn = __uint_as_float(__float_as_uint(sv) ^ ((q << 30) & 0x80000000u));
+            const float cs = __uint_as_float(__float_as_uint(cv) ^ (((q + 1u) << 30) & 0x80000000u));
+            const float wc = cs, ws = -sn;                          // Complex32::new(cos_p, -sin)
+            xr[k] = d[k].x * wc - d[k].y * ws;                      // num-complex Mul
+            xi[k] = d[k].x * ws + d[k].y * wc;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- stage 3: sums (chips are exactly +-1 x BOC sign: the product is exact, fma(x, chip, acc) == acc + x*chip bitwise)
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        if (BOC_T) {   // BOC(1,1): sub-carrier sign = +1 on the first half chip, -1 on the second (fract = x - floor(x))
+            pc[k] = __builtin_amdgcn_fractf(chip_idx[k]) < 0.5f ? pc[k] : -pc[k];
+            ec[k] = __builtin_amdgcn_fractf(chip_idx[k] + c.el) < 0.5f ? ec[k] : -ec[k];
+            lc[k] = __builtin_amdgcn_fractf(chip_idx[k] - c.el) < 0.5f ? lc[k] : -lc[k];
+            if constexpr (ARMS == 5) {
+                vec[k] = __builtin_amdgcn_fractf(chip_idx[k] + c.vel) < 0.5f ? vec[k] : -vec[k];
+                vlc[k] = __builtin_amdgcn_fractf(chip_idx[k] - c.vel) < 0.5f ? vlc[k] : -vlc[k];
+            }
+        }
+        float (&acc)[2 * ARMS] = (k & 1) ? acc1 : acc0;      // even samples of the block into one set of sums, odd into the other
+        acc[0] = __builtin_fmaf(xr[k], pc[k], acc[0]); acc[1] = __builtin_fmaf(xi[k], pc[k], acc[1]);
+        acc[2] = __builtin_fmaf(xr[k], ec[k], acc[2]); acc[3] = __builtin_fmaf(xi[k], ec[k], acc[3]);
+        acc[4] = __builtin_fmaf(xr[k], lc[k], acc[4]); acc[5] = __builtin_fmaf(xi[k], lc[k], acc[5]);
+        if constexpr (ARMS == 5) {
+            acc[6] = __builtin_fmaf(xr[k], vec[k], acc[6]); acc[7] = __builtin_fmaf(xi[k], vec[k], acc[7]);
+            acc[8] = __builtin_fmaf(xr[k], vlc[k], acc[8]); acc[9] = __builtin_fmaf(xi[k], vlc[k], acc[9]);
+        }
+    }
+}
+
 __device__ __forceinline__ int code_row(const TrkDevCfg& cfg, const gm_trk_state& st) {
     // FAITHFUL indexes GPS_CA_CODE_32_PRN[prn] (:276), FIXED [prn-1]
     return cfg.gps_ca ? (cfg.code_index_mode == GM_CODE_INDEX_FAITHFUL ? int(st.prn) : int(st.prn) - 1)
@@ -756,68 +860,40 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 const cf zero = cf_make(0.0f, 0.0f);
                 const float fb0 = float(b0);                             // sample indices as floats: exact below 2^24
                 constexpr float TF = float(T);
-                // interleave width: four chains with three arms; two with five (ten accumulators per chain: four chains spill)
+                // block width: four samples with three arms; two with five (ten accumulators per sample: four spill)
                 constexpr uint32_t IL = ARMS == 3 ? 4 : 2;
-                if constexpr (IL == 4) {
-                    float acc3[NV], acc4[NV];
+                for (uint32_t j = 0; j < wtot; j += IL) {                // the first block(s) come from the prefetched registers
+                    const uint32_t left = wtot - j;
+                    cf dd[IL];
+                    float ff[IL];
 #pragma unroll
-                    for (int k = 0; k < NV; ++k) { acc3[k] = 0.0f; acc4[k] = 0.0f; }
-                    for (uint32_t j = 0; j < wtot; j += 4) {             // the first block comes from the prefetched registers
-                        const uint32_t left = wtot - j;
-                        cf d0 = zero, d1 = zero, d2 = zero, d3 = zero;
-                        if (j == 0) {
-                            if (tot > 0) d0 = pf0;
-                            if (tot > 1) d1 = pf1;
-                            if (tot > 2) d2 = pf2;
-                            if (tot > 3) d3 = pf3;
-                        } else {
-                            if (j < tot) d0 = a.ring[(win + b0 + j * T) & a.mask];
-                            if (j + 1 < tot) d1 = a.ring[(win + b0 + (j + 1) * T) & a.mask];
-                            if (j + 2 < tot) d2 = a.ring[(win + b0 + (j + 2) * T) & a.mask];
-                            if (j + 3 < tot) d3 = a.ring[(win + b0 + (j + 3) * T) & a.mask];
+                    for (uint32_t q = 0; q < IL; ++q) dd[q] = zero;
+                    if (j == 0) {
+                        if (tot > 0) dd[0] = pf0;
+                        if (tot > 1) dd[1] = pf1;
+                        if constexpr (IL == 4) {
+                            if (tot > 2) dd[2] = pf2;
+                            if (tot > 3) dd[3] = pf3;
                         }
-                        const float f0 = fb0 + float(j * T), f1 = f0 + TF, f2 = f0 + 2.0f * TF, f3 = f0 + 3.0f * TF;
-                        // one basic block per block size, so that the chains really are interleaved
-                        if (left >= 4) {
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d1, f1, acc2);
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d2, f2, acc3);
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d3, f3, acc4);
-                        } else if (left == 3) {
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d1, f1, acc2);
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d2, f2, acc3);
-                        } else if (left == 2) {
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d1, f1, acc2);
-                        } else {
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
-                        }
-                    }
+                    } else if (IL == 2 && j == 2) {
+                        if (tot > 2) dd[0] = pf2;
+                        if (tot > 3) dd[1] = pf3;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < NV; ++k) { acc[k] = acc[k] + acc3[k]; acc2[k] = acc2[k] + acc4[k]; }
-                } else {
-                    for (uint32_t j = 0; j < wtot; j += 2) {
-                        const uint32_t left = wtot - j;
-                        cf d0 = zero, d1 = zero;
-                        if (j == 0) {
-                            if (tot > 0) d0 = pf0;
-                            if (tot > 1) d1 = pf1;
-                        } else if (j == 2) {
-                            if (tot > 2) d0 = pf2;
-                            if (tot > 3) d1 = pf3;
-                        } else {
-                            if (j < tot) d0 = a.ring[(win + b0 + j * T) & a.mask];
-                            if (j + 1 < tot) d1 = a.ring[(win + b0 + (j + 1) * T) & a.mask];
-                        }
-                        const float f0 = fb0 + float(j * T), f1 = f0 + TF;
-                        if (left >= 2) {
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d1, f1, acc2);
-                        } else {
-                            correlate_sample_fast<ARMS, BOC_T>(ec, chips, d0, f0, acc);
-                        }
+                        for (uint32_t q = 0; q < IL; ++q)
+                            if (j + q < tot) dd[q] = a.ring[(win + b0 + (j + q) * T) & a.mask];
                     }
+                    ff[0] = fb0 + float(j * T);
+#pragma unroll
+                    for (uint32_t q = 1; q < IL; ++q) ff[q] = ff[0] + float(q) * TF;
+                    // one instantiation per block size; a slot beyond the wave's count (left < IL) is not computed at all
+                    if (left >= IL) correlate_block_fast<ARMS, BOC_T, IL>(ec, chips, dd, ff, acc, acc2);
+                    else if (IL == 4 && left == 3)
+                        correlate_block_fast<ARMS, BOC_T, 3>(ec, chips, reinterpret_cast<const cf(&)[3]>(dd), reinterpret_cast<const float(&)[3]>(ff), acc, acc2);
+                    else if (IL == 4 && left == 2)
+                        correlate_block_fast<ARMS, BOC_T, 2>(ec, chips, reinterpret_cast<const cf(&)[2]>(dd), reinterpret_cast<const float(&)[2]>(ff), acc, acc2);
+                    else
+                        correlate_block_fast<ARMS, BOC_T, 1>(ec, chips, reinterpret_cast<const cf(&)[1]>(dd), reinterpret_cast<const float(&)[1]>(ff), acc, acc2);
                 }
             } else {   // out-of-family state (e.g. set by the caller): general fmodf, no prefetch use
                 for (uint32_t i = i0 + tid; i < i1; i += T)
