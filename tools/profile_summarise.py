@@ -17,6 +17,26 @@ stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursi
 shutil.copy(stats[0], os.path.join(dst, f"{rr}_bench_kernel_stats.csv"))
 
 
+def by_grid():
+    """Per (kernel, grid size) launch count and average duration from the --stats pass's per-dispatch trace: bench.py's
+    other legs launch acq_corr_kernel<Plan8000> too (the GPS family of the cfg4 grid, one-PRN searches), so the plain
+    --stats average of that name mixes shapes; the headline launches are the rows with the headline grid size."""
+    tr = glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True)
+    if not tr:
+        return
+    acc = {}
+    for row in csv.DictReader(open(tr[0])):
+        k = (short(row["Kernel_Name"]), int(row["Grid_Size_X"]) // max(1, int(row["Workgroup_Size_X"])), int(row["Workgroup_Size_X"]))
+        a = acc.setdefault(k, [0, 0.0, 1e30, 0.0])
+        dt = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        a[0] += 1; a[1] += dt; a[2] = min(a[2], dt); a[3] = max(a[3], dt)
+    with open(os.path.join(dst, f"{rr}_bench_kernel_by_grid.csv"), "w") as f:
+        f.write("kernel,workgroups,workgroup_size,launches,avg_ns,min_ns,max_ns\n")
+        for (k, g, w), (n, t, lo, hi) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            if k.startswith("gm::"):
+                f.write(f"{k},{g},{w},{n},{t / n:.0f},{lo:.0f},{hi:.0f}\n")
+
+
 def short(name):
     m = re.search(r"gm::(?:\(anonymous namespace\)::)?(\w+)", name)
     if not m:
@@ -45,6 +65,7 @@ for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             a[1] += float(row["Counter_Value"])
     out[ctr] = {k: {"launches": n, "avg_counter_KB": v / n} for k, (n, v) in acc.items() if k.startswith("gm::")}
 json.dump(out, open(os.path.join(dst, f"{rr}_pmc_fetch_write.json"), "w"), indent=1)
+by_grid()
 
 
 def kb(ctr, k):
