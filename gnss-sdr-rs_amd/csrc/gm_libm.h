@@ -118,6 +118,22 @@ GM_LIBM_HD float fmod_bounded(float x, float y, float inv) {
     return __builtin_copysignf(r, x);
 }
 
+// The tracking epoch length n = round(fs / (code_rate / len)) (ca_code.rs:13-16 through do_tracking.rs:165-166) changes
+// only when the code rate crosses one of the rates at which the quotient passes a half-integer; between two epochs it
+// almost never does.  spc_rate_bounds gives an interval of rates [lo, hi] that PROVABLY keeps the f32 evaluation at n
+// (n < 2^23): the exact quotient F / r, F = fs * len, lies in [(n - 0.5)(1 + 9e-7), (n + 0.5)(1 - 9e-7)] for every r in
+// the interval (the bounds are formed in f32 with a 2e-6 inward margin against their own < 3e-7 of rounding), and the
+// reference's two correctly rounded divisions move it by < 1.3e-7 relative — so roundf lands on n.  A rate outside the
+// interval proves nothing: the caller then evaluates the definition.  tests/cpu/test_libm.cpp checks the claim on the
+// end points, their float neighbours inside, and random rates, for the library's sample rates and code lengths.
+GM_LIBM_HD void spc_rate_bounds(float fs, float lenf, float n, float& lo, float& hi) {
+    const float F = fs * lenf;
+    lo = div_rn(F, n + 0.5f) * 1.000002f;
+    hi = div_rn(F, n - 0.5f) * 0.999998f;
+}
+// the definition, in the reference's order (f32, two IEEE divisions, round half away from zero)
+GM_LIBM_HD float spc_definition(float fs, float code_rate, float lenf) { return __builtin_roundf(div_rn(fs, div_rn(code_rate, lenf))); }
+
 // sin and cos of an f32 phase of moderate size (|x| < 1.3e5 rad: k = rint(x * 2/pi) < 2^17), for the carrier wipe-off of the
 // tracking correlators (do_tracking.rs:243-246 calls f32::cos / f32::sin = glibc's cosf / sinf, < 1 ulp, not correctly
 // rounded).  Cody-Waite reduction in f32 with the first product split exactly: k*c1 = ph + pl (one multiply, one fma),

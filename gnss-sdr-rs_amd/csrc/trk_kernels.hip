@@ -527,9 +527,12 @@ __device__ __forceinline__ CarrierHalf carrier_half(const TrkDevCfg& cfg, const 
     return o;
 }
 
+// rate_lo / rate_hi: an interval of code rates proven to keep the epoch length at n_stored (gm_libm.h spc_rate_bounds), or an
+// empty one (lo > hi): inside it the two divisions and the rounding of the definition are skipped
 template <int ARMS>
 __device__ __forceinline__ CodeHalf code_half(const TrkDevCfg& cfg, const gm_trk_state& s, const float (&v)[2 * ARMS], uint64_t n,
-                                              uint64_t n_stored, int mode, const float* pre_phase = nullptr) {
+                                              uint64_t n_stored, int mode, const float* pre_phase = nullptr,
+                                              float rate_lo = 1.0f, float rate_hi = 0.0f) {
     CodeHalf o;
     o.num_samples_per_code = n_stored; o.code_error = s.code_error; o.code_nco = s.code_nco; o.code_rate = s.code_rate;
     const float nf = float(n);
@@ -550,7 +553,8 @@ __device__ __forceinline__ CodeHalf code_half(const TrkDevCfg& cfg, const gm_trk
         o.code_phase = 0.f; o.code_error = 0.f; o.code_nco = 0.f; o.code_rate = 0.f;
         return o;
     }
-    o.num_samples_per_code = samples_per_code(cfg, o.code_rate);
+    if (o.code_rate >= rate_lo && o.code_rate <= rate_hi) o.num_samples_per_code = n_stored;     // (false for NaN and for the empty interval)
+    else o.num_samples_per_code = samples_per_code(cfg, o.code_rate);
     return o;
 }
 
@@ -768,7 +772,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     __shared__ float wsum[NW][NV];
     __shared__ EpochShared sh;          // wave 0 -> everyone, once per epoch
     __shared__ int ctl;                 // 0 continue, 1 exchange timed out
-    __shared__ float pre_phase[2];      // the carrier / code phase the coming state will hold (waves 2 / 3, every epoch)
+    __shared__ float pre_phase[4];      // the carrier / code phase the coming state will hold, and the code-rate interval that keeps n (waves 2 / 3, every epoch)
     // The channel state between epochs: wave 0's copy (it owns the carrier fields and the bookkeeping) and wave 1's (code
     // fields).  Parked in LDS rather than in registers while the workgroup correlates: held in registers it put the hot loop
     // over the 128-VGPR budget of two workgroups per CU, and the spilled values came back through scratch memory in the
@@ -915,7 +919,11 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 if (lane == 0) pre_phase[0] = ph;
             } else if (wave == 3) {
                 const float ph = advance_code_phase(cfg, ec.code_phase, ec.step, float(n));
-                if (lane == 0) pre_phase[1] = ph;
+                // ... and the code rates for which the NEXT epoch provably keeps this epoch's length n (the rate moves by
+                // parts in 1e7 per epoch; the length changes when it crosses a half-integer quotient)
+                float rlo = 1.0f, rhi = 0.0f;
+                if (n < (1u << 23)) spc_rate_bounds(cfg.fs, cfg.code_len_f, float(n), rlo, rhi);
+                if (lane == 0) { pre_phase[1] = ph; pre_phase[2] = rlo; pre_phase[3] = rhi; }
             }
 #pragma unroll
             for (int k = 0; k < NV; ++k) acc[k] += acc2[k];
@@ -1059,6 +1067,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     for (int k = 0; k < NV; ++k) v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tk), k));
                 }
                 if (st_on) stp[5] = stamp_now();
+                if (st1_on) stp[43] = stamp_now();
                 if (wave == 0) {          // ---- carrier half + the bookkeeping (do_work :183-210, run_loop_filters' PLL :279-290)
                     uint8_t lst = 0, lprn = 0;
                     if (!to) {
@@ -1094,7 +1103,8 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     if (!to) {
                         st.num_samples_per_code = n;                 // update() stores the length it used (:166)
                         const CommonHalf c = common_half(cfg, st, v[0], v[1], n, TRK_MODE_DO_WORK);
-                        const CodeHalf h = code_half<ARMS>(cfg, st, v, n, n, TRK_MODE_DO_WORK, &pre_phase[1]);
+                        if (st1_on) stp[44] = stamp_now();
+                        const CodeHalf h = code_half<ARMS>(cfg, st, v, n, n, TRK_MODE_DO_WORK, &pre_phase[1], pre_phase[2], pre_phase[3]);
                         st.prn = c.prn; st.active = c.active; st.lost_counter = c.lost_counter; st.next_sample_index = c.next_sample_index;
                         st.num_samples_per_code = h.num_samples_per_code; st.code_phase = h.code_phase; st.code_error = h.code_error;
                         st.code_nco = h.code_nco; st.code_rate = h.code_rate;

@@ -78,6 +78,39 @@ int main() {
         printf("fmod_bounded: %llu operands, %llu mismatches\n", nf, badf);
         bad += badf;
     }
+    // spc_rate_bounds: every rate inside the interval must give n by the definition
+    {
+        const float fss[] = {2.048e6f, 4.0e6f, 4.096e6f, 5.0e6f, 8.0e6f, 1.0e7f, 1.6368e7f, 1.63676e7f, 2.5e7f, 3.8192e7f, 5.0e7f};
+        const struct { float len, rate; } codes[] = {{1023.0f, 1.023e6f}, {2046.0f, 2.046e6f}, {4092.0f, 1.023e6f}, {10230.0f, 1.023e7f}};
+        unsigned long long ns = 0, bads = 0, empty = 0;
+        unsigned long long st = 0xA0761D6478BD642Full;
+        for (float fs : fss)
+            for (auto cd : codes) {
+                const float n0 = gm::spc_definition(fs, cd.rate, cd.len);
+                for (int dn = -40; dn <= 40; ++dn) {
+                    const float n = n0 + float(dn);
+                    if (!(n >= 2.0f && n < 8388608.0f)) continue;
+                    float lo, hi;
+                    gm::spc_rate_bounds(fs, cd.len, n, lo, hi);
+                    if (!(lo <= hi)) { ++empty; continue; }       // (n so large that the margins meet: the caller falls back)
+                    auto check = [&](float r) {
+                        if (r < lo || r > hi) return;
+                        ++ns;
+                        if (gm::spc_definition(fs, r, cd.len) != n && bads++ < 10)
+                            printf("spc_rate_bounds MISMATCH fs=%a len=%a n=%a rate=%a lo=%a hi=%a -> %a\n", fs, cd.len, n, r, lo, hi,
+                                   gm::spc_definition(fs, r, cd.len));
+                    };
+                    check(lo); check(hi);
+                    for (int k = 1; k <= 64; ++k) { check(gm::f32_from_bits(gm::f32_bits(lo) + k)); check(gm::f32_from_bits(gm::f32_bits(hi) - k)); }
+                    for (int i = 0; i < 2000; ++i) {
+                        st = st * 6364136223846793005ull + 1442695040888963407ull;
+                        check(lo + (hi - lo) * (float(unsigned(st >> 40)) * (1.0f / 16777216.0f)));
+                    }
+                }
+            }
+        printf("spc_rate_bounds: %llu rates inside their intervals, %llu mismatches (%llu empty intervals)\n", ns, bads, empty);
+        bad += bads;
+    }
     // sincos_cw against the f64 functions of the same f32 argument: |x| <= 131072 (the fast path admits 1e5), 2^25 arguments
     double worst = 0.0;
     unsigned long long ns = 0, lastbit = 0;

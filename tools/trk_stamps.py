@@ -26,3 +26,5 @@ w1 = buf[5:, 40:43] - buf[5:, 2:3]      # wave 1 of the serial section, relative
 print('wave 1 (code half) after the barrier: gathered %d, half done %d, next-epoch constants %d   | wave 0: gathered %d, half done %d, constants+outs %d' % (
     np.median(w1[:, 0]), np.median(w1[:, 1]), np.median(w1[:, 2]),
     np.median(buf[5:, 4] - buf[5:, 2]), np.median(buf[5:, 6] - buf[5:, 2]), np.median(buf[5:, 7] - buf[5:, 2])))
+w1b = buf[5:, 43:45] - buf[5:, 2:3]
+print('wave 1 detail: totals done %d, bookkeeping done %d' % (np.median(w1b[:, 0]), np.median(w1b[:, 1])))
