@@ -28,11 +28,16 @@ template <class PL>
 __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restrict__ samples, int fmt,
                                                             const cf* __restrict__ tables,
                                                             const cf* __restrict__ tw_fwd,
-                                                            cf* __restrict__ spectra, int n_int) {
+                                                            cf* __restrict__ spectra, int n_int,
+                                                            uint32_t* __restrict__ clear_tickets) {
     __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
     const int d = blockIdx.x / n_int, m = blockIdx.x % n_int;
+    // the ticket counters of the correlation kernel's tail split start every dwell at zero (a launch that died half-way must
+    // not leave tickets behind): cleared here, one kernel ahead on the same stream, instead of by a memset launch of their own
+    if (clear_tickets && blockIdx.x == 0)
+        for (int i = tid; i < GM_CORR_SPLIT_MAX_ITEMS; i += PL::T) clear_tickets[i] = 0u;
     load_twiddles<PL>(tw, tw_fwd, tid);
     const size_t sbase = size_t(m) * PL::N;
     const cf* tab = tables + size_t(d) * PL::N;
@@ -516,14 +521,14 @@ template <class PL> struct Launch {
         fill_twiddles<PL>(tw, inverse, [](double a) { return ::cos(a); }, [](double a) { return ::sin(a); });
     }
     static void mix_fft(hipStream_t st, const void* samples, int fmt, const cf* tables, const cf* tw_fwd,
-                        cf* spectra, int n_bins, int n_int) {
+                        cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets) {
         hipLaunchKernelGGL(acq_mix_fft_kernel<PL>, dim3(n_bins * n_int), dim3(PL::T), 0, st, samples, fmt,
-                           tables, tw_fwd, spectra, n_int);
+                           tables, tw_fwd, spectra, n_int, clear_tickets);
     }
     static constexpr int SPLIT_SLAB = (PL::RL % 4 == 0) ? PL::ITL * PL::RL * PL::T : 0;   // floats per partial plane
     static void corr(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
-                     int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum) {
+                     int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum, int tickets_cleared) {
         if (n_workers <= 0) return;
         // Tile map: whole Doppler bins per XCD (best L2 locality) unless that costs an XCD an extra round of
         // workgroups (2 x 32 resident per XCD) compared with equal shares of the item list.  Measured on configs[1]
@@ -567,7 +572,7 @@ template <class PL> struct Launch {
         // the merge tickets start from zero in EVERY launch (a launch that was aborted, or two host threads on one handle,
         // must not leave a count behind that makes a later dwell merge early): the whole ticket block, a multiple of 16 bytes
         // at the start of its allocation (cdna_hip_programming.md G16 "Re-initialise every call")
-        if (split_k > 1) (void)hipMemsetAsync(split_counter, 0, size_t(GM_CORR_SPLIT_MAX_ITEMS) * sizeof(uint32_t), st);
+        if (split_k > 1 && !tickets_cleared) (void)hipMemsetAsync(split_counter, 0, size_t(GM_CORR_SPLIT_MAX_ITEMS) * sizeof(uint32_t), st);
         if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
             hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, true>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,

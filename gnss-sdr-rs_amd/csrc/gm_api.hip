@@ -647,7 +647,7 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     hipEvent_t* ev = t ? &a->tm.ev[size_t(a->tm.count % Timing::CAP) * 4] : nullptr;
     if (t) HIPC(hipEventRecord(ev[0], a->stream));
     if (a->Q == 1) {
-        a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_fwd, a->d_spectra, int(a->D), int(a->M));
+        a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_fwd, a->d_spectra, int(a->D), int(a->M), a->d_split_counter);
     } else {
         a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_fwd, a->d_comp_tmp, a->D * a->M, a->M);
         a->comp->fwd_post(a->stream, a->d_comp_tmp, a->d_spectra, a->D * a->M, 1);
@@ -656,7 +656,7 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     if (a->Q == 1) {
         a->plan->corr(a->stream, a->d_spectra, a->plan->code_paired ? a->d_code_fft_paired : a->d_code_fft, a->d_tw_inv, reinterpret_cast<float*>(met), met + PD,
                       reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M),
-                      a->d_split_scratch, a->d_split_counter, a->cfg.strict_sum_order ? 1 : 0);
+                      a->d_split_scratch, a->d_split_counter, a->cfg.strict_sum_order ? 1 : 0, a->d_split_counter ? 1 : 0);
     } else if (a->n_workers) {
         a->comp->corr(a->stream, a->d_spectra, a->d_code_comb, a->d_comp_twn, a->d_tw_inv, reinterpret_cast<float*>(met),
                       met + PD, reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M));

@@ -34,13 +34,15 @@ struct PlanOps {
     void (*fill_tw)(cf* tw, bool inverse);
     // stage F: carrier mix (apply_doppler_shift, doppler_shift.rs:25-58) fused into the forward FFT
     // (do_acquisition.rs:177-182).  One workgroup per (doppler bin, ms block); shared by all PRNs.
+    // clear_tickets (may be null): the tail split's ticket counters, zeroed by the first workgroup for the corr() launch
+    // that follows on the same stream (saves that launch its own hipMemsetAsync: ~8 us per dwell)
     void (*mix_fft)(hipStream_t, const void* samples, int fmt, const cf* tables, const cf* tw_fwd,
-                    cf* spectra, int n_bins, int n_int);
+                    cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets);
     // stage C (spectra and code_fft in the PAIRED layout): x conj(code spectrum) -> inverse FFT -> |.|^2 accumulated over the integrations ->
     // {max, first argmax, sum} per (worker, bin)  (do_acquisition.rs:184-202, 229-235)
     void (*corr)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                  uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
-                 int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum);
+                 int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum, int tickets_cleared);   // tickets_cleared: mix_fft(.., split_counter) ran just before on this stream
     // AcquisitionWorker::new's replica spectrum (do_acquisition.rs:132-138)
     void (*code_fft)(hipStream_t, const int8_t* code_samples, const cf* tw_fwd, cf* code_fft, int n_codes);
     // the same spectra re-stored in the paired layout stage C reads (PairLayout in acq_kernels.hip); stage F writes its
