@@ -641,6 +641,7 @@ struct TrkPersistArgs {
     gm_trk_state* states;
     const cf* ring; uint64_t mask, head;
     int G, epochs;
+    int force_write_through;         // diagnostic (GM_TRK_FORCE_SC1=1): keep the cross-XCD exchange form even when a channel's workgroups share an XCD
     uint32_t per;                    // samples per workgroup slice (multiple of 64), fixed for the launch
     uint32_t tag_base;               // unique per launch: tag = tag_base + epoch + 1
     unsigned long long* xchg;        // [2][n_channels][G][NV] granules of partials, then [n_channels][G] of XCC_IDs
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                         pend = (xg >> 32) != want;
                         if ((++rounds & 63u) == 0u && wall_clock64() - t0 > 20000000ll) to = true;
                     }
-                    same_xcd = __all(!pend && uint32_t(xg) == my_xcc) != 0;
+                    same_xcd = __all(!pend && uint32_t(xg) == my_xcc) != 0 && !a.force_write_through;
                 }
                 to = __any(to);
                 if (st_on) stp[4] = stamp_now();
@@ -1172,6 +1173,10 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     a.stamps = d_stamps;
     a.cfg = cfg; a.codes = d_codes; a.states = d_states; a.ring = ring; a.mask = mask; a.head = head;
     a.G = G; a.epochs = epochs; a.tag_base = tag_base;
+    {
+        const char* e = getenv("GM_TRK_FORCE_SC1");
+        a.force_write_through = (e && atoi(e) != 0) ? 1 : 0;
+    }
     {   // slice length from the nominal code period (+1 % margin), whole wavefronts
         const float nn = roundf(cfg.fs / (cfg.nominal_code_rate / cfg.code_len_f));
         const uint64_t n_nom = nn > 0 ? uint64_t(nn * 1.01f) + 64 : 64;

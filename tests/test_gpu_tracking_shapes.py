@@ -85,10 +85,17 @@ def _compare(mgr, ring, oring, starts, make_oracle, arms, epochs_req, epochs_exp
     return worst
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_cfg3_32_channels_25msps(gpu, oracle, mode):
-    """BASELINE configs[2]: 32 channels x 25 Msps, E/P/L (G = 16: the DPP-row totals of trk_persistent_kernel)."""
+@pytest.mark.parametrize("mode,exchange", [(0, "l2"), (1, "l2"), (1, "write-through")])
+def test_cfg3_32_channels_25msps(gpu, oracle, mode, exchange, monkeypatch):
+    """BASELINE configs[2]: 32 channels x 25 Msps, E/P/L (G = 16: the DPP-row totals of trk_persistent_kernel).
+    exchange: "l2" — a channel's workgroups agree on their XCD after the first epoch and publish with plain stores (the
+    form the benchmark runs); "write-through" — the cross-XCD form kept for every epoch (GM_TRK_FORCE_SC1=1), which is
+    what a grid whose workgroups land on different XCDs would run."""
     from gnss_sdr_rs_amd import tracking as T, synth
+    if exchange == "write-through":
+        monkeypatch.setenv("GM_TRK_FORCE_SC1", "1")
+    else:
+        monkeypatch.delenv("GM_TRK_FORCE_SC1", raising=False)
     fs, n, C, E = 25.0e6, 25000, 32, 12
     t = oracle.ca_code_table()
     # FAITHFUL indexes GPS_CA_CODE_32_PRN[prn] (do_tracking.rs:276): PRN 32 would index row 32 (the reference panics), so
