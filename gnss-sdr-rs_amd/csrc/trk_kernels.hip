@@ -732,7 +732,8 @@ __device__ __forceinline__ void lds_barrier() {
 // travels through LDS, and of the constants only the four that change from epoch to epoch)
 struct EpochShared {
     uint64_t win;      // next_sample_index: first sample of the coming epoch's window
-    uint32_t n;        // samples of the coming epoch (0: channel cannot run)
+    uint32_t n;        // samples of the coming epoch (0: the data gate is closed)
+    int alive;         // 0: the channel has just given up (do_work :183-210): the coming epoch does not run whatever n says
     int fast_car, fast_code;   // fast_car_ok / fast_code_ok for the coming epoch (both: the exact fast forms may be used)
     EpochConsts ec;
 };
@@ -746,6 +747,7 @@ __device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t hea
     if (run) run = (int64_t)(head - (s.next_sample_index + n)) >= 0;              // :170-172
     sh.win = s.next_sample_index;
     sh.n = run ? uint32_t(n) : 0u;
+    sh.alive = 1;
     const EpochConsts ec = epoch_consts(cfg, s);
     if (first) sh.ec = ec;
     else { sh.ec.carrier_phase = ec.carrier_phase; sh.ec.two_pi_f = ec.two_pi_f; sh.ec.code_phase = ec.code_phase; sh.ec.step = ec.step; }
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
         cf pf3 = a.ring[(s0.next_sample_index + i0 + tid + 3 * T) & a.mask];
 
         for (; e < a.epochs; ++e) {
-            const uint32_t n = sh.n;
+            const uint32_t n = sh.alive ? sh.n : 0u;
             if (n == 0) break;                     // state is identical in the G workgroups: they all leave
             const EpochConsts ec = sh.ec;
             const uint64_t win = sh.win;
@@ -1083,6 +1085,8 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                         const EpochConsts nx = epoch_consts(cfg, st);
                         sh.ec.carrier_phase = nx.carrier_phase; sh.ec.two_pi_f = nx.two_pi_f;
                         sh.fast_car = fast_car_ok(nx, n_cap) ? 1 : 0;
+                        sh.win = st.next_sample_index;           // this wave owns the bookkeeping
+                        sh.alive = st.active ? 1 : 0;
                         if (to) ctl = 1;
                         if (g == 0 && !to) {
                             const size_t o = size_t(e) * C + ch;
@@ -1103,10 +1107,13 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 } else {                  // ---- code half (DLL :291-302, :265-270) + the gate and length of the next epoch
                     if (!to) {
                         st.num_samples_per_code = n;                 // update() stores the length it used (:166)
-                        const CommonHalf c = common_half(cfg, st, v[0], v[1], n, TRK_MODE_DO_WORK);
+                        // (the lost counter this half's give-up test reads is kept here; prn / active / next_sample_index are
+                        // wave 0's: this wave only needs to know whether the channel goes on, which wave 0 tells through sh.alive)
+                        const bool locked = trk_locked(cfg, v[0], v[1]);
+                        const uint32_t lost_next = locked ? 0u : (trk_give_up(cfg, st, locked) ? 0u : st.lost_counter + 1u);
                         if (st1_on) stp[44] = stamp_now();
                         const CodeHalf h = code_half<ARMS>(cfg, st, v, n, n, TRK_MODE_DO_WORK, &pre_phase[1], pre_phase[2], pre_phase[3]);
-                        st.prn = c.prn; st.active = c.active; st.lost_counter = c.lost_counter; st.next_sample_index = c.next_sample_index;
+                        st.lost_counter = lost_next;
                         st.num_samples_per_code = h.num_samples_per_code; st.code_phase = h.code_phase; st.code_error = h.code_error;
                         st.code_nco = h.code_nco; st.code_rate = h.code_rate;
                     }
@@ -1114,10 +1121,9 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     if (lane == 0) {
                         // the epilogue has just stored round(fs/(code_rate/len)) for the new code_rate (update() :165-166)
                         const uint64_t nn = st.num_samples_per_code;
-                        bool run = st.active && nn > 0 && nn < (1ull << 31);
-                        if (run) run = (int64_t)(a.head - (st.next_sample_index + nn)) >= 0;              // :170-172
+                        bool run = nn > 0 && nn < (1ull << 31);
+                        if (run) run = (int64_t)(a.head - (win + uint64_t(n) + nn)) >= 0;                 // :170-172 (next_sample_index = win + n while the channel lives)
                         const EpochConsts nx = epoch_consts(cfg, st);
-                        sh.win = st.next_sample_index;
                         sh.n = run ? uint32_t(nn) : 0u;
                         sh.ec.code_phase = nx.code_phase; sh.ec.step = nx.step;
                         sh.fast_code = (fast_code_ok(nx, nn) && float(uint32_t(nn)) <= n_cap) ? 1 : 0;
