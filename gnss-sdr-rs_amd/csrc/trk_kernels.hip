@@ -629,12 +629,14 @@ __global__ void trk_update_kernel(TrkDevCfg cfg, gm_trk_state* __restrict__ stat
 
 // ------------------------------------------------------------------------------------ persistent tracking
 // One launch runs `epochs` consecutive passes of process_channels (do_tracking.rs:364-371, 408-413).
-// Grid: n_channels * G workgroups of 1024 lanes, all co-resident (<= one per CU).  The G workgroups of a
-// channel each correlate one slice of every code period; per epoch they exchange their partial sums
-// through self-validating 8-byte {value, tag} granules in HBM (one sc1 store / sc1 load each, no fences:
-// MI355X_MICROARCH.md "Valid forms", R2), every workgroup adds the G partials in the same order and runs
-// the scalar epilogue redundantly, so all of them hold bit-identical channel state without a broadcast.
-// The epoch-to-epoch dependence (carrier_freq/phase, code_rate/phase, next_sample_index) never leaves the chip.
+// Grid: ceil(n_channels / 8) * 8 channel slots x G workgroups of TRK_PERSIST_THREADS lanes, all co-resident (two per CU);
+// the G workgroups of a channel sit on one XCD.  Each correlates one slice of every code period; per epoch they exchange
+// their partial sums through self-validating 8-byte {value, tag} granules (write-through stores and L1-bypassing loads
+// in a launch's first epoch — MI355X_MICROARCH.md "Valid forms", R2 — and plain stores that stay in the XCD's L2 once the
+// workgroups have confirmed from XCC_ID that they share it), every workgroup adds the G partials in the same order and
+// runs the scalar update redundantly (carrier half on wave 0, code half on wave 1), so all of them hold bit-identical
+// channel state without a broadcast.  The epoch-to-epoch dependence (carrier_freq/phase, code_rate/phase,
+// next_sample_index) never leaves the chip.  DESIGN.md 4.3 walks through one epoch with its measured phases.
 struct TrkPersistArgs {
     TrkDevCfg cfg;
     const int8_t* codes;
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     // middle of the serial section.
     __shared__ gm_trk_state st_sh[2];
     static_assert(NW >= 4, "waves 0/1 run the two halves of the serial section, waves 2/3 the phase advances");
-    __shared__ float gathered[256];     // the G*NV partials of one epoch (wave 0 only)
+    __shared__ float gathered[2][256];  // the G*NV partials of one epoch (G other than 16 / 32): one staging area per gathering wave
     extern __shared__ float chips_pad[];   // the channel's chip row as floats, one guard entry at each end (correlate_sample_fast)
     float* const chips = chips_pad;
 
@@ -1058,14 +1060,14 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int idx = lane + q * 64;
-                        if (idx < ng) gathered[idx] = val[q];
+                        if (idx < ng) gathered[wave][idx] = val[q];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     float tk = 0.0f;
                     if (lane < NV)
-                        for (int gg = 0; gg < a.G; ++gg) tk += gathered[lane * a.G + gg];
+                        for (int gg = 0; gg < a.G; ++gg) tk += gathered[wave][lane * a.G + gg];
 #pragma unroll
                     for (int k = 0; k < NV; ++k) v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tk), k));
                 }
@@ -1136,7 +1138,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             lds_barrier();
             if (ctl) { timed_out = true; break; }
             if (wave < 2 && lane == 0) st_sh[wave] = st;      // off the serial chain: the other waves are already correlating
-            // no third barrier: wsum is rewritten only after every wave has passed the NEXT epoch's compute, and
+            // no third barrier: wsum is rewritten only after every wave has passed the NEXT epoch's correlation, and
             // `sh` only after the next epoch's first barrier, which no wave reaches before reading it above
             if (st_on) stp[7] = stamp_now();
         }
