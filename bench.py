@@ -742,11 +742,11 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0,
     (FAITHFUL cannot run PRN 32: the reference indexes GPS_CA_CODE_32_PRN[32]).  C = 32 is BASELINE configs[2];
     larger C (channels beyond 32 re-track the same 32 satellites) shows the kernel away from the per-epoch latency floor."""
     fs, reps = 25.0e6, 5
-    epochs = 120 if C == 32 else 40      # one persistent launch; its ~10 us of launch + set-up amortise over the epochs
+    epochs = 480 if C == 32 else 120     # one persistent launch; its ~10 us of launch + hand-shake amortise over the epochs (120: +0.1 us per epoch)
     n = 25000
     prns = list(range(1, 33))
     sc = synth.tracking_scene(ca, fs, 0.0, prns, epochs + 2, config_id=3, cn0=47.0)
-    ring = T.MulticastRingBuffer(1 << 22 if epochs > 80 else 1 << 21)
+    ring = T.MulticastRingBuffer(1 << 24 if epochs > 320 else 1 << 23 if epochs > 160 else 1 << 22 if epochs > 80 else 1 << 21)
     ring.write_samples(synth.to_c32(sc["x"]))
     mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED)
     mgr.set_stream(stream)
@@ -796,8 +796,9 @@ def tracking_cpu_baseline(sc, fs, n, budget_s):
     O.build(native=True)
     nthreads = min(32, os.cpu_count() or 1)
     ring = O.MulticastRingBuffer(1 << 22)
-    ring.write_samples(synth.to_c32(sc["x"]))
-    avail = int(sc["x"].size // n) - 2
+    x_cpu = sc["x"][: min(int(sc["x"].size), 122 * n)]      # the first 122 ms of the GPU leg's scene: a bounded sample for the CPU
+    ring.write_samples(synth.to_c32(x_cpu))
+    avail = int(x_cpu.size // n) - 2
 
     def fresh():
         chans = []
