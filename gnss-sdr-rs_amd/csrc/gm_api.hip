@@ -1286,10 +1286,18 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
         int g = 1;
         const int per_cu = gm::trk_persistent_blocks_per_cu(d);      // occupancy of this instantiation, capped at the design's 2
         const size_t slots = size_t(gm::trk_persistent_slots(t->C));   // the grid is slots * G workgroups (empty ones leave at once)
-        while (g * 2 <= 32 && size_t(g) * 2 * slots <= size_t(cus) * per_cu && g * 2 * nv <= 256) g *= 2;
-        if (const char* e = getenv("GM_TRK_G")) {   // diagnostic override (power of two; must keep n_channels * G resident)
+        // the most workgroups per channel the chip holds at once (any count, not only powers of two: 36 channels take 12 each,
+        // 480 of the 512 places, where 8 left a third of the chip idle and two-workgroup CUs beside one-workgroup CUs);
+        // 17..31 fall back to 16, the width of the DPP totals path
+        {
+            const size_t fit = (size_t(cus) * per_cu) / slots;
+            g = int(fit < 1 ? 1 : fit > 32 ? 32 : fit);
+            while (g > 1 && g * nv > 256) --g;
+            if (g > 16 && g < 32) g = 16;
+        }
+        if (const char* e = getenv("GM_TRK_G")) {   // diagnostic override (must keep n_channels * G resident)
             const int f = atoi(e);
-            if (f >= 1 && f <= 32 && (f & (f - 1)) == 0 && size_t(f) * slots <= size_t(cus) * per_cu && f * nv <= 256) g = f;
+            if (f >= 1 && f <= 32 && size_t(f) * slots <= size_t(cus) * per_cu && f * nv <= 256) g = f;
         }
         t->G = g;
         const size_t xb = (size_t(2) * t->C * g * nv + size_t(t->C) * g) * sizeof(unsigned long long);   // partials + XCC_ID granules
