@@ -221,3 +221,57 @@ def test_two_managers_on_two_streams_do_not_strand_each_other(gpu, oracle):
                     assert _ulps(getattr(s, k), getattr(w[i], k)) == 0, (i, k)
         a.close(); b.close()
     ring.close()
+
+
+def test_epoch_length_that_flips_between_two_values(gpu, oracle):
+    """fs chosen so that fs / (code_rate / 1023) sits at a half-integer (4000.5): the DLL's parts-per-million steps of
+    the code rate move the rounded epoch length n between 4000 and 4001 from epoch to epoch.  The kernel keeps n without the
+    two divisions only while the new rate lies in an interval proven to round to the same n (gm_libm.h spc_rate_bounds)
+    and evaluates the definition otherwise; the bookkeeping (num_samples_per_code, next_sample_index) must equal the
+    oracle's at every epoch and the lengths must in fact change during the run."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    fs, C, E = 4_000_500.0, 4, 60
+    t = oracle.ca_code_table()
+    prns = [4, 9, 17, 26]
+    sc = synth.tracking_scene(t, fs, 0.0, prns, E + 3, config_id=61, cn0=48.0)
+    x = synth.to_c32(sc["x"])
+    ring, oring = T.MulticastRingBuffer(1 << 19), oracle.MulticastRingBuffer(1 << 19)
+    ring.write_samples(x[:(E + 2) * 4001])
+    oring.write_samples(x[:(E + 2) * 4001])
+    mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=1)
+    starts = [_acq_result(s["prn"], s["doppler_hz"] + 15.0, fs, s["code_start"]) for s in sc["sats"]]
+    forced = []
+    for i, r in enumerate(starts):
+        mgr.channels[i].start(r)
+        oc = oracle.TrackingChannel(i, fs, code_index_mode=1)
+        oc.start(r)
+        forced.append(oc)
+    lengths = set()
+    for ep in range(E):
+        outs, proc, lost, done = mgr.update_all(ring, 1)          # one pass per call: the state is read back after each
+        assert done == 1 and not lost.any()
+        for i, oc in enumerate(forced):
+            rc, comp, comp64, _ = oc.update_forced(oring, outs[0, i])
+            assert rc != 0 and proc[0, i]
+            env = float(np.hypot(comp[0], comp[1]))
+            assert float(np.max(np.abs(outs[0, i] - comp[:6]))) <= REL * env, (i, ep)
+            s = mgr.channels[i].state
+            assert s.num_samples_per_code == oc.c.num_samples_per_code, (i, ep, s.num_samples_per_code, oc.c.num_samples_per_code)
+            assert s.next_sample_index == oc.c.next_sample_index, (i, ep)
+            assert _ulps(s.code_rate, oc.c.code_rate) == 0 and _ulps(s.code_phase, oc.c.code_phase) == 0
+            lengths.add(int(s.num_samples_per_code))
+    assert lengths == {4000, 4001}, lengths
+    # the same run as ONE persistent launch (the length changes inside the launch): identical state, word for word
+    one = T.TrackingManager(fs, n_channels=C, code_index_mode=1)
+    for i, r in enumerate(starts):
+        one.channels[i].start(r)
+    outs1, proc1, lost1, done1 = one.update_all(ring, E)
+    assert done1 == E and proc1[:E, :C].all() and not lost1.any()
+    for i in range(C):
+        a, b = mgr.channels[i].state, one.channels[i].state
+        for k in ("next_sample_index", "num_samples_per_code", "lost_counter", "prn"):
+            assert getattr(a, k) == getattr(b, k), (i, k)
+        for k in ("carrier_freq", "carrier_phase", "carrier_error", "carrier_nco", "code_phase", "code_error", "code_nco", "code_rate",
+                  "i_prompt", "q_prompt"):
+            assert _ulps(getattr(a, k), getattr(b, k)) == 0, (i, k)
+    one.close(); mgr.close(); ring.close()
