@@ -275,3 +275,24 @@ def test_epoch_length_that_flips_between_two_values(gpu, oracle):
                   "i_prompt", "q_prompt"):
             assert _ulps(getattr(a, k), getattr(b, k)) == 0, (i, k)
     one.close(); mgr.close(); ring.close()
+
+
+def test_phase_beyond_the_fast_range_takes_the_general_forms(gpu, oracle):
+    """A 20 MHz IF at 50 Msps turns the carrier by 1.26e5 rad per epoch: beyond the 1e5 rad the fast sin/cos admits
+    (fast_car_ok), so every epoch runs correlate_sample<FAST = false> (f64 argument reduction, library fmod) inside the
+    persistent kernel.  Same teacher-forced comparison as the BASELINE shapes."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    fs, f_if, n, C, E = 50.0e6, 20.0e6, 50000, 3, 6
+    t = oracle.ca_code_table()
+    prns = [2, 12, 30]
+    sc = synth.tracking_scene(t, fs, f_if, prns, E + 2, config_id=71, cn0=50.0)
+    x = synth.to_c32(sc["x"])
+    ring, oring = T.MulticastRingBuffer(1 << 19), oracle.MulticastRingBuffer(1 << 19)
+    ring.write_samples(x[:(E + 1) * n])
+    oring.write_samples(x[:(E + 1) * n])
+    mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=1)
+    starts = [_acq_result(s["prn"], f_if + s["doppler_hz"] + 10.0, fs, s["code_start"]) for s in sc["sats"]]
+    w = _compare(mgr, ring, oring, starts, lambda i: oracle.TrackingChannel(i, fs, code_index_mode=1), 3, E, E,
+                 rel=2e-5, free_rel=2e-4)     # 50 000 terms per sum: the reference's own sequential f32 order is 1.3e-5 away from f64 (cfg5 note)
+    print("20 MHz IF", w)
+    mgr.close(); ring.close()
