@@ -33,7 +33,7 @@ def _worker(rank, world, port, q):
     sats = [dict(prn_row=2, cn0_dbhz=52.0, doppler_hz=480.0, code_start=100),
             dict(prn_row=6, cn0_dbhz=51.0, doppler_hz=-20.0, code_start=1999)]
     x = synth.to_c32(synth.make_scene(t, fs, 0.0, M * N, sats, config_id=31))
-    all_prns = [1, 3, 5, 7, 9, 11]
+    all_prns = [1, 3, 5, 7, 9, 11] if world == 2 else [1, 3, 5, 7, 9, 11, 13, 15]     # equal blocks per rank (one all-gather of equal-sized blocks)
     mine = Dm.shard_prns(all_prns, world, rank)
     tables = [O.DopplerShiftTable(0.0, float(d), fs, N) for d in dop]
     tf = np.array([tb.doppler_freq_hz for tb in tables], np.float32)
@@ -157,6 +157,31 @@ def test_world2_mixed_family_grid_equals_single_process():
     assert s0 == [(0, 0, 5)] and s1 == [(1, 0, 4)]
     assert [r["prn"] for r in r0["gps"] if r] == [3], r0["gps"]
     assert 4 in [r["prn"] for r in r0["b"] if r] and r0["b"][3]["code_phase_samples"] == 1999, r0["b"]
+
+
+def test_world4_gloo_equals_single_process():
+    """The same two paths at world size 4 (two codes per rank; the mixed grid in blocks of 3, 2, 2, 2 codes): every rank's
+    decision equals the single-process one."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    for worker in (_worker, _grid_worker):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=worker, args=(r, 4, port, q)) for r in range(4)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=240) for _ in range(4)]
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        got.sort(key=lambda t: t[0])
+        single = got[0][2]
+        for g in got:
+            assert g[1] == single, (worker.__name__, g[0])
+        if worker is _grid_worker:
+            shards = [g[3] for g in got]
+            sizes = [sum(cnt for _, _, cnt in sh) for sh in shards]
+            assert sum(sizes) == 9 and max(sizes) - min(sizes) <= 1, shards
 
 
 def test_shard_grid_of_the_90_code_baseline_grid():
