@@ -1009,8 +1009,8 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     same_xcd = __all(!pend && uint32_t(xg) == my_xcc) != 0 && !a.force_write_through;
                 }
                 to = __any(to);
-                if (st_on) stp[4] = stamp_now();
-                if (st1_on) stp[40] = stamp_now();
+                if (st_on) { stp[4] = stamp_now(); stp[45] = (long long)rounds; }
+                if (st1_on) { stp[40] = stamp_now(); stp[46] = (long long)rounds; }
                 // totals of the G partials of every arm, identical in all lanes and in all workgroups of the channel.
                 // Granules are arm-major ([k][g]).  G == 16: arm k's partials sit in one DPP row of 16 lanes (arms 0-3 in
                 // the first sweep's registers, 4.. in the next), so four row_shr adds leave the arm total in the row's last

@@ -28,3 +28,5 @@ print('wave 1 (code half) after the barrier: gathered %d, half done %d, next-epo
     np.median(buf[5:, 4] - buf[5:, 2]), np.median(buf[5:, 6] - buf[5:, 2]), np.median(buf[5:, 7] - buf[5:, 2])))
 w1b = buf[5:, 43:45] - buf[5:, 2:3]
 print('wave 1 detail: totals done %d, bookkeeping done %d' % (np.median(w1b[:, 0]), np.median(w1b[:, 1])))
+print('extra poll rounds after the first sweep (median / mean over epochs): wave 0 %.1f / %.2f, wave 1 %.1f / %.2f' % (
+    np.median(buf[5:, 45]), np.mean(buf[5:, 45]), np.median(buf[5:, 46]), np.mean(buf[5:, 46])))
