@@ -643,6 +643,7 @@ struct TrkPersistArgs {
     gm_trk_state* states;
     const cf* ring; uint64_t mask, head;
     int G, epochs;
+    int stamp_block;                 // diagnostic: the workgroup whose phases are stamped (GM_TRK_STAMP_WG, default 0)
     int force_write_through;         // diagnostic (GM_TRK_FORCE_SC1=1): keep the cross-XCD exchange form even when a channel's workgroups share an XCD
     uint32_t per;                    // samples per workgroup slice (multiple of 64), fixed for the launch
     uint32_t tag_base;               // unique per launch: tag = tag_base + epoch + 1
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             if (n == 0) break;                     // state is identical in the G workgroups: they all leave
             const EpochConsts ec = sh.ec;
             const uint64_t win = sh.win;
-            const bool st_on = a.stamps && blockIdx.x == 0 && tid == 0;
+            const bool st_on = a.stamps && int(blockIdx.x) == a.stamp_block && tid == 0;
             long long* stp = a.stamps + size_t(e) * 48;
             if (st_on) stp[0] = stamp_now();
             const uint32_t i1 = (g == a.G - 1 || i0 + per > n) ? n : i0 + per;
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     correlate_sample<ARMS, false, MODE_T, BOC_T, float>(ec, chips, a.ring[(win + i) & a.mask], i, acc);
             }
             if (st_on) stp[1] = stamp_now();
-            if (a.stamps && blockIdx.x == 0 && lane == 0) stp[8 + wave] = stamp_now();        // per-wave compute end
+            if (a.stamps && int(blockIdx.x) == a.stamp_block && lane == 0) stp[8 + wave] = stamp_now();        // per-wave compute end
             {   // request the next epoch's samples now; they land during the exchange below
                 const uint64_t nb = win + n;
                 pf0 = a.ring[(nb + i0 + tid) & a.mask];
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             for (int k = 0; k < NV; ++k) acc[k] += acc2[k];
             const float wtotal = wave_sums_scatter<NV>(acc, lane);     // lane k < NV: this wave's total of value k
             if (lane < NV) wsum[wave][lane] = wtotal;
-            if (a.stamps && blockIdx.x == 0 && lane == 0) stp[24 + wave] = stamp_now();       // per-wave barrier arrival
+            if (a.stamps && int(blockIdx.x) == a.stamp_block && lane == 0) stp[24 + wave] = stamp_now();       // per-wave barrier arrival
             lds_barrier();    // NOT __syncthreads(): its fence would wait for the prefetch loads (vmcnt(0))
             if (st_on) stp[2] = stamp_now();
             gm_trk_state st;      // waves 0 / 1: this wave's copy of the channel state, from LDS and back (after the barrier below)
@@ -946,7 +947,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 // the dependencies, so two waves halve the section).  The other workgroup of this CU is usually correlating
                 // on the same SIMDs: raised issue priority keeps the chains from queueing behind it.
                 __builtin_amdgcn_s_setprio(3);
-                const bool st1_on = a.stamps && blockIdx.x == 0 && tid == 64;
+                const bool st1_on = a.stamps && int(blockIdx.x) == a.stamp_block && tid == 64;
                 // this workgroup's partial (waves added in a fixed order), published as {value, tag} granules
                 const uint32_t tag = a.tag_base + uint32_t(e) + 1u;
                 unsigned long long* slot = a.xchg + (size_t(e & 1) * C + ch) * a.G * NV;
@@ -1181,6 +1182,7 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     a.stamps = d_stamps;
     a.cfg = cfg; a.codes = d_codes; a.states = d_states; a.ring = ring; a.mask = mask; a.head = head;
     a.G = G; a.epochs = epochs; a.tag_base = tag_base;
+    { const char* z = getenv("GM_TRK_STAMP_WG"); a.stamp_block = z ? atoi(z) : 0; }
     {
         const char* e = getenv("GM_TRK_FORCE_SC1");
         a.force_write_through = (e && atoi(e) != 0) ? 1 : 0;
