@@ -186,7 +186,7 @@ def test_update_all_matches_per_channel_oracle(gpu, oracle):
             assert (rc != 0) == bool(proc[ep, i]), (i, ep)
             if rc:
                 env = float(np.hypot(exp[0], exp[1]))
-                assert np.max(np.abs(outs[ep, i] - exp)) <= 5 * REL * env, (i, ep)   # free-running: loop state feeds back
+                assert np.max(np.abs(outs[ep, i] - exp)) <= 2.5 * REL * env, (i, ep)   # free-running: loop state feeds back
         s = mgr.channels[i].state
         assert s.next_sample_index == oc.c.next_sample_index
         assert s.carrier_freq == pytest.approx(oc.c.carrier_freq, abs=5e-3)
@@ -254,7 +254,7 @@ def test_more_channels_than_resident_workgroups(gpu, oracle):
         assert (pb[:, i] == ps[:, i % 3]).all()
         # different slice counts per channel (G = 1 vs G = 32) change the summation tree, not the value
         env = np.hypot(os_[:, i % 3, 0], os_[:, i % 3, 1]).max()
-        assert np.abs(ob[:, i] - os_[:, i % 3]).max() <= 5 * REL * env
+        assert np.abs(ob[:, i] - os_[:, i % 3]).max() <= 2.5 * REL * env
         assert big.channels[i].state.next_sample_index == small.channels[i % 3].state.next_sample_index
     big.close(); small.close(); ring.close()
 
@@ -312,7 +312,7 @@ def test_persistent_kernel_sweep_over_sample_rates(gpu, oracle, fs, f_if, mode):
             assert (rc != 0) == bool(proc[ep, i]), (i, ep)
             if rc:
                 env = float(np.hypot(exp[0], exp[1]))
-                assert np.max(np.abs(outs[ep, i] - exp)) <= 5 * REL * env, (fs, i, ep)
+                assert np.max(np.abs(outs[ep, i] - exp)) <= 2.5 * REL * env, (fs, i, ep)
         s = mgr.channels[i].state
         assert s.next_sample_index == oc.c.next_sample_index and s.num_samples_per_code == oc.c.num_samples_per_code
         assert s.lost_counter == oc.c.lost_counter
