@@ -81,6 +81,10 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    # one explicit stream for everything this process enqueues (library kernels through gm_*_set_stream, torch's copies and
+    # collectives through torch's current stream): nothing relies on the NULL stream's implicit ordering
+    bench_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(bench_stream)
 
     from gnss_sdr_rs_amd import _lib, acquisition as A, synth, tracking as T
     _lib.init(local_rank)                      # raises if the HIP library is missing: no fallback
@@ -105,23 +109,51 @@ def main():
     eng.set_stream(stream)
     d_samples = torch.from_numpy(xi8).to(dev)                       # IF snapshot resident in HBM
     d_metrics = torch.zeros(3 * P * D, dtype=torch.int32, device=dev)
-    # GM_BENCH_NATIVE_COMM=1: exchange through the C ABI's own RCCL communicator (gm_comm_*, what a Rust host would
-    # call) instead of torch.distributed's; default off at N > 1 only because this round could rehearse it on one GPU only
-    native_comm = None
-    if os.environ.get("GM_BENCH_NATIVE_COMM") == "1" and not debug_gloo:
-        from gnss_sdr_rs_amd import distributed as Dm
-        native_comm = Dm.NativeComm.from_torch_dist() if world > 1 else Dm.NativeComm(1, 0, Dm.NativeComm.unique_id())
+    # The exchange carrier.  At N > 1 the default is the C ABI's own RCCL communicator (gm_comm_*: what a Rust host calls,
+    # all-gather + regroup inside the library, overlapped with the next dwell on the communicator's stream); before the
+    # timed region one dwell is exchanged through BOTH carriers and the native result must equal torch.distributed's bit
+    # for bit on every rank, else (or on any error) the run falls back to torch.distributed and says so in config.exchange.
+    # GM_BENCH_TORCH_COMM=1 forces the torch carrier, GM_BENCH_NATIVE_COMM=1 exercises the native one at N = 1.
+    from gnss_sdr_rs_amd import distributed as Dm
+    native_comm, carrier_note = None, None
+    want_native = (world > 1 and os.environ.get("GM_BENCH_TORCH_COMM") != "1") or os.environ.get("GM_BENCH_NATIVE_COMM") == "1"
+    if want_native and not debug_gloo:
+        try:
+            native_comm = Dm.NativeComm.from_torch_dist() if world > 1 else Dm.NativeComm(1, 0, Dm.NativeComm.unique_id())
+        except Exception as e:
+            native_comm, carrier_note = None, "gm_comm_init failed: %r" % (e,)
     if world > 1 or native_comm:
         d_gather = torch.zeros(world * 3 * P * D, dtype=torch.int32, device=dev)
         ids_all = np.tile(np.arange(1, 33, dtype=np.uint8), world)
-
-    # N > 1: the exchange of dwell i (RCCL, on torch.distributed's own stream) overlaps the search of dwell i + 1 — the
-    # all-gather is issued asynchronously right behind search(i), and regroup + decision of dwell i are enqueued after
-    # search(i + 1).  Metrics / gather buffers alternate.  Every timed step is still issued AND finished inside the region.
-    if world > 1 and not native_comm:
+    if world > 1:
         met2 = [d_metrics, torch.zeros_like(d_metrics)]
         gat2 = [d_gather, torch.zeros_like(d_gather)]
+    if world > 1 and not debug_gloo:
+        ok = 1
+        if native_comm:
+            try:
+                eng.search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, d_metrics.data_ptr())
+                native_comm.allgather_metrics(eng, gat2[1].data_ptr(), d_metrics.data_ptr())       # -> [3][world*P][D]
+                ref = torch.empty_like(d_gather)
+                dist.all_gather_into_tensor(ref, d_metrics)
+                torch.cuda.synchronize()
+                ok = int(torch.equal(ref.view(world, 3, P * D).permute(1, 0, 2).contiguous().view(-1), gat2[1]))
+                if not ok:
+                    carrier_note = "gm_comm all-gather differed from torch.distributed's"
+            except Exception as e:
+                ok, carrier_note = 0, "gm_comm trial failed: %r" % (e,)
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # one carrier for every rank
+        if int(flag.item()) == 0 and native_comm:
+            native_comm.close()
+            native_comm = None
+            carrier_note = carrier_note or "another rank could not use gm_comm"
 
+    # N > 1: the exchange of dwell i overlaps the search of dwell i + 1 — the all-gather is issued behind search(i) on the
+    # carrier's own stream, and regroup + decision of dwell i are enqueued after search(i + 1).  Metrics / gather buffers
+    # alternate.  Every timed step is still issued AND finished inside the region.
     def issue(i):
         k = i & 1
         eng.search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, met2[k].data_ptr())
@@ -144,7 +176,24 @@ def main():
 
     def run(n_steps):
         keep = None
-        if world > 1 and not native_comm and overlap["on"]:
+        if world > 1 and native_comm:
+            # search(i) | wait gather(i-1), decide(i-1) | gather(i) on the communicator's stream, beside search(i+1)
+            for i in range(n_steps):
+                k = i & 1
+                eng.search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, met2[k].data_ptr())
+                if overlap["on"]:
+                    if i > 0:
+                        native_comm.wait(stream)
+                        eng.decide_dev(gat2[k ^ 1].data_ptr(), n_prn=world * P, prn_ids=ids_all)
+                    native_comm.allgather_metrics_async(eng, gat2[k].data_ptr(), met2[k].data_ptr())
+                else:
+                    native_comm.allgather_metrics(eng, gat2[k].data_ptr(), met2[k].data_ptr())
+                    eng.decide_dev(gat2[k].data_ptr(), n_prn=world * P, prn_ids=ids_all)
+            if overlap["on"] and n_steps > 0:
+                native_comm.wait(stream)
+                eng.decide_dev(gat2[(n_steps - 1) & 1].data_ptr(), n_prn=world * P, prn_ids=ids_all)
+            return keep
+        if world > 1 and overlap["on"]:
             try:
                 prev = None
                 for i in range(n_steps):
@@ -159,7 +208,7 @@ def main():
                 overlap["on"] = False
                 if rank == 0:
                     print(f"overlapped exchange failed ({e!r}); using the synchronous order", file=sys.stderr, flush=True)
-        if world > 1 and not native_comm:
+        if world > 1:
             for i in range(n_steps):    # search -> all-gather -> regroup -> decision, in order on one stream
                 work, k = issue(i)
                 keep = finish((work, k))
@@ -196,6 +245,31 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # the exchange alone (all-gather + regroup of the 3*P*D-word blocks, no search in front), in order on the stream:
+    # what a dwell would pay for it without the overlap
+    exchange_us = None
+    if world > 1 and not debug_gloo:
+        try:
+            def xchg():
+                if native_comm:
+                    native_comm.allgather_metrics(eng, gat2[0].data_ptr(), met2[0].data_ptr())
+                else:
+                    dist.all_gather_into_tensor(gat2[0], met2[0])
+                    gat2[0].view(world, 3, P * D).permute(1, 0, 2).contiguous()
+            for _ in range(5):
+                xchg()
+            torch.cuda.synchronize()
+            dist.barrier()
+            tx = time.perf_counter()
+            for _ in range(50):
+                xchg()
+            torch.cuda.synchronize()
+            txe = torch.tensor([(time.perf_counter() - tx) / 50 * 1e6], dtype=torch.float64, device=dev)
+            dist.all_reduce(txe, op=dist.ReduceOp.MAX)
+            exchange_us = float(txe.item())
+        except Exception as e:
+            exchange_us = repr(e)
 
     # detections must be the simulated satellites (rank 0's block), every step's result identical by construction
     res = eng.fetch_results(world * P if world > 1 else P)
@@ -251,23 +325,35 @@ def main():
                                "N=8000, 10 x 1 ms non-coherent, per GPU" + ("; all-gather of {max,argmax,sum}[P][D]" if world > 1 else ""),
                    "prns_per_gpu": P, "doppler_bins": D, "fft_size": N, "integrations": M,
                    "cells_per_step": cells_per_step, "cell_integrations_per_s": value * M,
-                   "parallelism": f"prn-shard x{world}", "exchange_overlapped_with_next_dwell": bool(world > 1 and not native_comm and overlap["on"]), "exchange": ("gm_comm (RCCL via the C ABI)" if native_comm else "torch.distributed nccl" if world > 1 else None), "detections_ok": bool(detections_ok)},
-        "roofline": {"bound": "hbm", "kernel": "acq_corr_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command)",
+                   "parallelism": f"prn-shard x{world}", "exchange_overlapped_with_next_dwell": bool(world > 1 and overlap["on"] and not debug_gloo),
+                   "exchange": ("gm_comm (RCCL through the C ABI: gm_acq_allgather_metrics_async + gm_comm_wait)" if (native_comm and world > 1)
+                                else "gm_comm (one rank)" if native_comm else "gloo through host memory (rehearsal)" if (world > 1 and debug_gloo)
+                                else "torch.distributed nccl" if world > 1 else None),
+                   "exchange_fallback_reason": carrier_note, "exchange_us_per_dwell": exchange_us,
+                   "detections_ok": bool(detections_ok)},
+        # the binding roof of the dominant kernel is f32 VALU issue (MFMA is not used: no dense contraction on this path);
+        # SURVEY 8d's algorithmic-byte model sits beside it as `hbm_model`, without a `frac` of a physical peak: it counts
+        # every worker's re-read of a Doppler bin's spectra (P x) as HBM bytes, and on the chip those are L2 hits
+        "roofline": {"bound": "valu-f32", "kernel": "acq_corr_kernel", "achieved": compute["achieved"], "peak": FP32_VALU_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": compute["frac"], "issue_frac": compute.get("valu_issue_frac"),
+                     "traffic": traffic,
+                     "traffic_source": "profiles/traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command, launches of the benchmarked grid size only)",
                      "traffic_over_algorithmic": (traffic / corr_bytes) if traffic else None,
                      "fabric_GBs": (traffic / corr_s / 1e9) if (traffic and corr_s > 0) else None,
                      "fabric_frac_of_hbm_peak": (traffic / corr_s / 1e9 / HBM_PEAK_GBS) if (traffic and corr_s > 0) else None,
-                     "reading": "achieved/frac follow SURVEY 8d's algorithmic-byte model, which counts every worker's re-read of "
-                                "a Doppler bin's spectra (32x) as HBM bytes; on the chip those re-reads are served by the XCD's "
-                                "L2, so frac can pass 1 and says nothing about HBM: the measured fabric traffic is `traffic` "
-                                "(fabric_frac_of_hbm_peak of the 8 TB/s), and the kernel is bound by f32 VALU issue + LDS "
-                                "round trips + workgroup barriers: see `compute`",
+                     "reading": "frac = useful f32 flops (5 N log2 N + 10 N per inverse transform) / kernel time / the 157.3 TF vector "
+                                "peak; issue_frac = VALU wave-instructions x 1.02 ns per SIMD / kernel time (the share of the f32 issue "
+                                "slots the kernel fills); traffic = measured fabric bytes per launch (a few % of the HBM peak: the "
+                                "kernel is not HBM-bound); hbm_model = SURVEY 8d's algorithmic bytes / time, a model figure that "
+                                "can exceed the 8 TB/s peak because the re-reads it counts are served by L2",
                      "compute": compute,
-                     "algorithmic_bytes_per_launch": corr_bytes, "avg_launch_ms": tsum["avg_corr_ms"],
-                     "launches_timed": tsum["launches"],
+                     "hbm_model": {"algorithmic_bytes_per_launch": corr_bytes, "model_GBs": achieved, "hbm_peak_GBs": HBM_PEAK_GBS,
+                                   "model_over_peak": achieved / HBM_PEAK_GBS,
+                                   "note": "16 B per (PRN, bin, ms, k): not a fraction of a physical roof"},
+                     "avg_launch_ms": tsum["avg_corr_ms"], "launches_timed": tsum["launches"],
                      "stage_F": {"kernel": "acq_mix_fft_kernel", "algorithmic_bytes_per_launch": mix_bytes,
-                                 "avg_launch_ms": tsum["avg_mix_fft_ms"]},
+                                 "avg_launch_ms": tsum["avg_mix_fft_ms"],
+                                 "algorithmic_GBs": (mix_bytes / (tsum["avg_mix_fft_ms"] * 1e-3) / 1e9) if tsum["avg_mix_fft_ms"] > 0 else None},
                      "whole_step_algorithmic_GBs": (corr_bytes + mix_bytes) * args.steps / elapsed / 1e9},
     }
     del keep
@@ -315,7 +401,7 @@ def main():
     # ------------------------------------------------------------------ configs[3] as written: the 90-code mixed grid, sharded
     if os.environ.get("GM_BENCH_NO_GRID") != "1":
         try:
-            g4 = cfg4_grid_leg(torch, dev, stream, ca, A, synth, world, rank, dist, debug_gloo)
+            g4 = cfg4_grid_leg(torch, dev, stream, ca, A, synth, world, rank, dist, debug_gloo, native_comm)
             if rank == 0:
                 out["cfg4_grid"] = g4
         except Exception as e:
@@ -346,11 +432,13 @@ def main():
             out["tracking_256ch"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ configs[4] geometry (informative, no reference code)
-    if rank == 0 and world == 1 and not args.no_tracking:
+    if not args.no_tracking and os.environ.get("GM_BENCH_NO_CFG5") != "1":      # every rank takes part (strong scaling at N > 1)
         try:
-            out["cfg5_geometry"] = cfg5_leg(torch, stream, T)
+            c5 = cfg5_leg(torch, stream, T, world, rank, dist, dev, debug_gloo)
         except Exception as e:
-            out["cfg5_geometry"] = {"error": repr(e)}
+            c5 = {"error": repr(e)}
+        if rank == 0:
+            out["cfg5_geometry"] = c5
 
     # ------------------------------------------------------------------ digital front-end, informative
     if rank == 0 and world == 1:
@@ -465,46 +553,23 @@ def cfg1_cpu_single_prn(sc, prn):
             "cpu": cpu_model(), "found": bool(res[0])}
 
 
-def cfg4_grid_leg(torch, dev, stream, ca, A, synth, world, rank, dist, debug_gloo):
+def cfg4_grid_leg(torch, dev, stream, ca, A, synth, world, rank, dist, debug_gloo, native_comm=None):
     """BASELINE configs[3] as written: ONE 90-code grid — 32 GPS L1 C/A + 36 Galileo-E1-geometry codes (4092 chips, 4 ms:
     stand-in memory codes, the ICD's hex tables are not available offline) + 22 BeiDou B1I codes (real: gm_b1i_code) — on one
     10 ms IF snapshot at 8 Msps int8, sharded over the ranks in contiguous blocks (12, 12, 11, ... codes at 8 ranks; a rank may
-    hold two families with different transform sizes), ONE all-gather of the padded {max, argmax, sum}[P_max][41] blocks, and
-    the reference's decision per family on the gathered grid on every rank.  STRONG scaling (the grid is fixed); informative,
-    never `value`."""
+    hold two families with different transform sizes), ONE all-gather of the padded {max, argmax, sum}[P_max][41] blocks, then
+    assemble + the reference's decision per family on the gathered grid ON THE DEVICE on every rank (gm_grid_assemble_dev +
+    gm_acq_decide_planes_dev): no device-to-host copy inside a dwell.  STRONG scaling (the grid is fixed); informative,
+    never `value`.  The same path is parity-tested at these sizes in tests/test_gpu_mixed_grid.py."""
     from gnss_sdr_rs_amd import distributed as Dm
-    fs, D = 8.0e6, 41
-    dop = np.array([-5000.0 + 250.0 * i for i in range(D)], np.float32)
-    rng = np.random.default_rng(44)
-    e1 = np.where(rng.integers(0, 2, (36, 4092)) > 0, 1, -1).astype(np.int8)
     b1i = A.b1i_codes(range(1, 23))
-    fams = [Dm.GridFamily("gps", fs, 0.0, 8000, 10, dop, list(range(1, 33))),
-            Dm.GridFamily("e1", fs, 0.0, 32000, 2, dop, list(range(1, 37)), codes=e1, code_rate=1.023e6),
-            Dm.GridFamily("b1i", fs, 0.0, 8000, 10, dop, list(range(1, 23)), codes=b1i, code_rate=2.046e6)]
-    # one scene holding two satellites of every family (same seed on every rank: identical bytes)
-    n = 80000
-    x = synth.make_scene(ca, fs, 0.0, n, [dict(prn_row=4, cn0_dbhz=50.0, doppler_hz=1130.0, code_start=4321),
-                                         dict(prn_row=20, cn0_dbhz=47.0, doppler_hz=-2210.0, code_start=77)], config_id=4, quantize=False)
-    # (make_scene adds its own noise; the extra families are added noise-free on top of the first scene's noise)
-    def clean(codes, sats, rate):
-        t = np.arange(n, dtype=np.float64)
-        y = np.zeros(n, np.complex128)
-        for s_ in sats:
-            amp = 16.0 * np.sqrt(2.0 * 10.0 ** (s_["cn0_dbhz"] / 10.0) / fs)
-            chip = np.floor((t - s_["code_start"]) * rate / fs).astype(np.int64) % codes.shape[1]
-            y += amp * codes[s_["prn_row"]][chip] * np.exp(2j * np.pi * s_["doppler_hz"] * t / fs)
-        return y
-    truth = {"gps": {5: 4321, 21: 77}, "e1": {7: 20001, 31: 555}, "b1i": {3: 3000, 15: 6100}}
-    x = x + clean(e1, [dict(prn_row=6, cn0_dbhz=49.0, doppler_hz=620.0, code_start=20001),
-                       dict(prn_row=30, cn0_dbhz=47.0, doppler_hz=-3300.0, code_start=555)], 1.023e6)
-    x = x + clean(b1i, [dict(prn_row=2, cn0_dbhz=50.0, doppler_hz=-870.0, code_start=3000),
-                        dict(prn_row=14, cn0_dbhz=48.0, doppler_hz=2950.0, code_start=6100)], 2.046e6)
-    xq = np.clip(np.round(x.real), -127, 127) + 1j * np.clip(np.round(x.imag), -127, 127)
-    d_x = torch.from_numpy(synth.to_i8_iq(xq)).to(dev)
+    sc = synth.cfg4_grid_scene(ca, b1i)          # same seed on every rank: identical bytes
+    fams = Dm.baseline_grid_families(sc, b1i)
+    D, truth = sc["D"], sc["truth"]
+    d_x = torch.from_numpy(synth.to_i8_iq(sc["x"])).to(dev)
     grid, err = None, None
     try:
-        grid = Dm.MixedGrid(fams, world, rank)
-        grid.set_stream(stream)
+        grid = Dm.MixedGrid(fams, world, rank, stream=stream)
     except Exception as e:      # a rank that cannot build its engines must not leave the others waiting in the all-gather
         err = repr(e)
     if world > 1:
@@ -525,59 +590,53 @@ def cfg4_grid_leg(torch, dev, stream, ca, A, synth, world, rank, dist, debug_glo
             if debug_gloo:
                 h = [torch.empty(blk.numel(), dtype=torch.int32) for _ in range(world)]
                 dist.all_gather(h, blk.cpu())
-                g = torch.cat(h).numpy()
+                gathered.copy_(torch.cat(h))
+            elif native_comm:
+                native_comm.allgather_words(blk.data_ptr(), gathered.data_ptr(), blk.numel(), stream)   # the path's one exchange step
             else:
-                dist.all_gather_into_tensor(gathered, blk)          # the path's one exchange step
-                g = gathered.cpu().numpy()
+                dist.all_gather_into_tensor(gathered, blk)
+            grid.decide_dev(gathered)
         else:
-            g = blk.cpu().numpy()
-        return Dm.grid_decide(Dm.grid_assemble(g, fams, world, D), fams)
-    for _ in range(20):      # the host side of a dwell (numpy / ctypes glue of the decision) needs ~20 calls to warm up
-        res = dwell()
+            grid.decide_dev(blk)
+    for _ in range(3):
+        dwell()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     reps = 20
     t0 = time.perf_counter()
     for _ in range(reps):
-        res = dwell()
+        dwell()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = (time.perf_counter() - t0) / reps
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if not debug_gloo else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    res, asm = grid.fetch()
     if os.environ.get("GM_GRID_DEBUG"):
         for fam, sats in truth.items():
             print(fam, [(r["prn"], r["code_phase_samples"], r["doppler_bin"]) for r in res[fam] if r], "truth", sats, file=sys.stderr)
     # truth check on the strongest bin of each simulated satellite's plane (with two integrations of 32000 cells the
     # reference's max/mean > 7 test passes on noise at an early bin — the oracle agrees, tests/test_gpu_generalised.py — so
     # the early-exit result of an E1-geometry code is not where its satellite is)
-    blk = grid.search_dev(ptrs, A.FMT_I8_IQ)
-    if world > 1 and not debug_gloo:
-        dist.all_gather_into_tensor(gathered, blk)
-        gfin = gathered.cpu().numpy()
-    elif world > 1:
-        h = [torch.empty(blk.numel(), dtype=torch.int32) for _ in range(world)]
-        dist.all_gather(h, blk.cpu())
-        gfin = torch.cat(h).numpy()
-    else:
-        gfin = blk.cpu().numpy()
-    asm = Dm.grid_assemble(gfin, fams, world, D)
     ok = True
     for fi, f in enumerate(fams):
         for prn, cp in truth[f.name].items():
             mxp, amp = asm[fi][0][prn - 1].view(np.float32), asm[fi][1][prn - 1].view(np.uint32)
             ok = ok and int(amp[int(np.argmax(mxp))]) == cp
-    ok = ok and all(res[fam][prn - 1] is not None for fam in ("gps", "b1i") for prn in truth[fam])
+    ok = ok and all(res[fam][prn - 1] is not None and res[fam][prn - 1]["code_phase_samples"] == truth[fam][prn]
+                    for fam in ("gps", "b1i") for prn in truth[fam])
     shards = [sum(c for _, _, c in Dm.shard_grid(fams, world, r)) for r in range(world)]
     out = {"workload": "90-code grid: 32 GPS (N=8000, 10 ms) + 36 E1-geometry stand-in codes (N=32000, 2 x 4 ms) + 22 BeiDou B1I (N=8000, "
                        "10 ms), 41 bins, one 10 ms snapshot at 8 Msps int8; contiguous code blocks per rank + one all-gather + decision",
            "scaling": "strong", "n_gpus": world, "codes_per_rank": shards, "cells_per_dwell": grid.cells(),
            "ms_per_dwell": dt * 1e3, "cells_per_s": grid.cells() / dt, "simulated_satellites_found_at_true_phase": bool(ok),
-           "note": "host decision per dwell (D2H of the gathered 47 KB + gm_acq_decide_host): no overlap between dwells"}
+           "exchange": ("gm_comm_allgather_words (RCCL through the C ABI)" if (native_comm and world > 1 and not debug_gloo)
+                        else "gloo through host memory (rehearsal)" if (world > 1 and debug_gloo) else "torch.distributed nccl" if world > 1 else None),
+           "decision": "on the device (gm_grid_assemble_dev + gm_acq_decide_planes_dev per family); results fetched once after the timed dwells"}
     grid.close()
     return out
 
@@ -640,11 +699,16 @@ def cfg1_leg(torch, dev, stream, ca, A, synth, with_cpu=False):
             "prns_found": found, "prns_in_scene": sorted(s["prn"] for s in sc["sats"])}
 
 
-def cfg5_leg(torch, stream, T):
-    """BASELINE configs[4] geometry: 36 channels, 50 Msps, 4092-chip codes at 1.023 Mcps (4 ms period, 200 000 samples),
-    BOC(1,1), five arms (VE/E/P/L/VL).  The reference has no Galileo/BOC code: stand-in random codes, GPU-only number."""
+def cfg5_leg(torch, stream, T, world=1, rank=0, dist=None, dev=None, debug_gloo=False):
+    """BASELINE configs[4]: 36 channels, 50 Msps, 4092-chip codes at 1.023 Mcps (4 ms period, 200 000 samples), BOC(1,1), five
+    arms (VE/E/P/L/VL), "1 -> 8 GPU scaling": STRONG scaling — the 36 channels are sharded over the ranks in contiguous blocks
+    (5/5/5/5/4/4/4/4 at 8 ranks), every rank holds the same IF stream in its own ring mirror, no collective on the data path
+    (channels are independent, do_tracking.rs:364-371); ch_msps = 36 x 50 x signal time / the slowest rank's wall time.
+    The reference has no Galileo/BOC code: stand-in random codes, GPU-only number."""
+    from gnss_sdr_rs_amd import distributed as Dm
     fs, L, rate, C, periods = 50.0e6, 4092, 1.023e6, 36, 6
     n = int(round(fs / (rate / L)))
+    mine = Dm.shard_prns(list(range(C)), world, rank)
     rng = np.random.default_rng(5)
     codes = np.where(rng.integers(0, 2, (C, L)) > 0, 1, -1).astype(np.int8)
     tt = np.arange((periods + 1) * n, dtype=np.float64)
@@ -653,37 +717,62 @@ def cfg5_leg(torch, stream, T):
     ci = np.floor(cp).astype(np.int64)
     x = (rng.standard_normal(tt.size) + 1j * rng.standard_normal(tt.size)).astype(np.complex64) * np.float32(8.0)
     dopp = rng.uniform(-2000, 2000, C)
-    for c in range(C):   # all satellites code-aligned at sample 0 (keeps the generator cheap)
+    for c in range(C):   # all satellites code-aligned at sample 0 (keeps the generator cheap); the whole sky on every rank
         x += (np.float32(0.6) * codes[c][ci] * sub * np.exp(2j * np.pi * dopp[c] * tt / fs)).astype(np.complex64)
     ring = T.MulticastRingBuffer(1 << 21)
     ring.write_samples(x)
-    mgr = T.TrackingManager(fs, n_channels=C, n_arms=5, code_index_mode=T.CODE_INDEX_FIXED, early_late_space=0.25,
-                            very_early_late_space=0.6, boc11=True, codes=codes, nominal_code_rate=rate)
+    Cl = len(mine)
+    mgr = T.TrackingManager(fs, n_channels=Cl, n_arms=5, code_index_mode=T.CODE_INDEX_FIXED, early_late_space=0.25,
+                            very_early_late_space=0.6, boc11=True, codes=codes[mine], nominal_code_rate=rate)
     mgr.set_stream(stream)
 
     def restart():
-        for c in range(C):
-            mgr.channels[c].start(dict(prn=c + 1, code_phase_samples=0, code_phase_chips=0.0, carrier_freq=float(dopp[c]) + 10.0,
+        for j, c in enumerate(mine):
+            mgr.channels[j].start(dict(prn=j + 1, code_phase_samples=0, code_phase_chips=0.0, carrier_freq=float(dopp[c]) + 10.0,
                                        fs=fs, mag_relative=1.0, sample_global_index=0, doppler_bin=0))
-            mgr.channels[c].set_state(code_rate=rate, num_samples_per_code=n, carrier_phase=0.0, code_error=0.0,
+            mgr.channels[j].set_state(code_rate=rate, num_samples_per_code=n, carrier_phase=0.0, code_error=0.0,
                                       carrier_error=0.0, lost_counter=0)
-    restart()
-    mgr.update_all_dev(ring, periods)
-    mgr.synchronize()
-    locked = sum(1 for c in mgr.channels if c.is_active() and c.lost_counter == 0)
+    err, locked = None, 0
+    try:
+        restart()
+        mgr.update_all_dev(ring, periods)
+        mgr.synchronize()
+        locked = sum(1 for c in mgr.channels if c.is_active() and c.lost_counter == 0)
+    except Exception as e:      # a rank that fails must not leave the others waiting at the barrier below
+        err = repr(e)
+    if world > 1:
+        flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if debug_gloo else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            err = err or "another rank failed"
+    if err:
+        return {"error": err}
     times = []
     for _ in range(3):
         restart()
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
         mgr.update_all_dev(ring, periods)
         mgr.synchronize()
-        times.append(time.perf_counter() - t0)
+        t1 = time.perf_counter() - t0
+        if world > 1:      # the job is done when the slowest rank is
+            tm = torch.tensor([t1], dtype=torch.float64, device="cpu" if debug_gloo else dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            t1 = float(tm.item())
+        times.append(t1)
     dt = float(np.median(times))
     mgr.close()
     ring.close()
+    if world > 1:
+        lk = torch.tensor([locked], dtype=torch.int64, device="cpu" if debug_gloo else dev)
+        dist.all_reduce(lk, op=dist.ReduceOp.SUM)
+        locked = int(lk.item())
     sig_s = periods * n / fs
     return {"workload": "36 ch x 50 Msps, 4092-chip BOC(1,1), 5 arms, 4 ms code periods (no reference code: stand-in codes)",
+            "scaling": "strong", "n_gpus": world,
+            "channels_per_rank": [len(Dm.shard_prns(list(range(C)), world, r)) for r in range(world)],
             "ch_msps": C * fs / 1e6 * (sig_s / dt), "ms_per_code_period": dt / periods * 1e3, "channels_locked": locked,
             "algorithmic_GBs": C * n * 8 * periods / dt / 1e9}
 
@@ -783,8 +872,28 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0,
         trk_cpu = tracking_cpu_baseline(sc, fs, n, cpu_seconds)
     return {"metric": "tracking ch×Msps", "cpu_baseline": trk_cpu, "value": ch_msps * world, "unit": "ch*Msps", "channels_per_gpu": C,
             "fs_msps": 25.0, "epochs": epochs, "ms_per_epoch": dt / epochs * 1e3, "channels_locked": locked,
-            "roofline": {"bound": "hbm", "kernel": "trk_persistent_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_epoch": bytes_per_epoch}}
+            "roofline": trk_roofline(gbs, bytes_per_epoch, epochs, C)}
+
+
+def trk_roofline(gbs, bytes_per_epoch, epochs, C):
+    """The tracking kernel's record: its byte model is SURVEY 8d's (every channel streams its own window, C*n*8 bytes per
+    epoch), but an epoch of one channel is a dependent chain (correlate -> reduce -> exchange -> loop filters -> next NCO
+    values, do_tracking.rs:160-302), so the bound at C = 32 is that chain's latency, not bytes: `frac` is the share of the
+    HBM peak the model bytes reach, `traffic` the measured fabric bytes per epoch (channels share the ring window through L2)."""
+    r = {"bound": "latency-chain", "kernel": "trk_persistent_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_epoch": bytes_per_epoch, "traffic": None,
+         "traffic_over_algorithmic": None,
+         "reading": "one epoch per channel is a serial chain of ~3 us (DESIGN 4.3); HBM sees a few % of its peak"}
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        per_launch, ep = t.get("trk_persistent_kernel_hbm_bytes_per_launch"), t.get("trk_persistent_kernel_epochs_per_launch", 480)
+        if per_launch and C == 32:
+            r["traffic"] = per_launch / ep
+            r["traffic_over_algorithmic"] = per_launch / ep / bytes_per_epoch
+            r["traffic_source"] = "profiles/traffic.json (2 x FETCH_SIZE + WRITE_SIZE per launch / %d epochs per launch)" % ep
+    except Exception:
+        pass
+    return r
 
 
 def tracking_cpu_baseline(sc, fs, n, budget_s):

@@ -96,6 +96,11 @@ SIGNATURES = {
     "gm_comm_destroy": (_i, [_vp]),
     "gm_comm_info": (_i, [_vp, _vp, _vp]),
     "gm_acq_allgather_metrics": (_i, [_vp, _vp, _vp, _vp]),
+    "gm_acq_allgather_metrics_async": (_i, [_vp, _vp, _vp, _vp]),
+    "gm_comm_wait": (_i, [_vp, _vp]),
+    "gm_comm_allgather_words": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "gm_grid_assemble_dev": (_i, [_vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp]),
+    "gm_acq_decide_planes_dev": (_i, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _u32, _f, _f, _f, _i, _u64, _vp, _vp, _vp]),
     "gm_acq_fetch_results": (_i, [_vp, _u32, _vp, _vp]),
     "gm_acq_decide_host": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _f, _f, _f, _u64, _vp, _vp]),
     "gm_acq_synchronize": (_i, [_vp]),

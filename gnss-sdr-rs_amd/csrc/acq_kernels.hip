@@ -87,8 +87,11 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     // Grid tail: the items of an XCD beyond its last FULL round of resident workgroups (slot >= split_from) are cut into
     // split_k parts of n_int / split_k integrations each, so the last round is made of short workgroups (1312 items on
     // 512 slots are 2.56 rounds: whole items would take 3, fifths take 2.6).  The parts of an item meet through HBM: each
-    // stores its partial power plane write-through, the one whose ticket comes last adds the split_k planes in part order
-    // and does the reduction.  Placement is for speed only: correctness does not depend on where the parts run.
+    // stores the power plane of EVERY integration it ran write-through, and the part whose ticket comes last adds the n_int
+    // planes in integration order — the very additions, in the very order, an uncut item makes in registers — and does the
+    // reduction.  So a cell's {max, argmax, sum} do not depend on whether its item was cut, i.e. not on how many workers
+    // share the launch: a sharded grid equals the single-GPU grid word for word (tests/test_gpu_mixed_grid.py).
+    // Placement is for speed only: correctness does not depend on where the parts run.
     const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3;
     int slot = wslot, part = 0, parts = 1;
     if (wslot >= split_from) {
@@ -161,6 +164,13 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     if constexpr (STAMPS) stbase = (blockIdx.x == 0 && (tid & 63) == 0 && PL::T / 64 <= 8) ? g_corr_stamps : nullptr;
     const int wv = tid >> 6;
     const int m_per = n_int / parts, m_begin = part * m_per, m_end = m_begin + m_per;
+    constexpr bool CAN_SPLIT = PL::RL % 4 == 0 && !STAMPS;
+    constexpr int SLAB = PL::ITL * PL::RL * PL::T;                                // floats per power plane, register order
+    // a cut item's planes: [n_int][SLAB] floats at its own place in the scratch (parts == 1: an empty descriptor, never used)
+    const size_t item_plane0 = parts > 1 ? (size_t(xcd) * split_items + (slot - split_from)) * size_t(n_int) : 0;
+    const __amdgpu_buffer_rsrc_t srs = make_rsrc(split_scratch + item_plane0 * SLAB, parts > 1 ? unsigned(n_int) * SLAB * 4u : 0u);
+    float keep = parts > 1 ? 0.0f : 1.0f;
+    asm volatile("" : "+v"(keep));        // a VGPR operand: an SGPR source would put the sixteen fmas of a lane into the half-rate class
     for (int m = m_begin; m < m_end; ++m) {
         // all pass-0 loads of this transform are issued here, pairs as 16-byte loads (PairLayout)
         PLd xq[PL::IT0], cq[(KEEP_CODE || !CODE_PAIRED) ? 1 : PL::IT0];
@@ -181,7 +191,10 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
             // result_buf[i] *= conj(code[i])  (:184-186), num-complex Mul, no FMA
             return cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
         };
-        auto out = [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y); };   // += norm_sqr() (:190-192)
+        // acc += norm_sqr() (:190-192).  Written acc*keep + p with keep = 1: one rounding of the same sum, bit for bit
+        // acc + p.  A part of a cut item runs with keep = 0: every integration's plane starts from 0 + p = p without any
+        // instruction zeroing the sums after the plane's store (see the store below for why none may)
+        auto out = [&](int it, int r, cf v) { acc[it][r] = __builtin_fmaf(acc[it][r], keep, v.x * v.x + v.y * v.y); };
         if constexpr (!STAMPS) {
             lds_transform<PL, true>(in, out, lds, tw, tid);
         } else {   // diagnostic variant: the same phases with stamps next to the barriers
@@ -202,23 +215,27 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
             Fft<PL, true>::last_stage1(vl, lds, tw, tid);
             Fft<PL, true>::last_stage2(vl, out, tid);
         }
+        if constexpr (CAN_SPLIT) {
+            if (parts > 1) {      // a part of a cut item: this integration's plane goes out on its own
+                // NOTHING may write these registers in the instructions that follow: a `buffer_store_dwordx4 ... sN offen`
+                // (scalar offset register) directly followed by v_mov 0 of its data registers stored zeros for a few lanes now
+                // and then on gfx950 — hipcc inserts no wait state for this form — which cost the plane sums 0.01-0.5 %
+                // (found by tools/split_probe.py).  The next writer of acc is the next transform's last pass, far away.
+#pragma unroll
+                for (int it = 0; it < PL::ITL; ++it)
+#pragma unroll
+                    for (int r4 = 0; r4 < PL::RL / 4; ++r4) {
+                        u32x4 v;
+                        v.x = __float_as_uint(acc[it][4 * r4 + 0]); v.y = __float_as_uint(acc[it][4 * r4 + 1]);
+                        v.z = __float_as_uint(acc[it][4 * r4 + 2]); v.w = __float_as_uint(acc[it][4 * r4 + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, srs, tid * 16, (m * SLAB + (it * (PL::RL / 4) + r4) * PL::T * 4) * 4, 16);   // sc1: write-through
+                    }
+            }
+        }
     }
 
-    if constexpr (PL::RL % 4 == 0 && !STAMPS) {
+    if constexpr (CAN_SPLIT) {
         if (parts > 1) {
-            constexpr int SLAB = PL::ITL * PL::RL * PL::T;                        // floats per partial plane, register order
-            const size_t item_slab = (size_t(xcd) * split_items + (slot - split_from)) * parts;
-            const __amdgpu_buffer_rsrc_t srs =
-                make_rsrc(split_scratch + item_slab * SLAB, unsigned(parts) * SLAB * 4u);
-#pragma unroll
-            for (int it = 0; it < PL::ITL; ++it)
-#pragma unroll
-                for (int r4 = 0; r4 < PL::RL / 4; ++r4) {
-                    u32x4 v;
-                    v.x = __float_as_uint(acc[it][4 * r4 + 0]); v.y = __float_as_uint(acc[it][4 * r4 + 1]);
-                    v.z = __float_as_uint(acc[it][4 * r4 + 2]); v.w = __float_as_uint(acc[it][4 * r4 + 3]);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, srs, tid * 16, (part * SLAB + (it * (PL::RL / 4) + r4) * PL::T * 4) * 4, 16);   // sc1: write-through
-                }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left
             __syncthreads();                                         // ... and every wave's
             __shared__ int s_last;
@@ -229,12 +246,13 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
             }
             __syncthreads();
             if (!s_last) return;
-            // the last arriver: planes added in part order (the same order whoever comes last), sc1 loads bypass this CU's L1
+            // the last arriver: the n_int planes added in integration order — (((0 + p0) + p1) + ...), what an uncut item's
+            // registers hold — whoever comes last; sc1 loads bypass this CU's L1.  (Its own stores completed at the vmcnt(0) above.)
 #pragma unroll
             for (int it = 0; it < PL::ITL; ++it)
 #pragma unroll
                 for (int r = 0; r < PL::RL; ++r) acc[it][r] = 0.0f;
-            for (int q = 0; q < parts; ++q) {
+            for (int q = 0; q < n_int; ++q) {
 #pragma unroll
                 for (int it = 0; it < PL::ITL; ++it)
 #pragma unroll
@@ -558,13 +576,14 @@ template <class PL> struct Launch {
             // search) leaves most of the chip idle: then EVERY item is cut, which multiplies the parallelism by k
             const bool all = share <= slots;
             for (int k = 2; k <= GM_CORR_SPLIT_MAX_K; ++k)
-                if (n_int % k == 0 && (!all || share * k <= GM_CORR_SPLIT_MAX_SLABS / 8)) split_k = k;
+                if (n_int % k == 0 && (!all || share * n_int <= GM_CORR_SPLIT_MAX_SLABS / 8)) split_k = k;
             if (split_env > 1 && split_env <= GM_CORR_SPLIT_MAX_K && n_int % split_env == 0) split_k = split_env;
             if (split_k > 1) {
                 split_items = items_env > 0 ? items_env : (all ? share : (slots + split_k - 1) / split_k);
                 if (split_items > share) split_items = share;
                 if (split_items > GM_CORR_SPLIT_MAX_ITEMS / 8) split_items = GM_CORR_SPLIT_MAX_ITEMS / 8;
-                if (split_items * split_k > GM_CORR_SPLIT_MAX_SLABS / 8) split_items = GM_CORR_SPLIT_MAX_SLABS / 8 / split_k;
+                if (split_items * n_int > GM_CORR_SPLIT_MAX_SLABS / 8) split_items = GM_CORR_SPLIT_MAX_SLABS / 8 / n_int;   // one plane per integration
+                if (split_items <= 0) { split_items = 0; split_k = 1; }
                 split_from = share - split_items;
             }
         }

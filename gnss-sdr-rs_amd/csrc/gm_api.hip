@@ -1178,7 +1178,9 @@ static int trk_reserve_epochs(gm_trk* t, uint32_t e) {
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
     const size_t n = size_t(e) * t->C;
     HIPC(hipMalloc(&t->d_outs, n * sizeof(gm_trk_out)));
-    HIPC(hipMemset(t->d_outs, 0, n * sizeof(gm_trk_out)));   // with three arms the persistent kernel writes the six live sums only: ive..qvl stay 0
+    // with three arms the persistent kernel writes the six live sums only: ive..qvl stay 0.  Ordered on the handle's stream
+    // (a non-blocking stream does not synchronise with the NULL stream a plain hipMemset runs on)
+    HIPC(hipMemsetAsync(t->d_outs, 0, n * sizeof(gm_trk_out), t->stream));
     HIPC(hipMalloc(&t->d_proc, n)); HIPC(hipMalloc(&t->d_lost, n)); HIPC(hipMalloc(&t->d_lostprn, n));
     t->epochs_cap = e;
     return GM_OK;
@@ -1499,7 +1501,8 @@ static int trk_check_error(gm_trk* t) {
     const int err = *static_cast<volatile int*>(t->d_error);      // the stream has been synchronised by the caller
     if (err) {
         *t->d_error = 0;
-        (void)hipMemset(t->d_error_dev, 0, sizeof(int));
+        (void)hipMemsetAsync(t->d_error_dev, 0, sizeof(int), t->stream);
+        (void)hipStreamSynchronize(t->stream);
         return set_err(GM_ERR_HIP, "tracking: inter-workgroup exchange timed out (workgroups of a channel not co-resident?)");
     }
     return GM_OK;
@@ -1885,6 +1888,11 @@ struct gm_comm {
     ncclComm_t comm = nullptr;
     uint32_t* d_stage = nullptr;   // [nranks][3][PD] as the all-gather lays it out
     size_t stage_words = 0;
+    // overlapped exchange (gm_acq_allgather_metrics_async): the collective runs on the communicator's own stream between
+    // two events, so the next dwell's kernels on the handle's stream do not wait for it
+    hipStream_t xs = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    bool pending = false;
 };
 
 extern "C" {
@@ -1916,6 +1924,9 @@ int gm_comm_init(int nranks, int rank, const uint8_t id[GM_COMM_ID_BYTES], gm_co
 int gm_comm_destroy(gm_comm* c) {
     if (!c) return GM_OK;
     if (c->device >= 0) hipSetDevice(c->device);
+    if (c->xs) { hipStreamSynchronize(c->xs); hipStreamDestroy(c->xs); }
+    if (c->ev_in) hipEventDestroy(c->ev_in);
+    if (c->ev_out) hipEventDestroy(c->ev_out);
     if (c->comm) rccl().CommDestroy(c->comm);
     hipFree(c->d_stage);
     delete c;
@@ -1929,21 +1940,111 @@ int gm_comm_info(gm_comm* c, int* nranks, int* rank) {
     return GM_OK;
 }
 
+static int comm_gather_regroup(gm_acq* a, gm_comm* c, const void* d_local, void* d_all, hipStream_t st);
 int gm_acq_allgather_metrics(gm_acq* a, gm_comm* c, const void* d_local, void* d_all) {
     if (!a || !c || !d_all) return set_err(GM_ERR_INVALID_ARG, "null handle/comm/output");
     if (a->device != c->device) return set_err(GM_ERR_INVALID_ARG, "handle and communicator live on different devices");
     if (int rc = ensure_device(a->device)) return rc;
+    return comm_gather_regroup(a, c, d_local, d_all, a->stream);
+}
+
+static int comm_gather_regroup(gm_acq* a, gm_comm* c, const void* d_local, void* d_all, hipStream_t st) {
     const size_t PD = size_t(a->P) * a->D, words = 3 * PD;
     const uint32_t* src = d_local ? static_cast<const uint32_t*>(d_local) : a->d_metrics;
     if (c->stage_words < words * c->nranks) {
+        if (c->xs) HIPC(hipStreamSynchronize(c->xs));
         hipFree(c->d_stage); c->d_stage = nullptr; c->stage_words = 0;
         HIPC(hipMalloc(&c->d_stage, words * c->nranks * sizeof(uint32_t)));
         c->stage_words = words * c->nranks;
     }
-    RCCLC(rccl().AllGather(src, c->d_stage, words, ncclInt32, c->comm, a->stream));
+    RCCLC(rccl().AllGather(src, c->d_stage, words, ncclInt32, c->comm, st));
     const uint32_t total = uint32_t(words * c->nranks);
-    regroup_metrics_kernel<<<(total + 255) / 256, 256, 0, a->stream>>>(c->d_stage, static_cast<uint32_t*>(d_all),
-                                                                      uint32_t(c->nranks), uint32_t(PD));
+    regroup_metrics_kernel<<<(total + 255) / 256, 256, 0, st>>>(c->d_stage, static_cast<uint32_t*>(d_all),
+                                                                 uint32_t(c->nranks), uint32_t(PD));
+    HIPC(hipGetLastError());
+    return GM_OK;
+}
+
+int gm_acq_allgather_metrics_async(gm_acq* a, gm_comm* c, const void* d_local, void* d_all) {
+    if (!a || !c || !d_all) return set_err(GM_ERR_INVALID_ARG, "null handle/comm/output");
+    if (a->device != c->device) return set_err(GM_ERR_INVALID_ARG, "handle and communicator live on different devices");
+    if (int rc = ensure_device(a->device)) return rc;
+    if (!c->xs) {
+        HIPC(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+        HIPC(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        HIPC(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    }
+    HIPC(hipEventRecord(c->ev_in, a->stream));          // everything enqueued so far on the handle's stream (the search)
+    HIPC(hipStreamWaitEvent(c->xs, c->ev_in, 0));
+    if (int rc = comm_gather_regroup(a, c, d_local, d_all, c->xs)) return rc;
+    HIPC(hipEventRecord(c->ev_out, c->xs));
+    c->pending = true;
+    return GM_OK;
+}
+
+int gm_comm_wait(gm_comm* c, void* hip_stream) {
+    if (!c) return set_err(GM_ERR_INVALID_ARG, "null comm");
+    if (int rc = ensure_device(c->device)) return rc;
+    if (c->pending) {
+        HIPC(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), c->ev_out, 0));
+        c->pending = false;
+    }
+    return GM_OK;
+}
+
+int gm_comm_allgather_words(gm_comm* c, const void* d_local, void* d_all, size_t words, void* hip_stream) {
+    if (!c || !d_local || !d_all || !words) return set_err(GM_ERR_INVALID_ARG, "null comm/buffer or zero words");
+    if (int rc = ensure_device(c->device)) return rc;
+    RCCLC(rccl().AllGather(d_local, d_all, words, ncclInt32, c->comm, reinterpret_cast<hipStream_t>(hip_stream)));
+    return GM_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// gathered [R][3][pmax][D] -> out [3][n_rows][D], row i taken from block row_map[i] = rank * pmax + row
+__global__ void grid_assemble_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ row_map, uint32_t pmax,
+                                     uint32_t D, uint32_t n_rows, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3u * n_rows * D) return;
+    const uint32_t e = i % D, row = (i / D) % n_rows, q = i / (D * n_rows);
+    const uint32_t src = row_map[row], r = src / pmax, k = src - r * pmax;
+    out[i] = in[((size_t(r) * 3u + q) * pmax + k) * D + e];
+}
+}  // namespace
+
+extern "C" {
+
+int gm_grid_assemble_dev(const void* d_gathered, uint32_t nranks, uint32_t p_max, uint32_t n_bins, const uint32_t* d_row_map,
+                         uint32_t n_rows, void* d_out, void* hip_stream) {
+    if (!d_gathered || !d_row_map || !d_out || !nranks || !p_max || !n_bins || !n_rows)
+        return set_err(GM_ERR_INVALID_ARG, "null buffer or zero dimension");
+    if (n_rows > nranks * p_max) return set_err(GM_ERR_OUT_OF_RANGE, "more rows than the gathered blocks hold");
+    if (int rc = ensure_device(g_device)) return rc;
+    const uint32_t total = 3u * n_rows * n_bins;
+    grid_assemble_kernel<<<(total + 255) / 256, 256, 0, reinterpret_cast<hipStream_t>(hip_stream)>>>(
+        static_cast<const uint32_t*>(d_gathered), d_row_map, p_max, n_bins, n_rows, static_cast<uint32_t*>(d_out));
+    HIPC(hipGetLastError());
+    return GM_OK;
+}
+
+int gm_acq_decide_planes_dev(const float* d_max, const uint32_t* d_argmax, const float* d_sum, uint32_t n_prn, uint32_t n_bins,
+                             const uint8_t* d_prn_ids, const float* d_table_freq, uint32_t fft_size, float fs, float code_rate,
+                             float threshold, int decision_mode, uint64_t local_tail, gm_acq_result* d_results, uint8_t* d_found,
+                             void* hip_stream) {
+    if (!d_max || !d_argmax || !d_sum || !d_prn_ids || !d_table_freq || !d_results || !d_found || !n_prn || !n_bins || fft_size < 2)
+        return set_err(GM_ERR_INVALID_ARG, "null buffer or zero dimension");
+    if (int rc = ensure_device(g_device)) return rc;
+    gm::DecideArgs da;
+    da.mmax = d_max; da.margmax = d_argmax; da.msum = d_sum;
+    da.table_freq = d_table_freq; da.prn_ids = d_prn_ids;
+    da.mask_lo = ~0ull;
+    da.n_prn = int(n_prn); da.n_bins = int(n_bins); da.fft_size = int(fft_size);
+    da.fs = fs; da.threshold = threshold; da.code_rate = code_rate;
+    da.best_bin_mode = decision_mode == GM_DECIDE_BEST_BIN ? 1 : 0;
+    da.local_tail = local_tail;
+    da.results = d_results; da.found = d_found;
+    gm::launch_decide(reinterpret_cast<hipStream_t>(hip_stream), da);
     HIPC(hipGetLastError());
     return GM_OK;
 }

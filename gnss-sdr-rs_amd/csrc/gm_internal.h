@@ -60,9 +60,10 @@ void launch_fine_mean(hipStream_t, const void* samples, int fmt, uint32_t n, flo
 void launch_fine_final(hipStream_t, const float* rowmax, const uint32_t* rowarg, uint32_t n_rows, int n_sats,
                        float* peak_pow, uint32_t* peak_idx);
 // tail split of the correlation grid: per XCD about one resident round of slots (64) worth of parts, at most
-// GM_CORR_SPLIT_MAX_K parts per item; the scratch holds GM_CORR_SPLIT_MAX_SLABS partial planes, one ticket per item
+// GM_CORR_SPLIT_MAX_K parts per item; the scratch holds GM_CORR_SPLIT_MAX_SLABS power planes — one per integration of every
+// cut item (the merge then adds them in integration order: the uncut order, bit for bit) — and one ticket per item
 constexpr int GM_CORR_SPLIT_MAX_K = 5;
-constexpr int GM_CORR_SPLIT_MAX_SLABS = 8 * 160;
+constexpr int GM_CORR_SPLIT_MAX_SLABS = 8 * 320;
 constexpr int GM_CORR_SPLIT_MAX_ITEMS = 8 * 80;
 const PlanOps* find_plan(int n);
 int list_plans(uint32_t* sizes, int cap);

@@ -72,6 +72,18 @@ class NativeComm:
         """engine: AcquisitionEngine; d_all_ptr: device pointer to 3*nranks*P*D words; asynchronous on the handle's stream."""
         check(lib().gm_acq_allgather_metrics(engine._h, self._h, d_local_ptr, d_all_ptr), "gm_acq_allgather_metrics")
 
+    def allgather_metrics_async(self, engine, d_all_ptr, d_local_ptr=None):
+        """the same exchange on the communicator's own stream (overlaps the next dwell); wait(stream) before d_all is read"""
+        check(lib().gm_acq_allgather_metrics_async(engine._h, self._h, d_local_ptr, d_all_ptr), "gm_acq_allgather_metrics_async")
+
+    def wait(self, stream_ptr):
+        check(lib().gm_comm_wait(self._h, C.c_void_p(stream_ptr)), "gm_comm_wait")
+
+    def allgather_words(self, d_local_ptr, d_all_ptr, words, stream_ptr):
+        """raw all-gather of `words` 32-bit words per rank (the mixed grid's padded blocks), asynchronous on stream_ptr"""
+        check(lib().gm_comm_allgather_words(self._h, d_local_ptr, d_all_ptr, int(words), C.c_void_p(stream_ptr)),
+              "gm_comm_allgather_words")
+
     def close(self):
         if self._h:
             lib().gm_comm_destroy(self._h)
@@ -162,16 +174,28 @@ def grid_decide(assembled, families, local_tail=0, threshold=7.0):
 
 
 class MixedGrid:
-    """This rank's engines for its block of the grid (GPU).  search_dev() fills the padded local block; the caller does
-    the all-gather (torch.distributed / gm_comm) and grid_assemble + grid_decide."""
+    """This rank's engines for its block of the grid (GPU).  search_dev() fills the padded local block; the exchange is the
+    caller's (torch.distributed, or NativeComm.allgather_words: gm_comm); decide_dev() assembles the gathered blocks into the
+    family-major grid and replays the reference's decision per family ON THE DEVICE (gm_grid_assemble_dev +
+    gm_acq_decide_planes_dev); fetch() is the one device-to-host copy.  grid_assemble + grid_decide remain as the host form.
 
-    def __init__(self, families, world, rank):
+    Every engine, the block copy and the decision run on ONE explicit stream: `stream` (a non-zero HIP stream handle, e.g. a
+    torch.cuda.Stream's .cuda_stream), or a stream of the grid's own when none is given (never the NULL stream: its implicit
+    ordering with torch's copies proved unreliable for the first dwell of a multi-engine grid, tools/grid_probe2.py).
+    search_dev() makes the caller's current torch stream wait for the block, decide_dev() makes the grid's stream wait for
+    the caller's (the all-gather that produced `gathered`), so the hand-offs are ordered whatever stream the caller uses."""
+
+    def __init__(self, families, world, rank, stream=None, threshold=7.0, decision_modes=None):
         import torch
         from . import acquisition as A
         self.families, self.world, self.rank = families, world, rank
         self.D = int(families[0].doppler_hz.size)
         assert all(f.doppler_hz.size == self.D for f in families), "one Doppler grid for the whole exchange block"
         self.pmax = grid_pmax(families, world)
+        self.threshold = float(threshold)
+        self.decision_modes = list(decision_modes) if decision_modes is not None else [0] * len(families)
+        self._ext = torch.cuda.ExternalStream(int(stream)) if stream else torch.cuda.Stream()
+        self.stream = int(self._ext.cuda_stream)
         self.parts = []
         row = 0
         for fi, first, cnt in shard_grid(families, world, rank):
@@ -179,22 +203,83 @@ class MixedGrid:
             eng = A.AcquisitionEngine(f.fs, f.f_if, f.fft_size, doppler_hz=f.doppler_hz, prn_ids=f.prn_ids[first:first + cnt],
                                       n_integrations=f.M, codes=None if f.codes is None else f.codes[first:first + cnt],
                                       code_rate=f.code_rate)
+            eng.set_stream(self.stream)
             met = torch.zeros(3 * cnt * self.D, dtype=torch.int32, device="cuda")
             self.parts.append(dict(fi=fi, eng=eng, met=met, row=row, cnt=cnt))
             row += cnt
         self.block = torch.zeros(3 * self.pmax * self.D, dtype=torch.int32, device="cuda")
+        # device-side decision state: where each code of the family-major list sits in the gathered blocks
+        self.total = sum(f.n for f in families)
+        rmap = np.zeros(self.total, np.uint32)
+        base = [0]
+        for f in families:
+            base.append(base[-1] + f.n)
+        self.base = base
+        for r in range(world):
+            row = 0
+            for fi, first, cnt in shard_grid(families, world, r):
+                rmap[base[fi] + first:base[fi] + first + cnt] = r * self.pmax + row + np.arange(cnt, dtype=np.uint32)
+                row += cnt
+        self.d_row_map = torch.from_numpy(rmap.view(np.int32)).cuda()
+        self.d_grid = torch.zeros(3 * self.total * self.D, dtype=torch.int32, device="cuda")
+        self.d_ids = [torch.from_numpy(np.ascontiguousarray(f.prn_ids, np.uint8)).cuda() for f in families]
+        self.d_tf = [torch.from_numpy(f.table_freq()).cuda() for f in families]
+        self.d_res = torch.zeros(self.total * C.sizeof(AcqResult), dtype=torch.uint8, device="cuda")
+        self.d_found = torch.zeros(self.total, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
 
     def set_stream(self, stream_ptr):
+        """move the whole grid to another (non-zero) HIP stream handle"""
+        import torch
+        assert stream_ptr, "an explicit stream: the NULL stream is not accepted"
+        self._ext.synchronize()
+        self._ext = torch.cuda.ExternalStream(int(stream_ptr))
+        self.stream = int(stream_ptr)
         for p in self.parts:
-            p["eng"].set_stream(stream_ptr)
+            p["eng"].set_stream(self.stream)
 
     def search_dev(self, samples_ptr_by_family, fmt):
         """samples_ptr_by_family: {family index: device pointer to that family's n_integrations * fft_size samples}"""
+        import torch
         b = self.block.view(3, self.pmax, self.D)
-        for p in self.parts:
-            p["eng"].search_dev(samples_ptr_by_family[p["fi"]], fmt, p["met"].data_ptr())
-            b[:, p["row"]:p["row"] + p["cnt"], :] = p["met"].view(3, p["cnt"], self.D)
+        caller = torch.cuda.current_stream()
+        self._ext.wait_stream(caller)                # the samples (and whoever last read the block) on the caller's stream
+        with torch.cuda.stream(self._ext):          # the copies follow the searches on the engines' stream
+            for p in self.parts:
+                p["eng"].search_dev(samples_ptr_by_family[p["fi"]], fmt, p["met"].data_ptr())
+                b[:, p["row"]:p["row"] + p["cnt"], :] = p["met"].view(3, p["cnt"], self.D)
+        caller.wait_stream(self._ext)                # the block is complete for whatever the caller enqueues next
         return self.block
+
+    def decide_dev(self, gathered, local_tail=0):
+        """gathered: int32 device tensor [world][3][P_max][D] (this rank's own block when world == 1).  Asynchronous."""
+        import torch
+        L = lib()
+        self._ext.wait_stream(torch.cuda.current_stream())      # `gathered` was produced on the caller's stream
+        check(L.gm_grid_assemble_dev(gathered.data_ptr(), self.world, self.pmax, self.D, self.d_row_map.data_ptr(), self.total,
+                                     self.d_grid.data_ptr(), self.stream), "gm_grid_assemble_dev")
+        g, TD = self.d_grid.data_ptr(), self.total * self.D
+        for fi, f in enumerate(self.families):
+            o = self.base[fi] * self.D * 4
+            check(L.gm_acq_decide_planes_dev(g + o, g + TD * 4 + o, g + 2 * TD * 4 + o, f.n, self.D, self.d_ids[fi].data_ptr(),
+                                             self.d_tf[fi].data_ptr(), f.fft_size, f.fs, f.code_rate, self.threshold,
+                                             self.decision_modes[fi], int(local_tail),
+                                             self.d_res.data_ptr() + self.base[fi] * C.sizeof(AcqResult),
+                                             self.d_found.data_ptr() + self.base[fi], self.stream), "gm_acq_decide_planes_dev")
+
+    def fetch(self):
+        """-> ({family name: [result | None]}, {family index: int32 [3][n_family][D]}) of the last decide_dev (synchronises)."""
+        import torch
+        with torch.cuda.stream(self._ext):
+            raw, found, grid = self.d_res.cpu().numpy(), self.d_found.cpu().numpy(), self.d_grid.cpu().numpy()
+        res = (AcqResult * self.total).from_buffer_copy(raw.tobytes())
+        g = grid.reshape(3, self.total, self.D)
+        out, planes = {}, {}
+        for fi, f in enumerate(self.families):
+            b = self.base[fi]
+            out[f.name] = [res[b + i].as_dict() if found[b + i] else None for i in range(f.n)]
+            planes[fi] = g[:, b:b + f.n, :].copy()
+        return out, planes
 
     def cells(self):
         return sum(f.n * self.D * f.fft_size for f in self.families)
@@ -203,3 +288,11 @@ class MixedGrid:
         for p in self.parts:
             p["eng"].close()
         self.parts = []
+
+
+def baseline_grid_families(scene, b1i_codes):
+    """The GridFamily list of BASELINE configs[3] at its full sizes, for a synth.cfg4_grid_scene: 32 + 36 + 22 = 90 codes."""
+    fs, dop = scene["fs"], scene["doppler_hz"]
+    return [GridFamily("gps", fs, 0.0, 8000, 10, dop, list(range(1, 33))),
+            GridFamily("e1", fs, 0.0, 32000, 2, dop, list(range(1, 37)), codes=scene["e1"], code_rate=1.023e6),
+            GridFamily("b1i", fs, 0.0, 8000, 10, dop, list(range(1, 23)), codes=b1i_codes, code_rate=2.046e6)]

@@ -108,3 +108,34 @@ def tracking_scene(code_table, fs, f_if, prns, n_ms, config_id=3, cn0=47.0, sigm
                          phase=float(rng.uniform(0, 2 * np.pi))))
     x = make_scene(code_table, fs, f_if, n_ms * N, sats, sigma=sigma, config_id=config_id, quantize=quantize)
     return dict(fs=fs, f_if=f_if, N=N, sats=sats, x=x)
+
+
+def cfg4_grid_scene(ca_table, b1i_codes, config_id=4):
+    """BASELINE configs[3]: ONE 10 ms snapshot at 8 Msps complex int8 holding two satellites of each of the grid's three
+    families — 32 GPS L1 C/A codes (N = 8000, 10 x 1 ms), 36 codes of Galileo-E1 GEOMETRY (4092 chips at 1.023 Mcps, N = 32000,
+    2 x 4 ms; stand-in random codes: the ICD's memory codes are hex tables that cannot be derived offline) and 22 BeiDou B1I
+    codes (2046 chips at 2.046 Mcps, N = 8000; `b1i_codes` = the ICD generator's output, gm_b1i_code).  Same bytes on every
+    rank (fixed Philox keys).  -> dict(x complex128 quantised, e1 codes, truth {family: {prn: code start}}, fs, D, doppler_hz)."""
+    fs, D, n = 8.0e6, 41, 80000
+    dop = np.array([-5000.0 + 250.0 * i for i in range(D)], np.float32)
+    e1 = np.where(_rng(config_id, 7).integers(0, 2, (36, 4092)) > 0, 1, -1).astype(np.int8)
+    x = make_scene(ca_table, fs, 0.0, n, [dict(prn_row=4, cn0_dbhz=50.0, doppler_hz=1130.0, code_start=4321),
+                                          dict(prn_row=20, cn0_dbhz=47.0, doppler_hz=-2210.0, code_start=77)],
+                   config_id=config_id, quantize=False)
+
+    def clean(codes, sats, rate):      # the other families are added noise-free on top of the first scene's noise
+        t = np.arange(n, dtype=np.float64)
+        y = np.zeros(n, np.complex128)
+        for s_ in sats:
+            amp = 16.0 * np.sqrt(2.0 * 10.0 ** (s_["cn0_dbhz"] / 10.0) / fs)
+            chip = np.floor((t - s_["code_start"]) * rate / fs).astype(np.int64) % codes.shape[1]
+            y += amp * codes[s_["prn_row"]][chip] * np.exp(2j * np.pi * s_["doppler_hz"] * t / fs)
+        return y
+    x = x + clean(e1, [dict(prn_row=6, cn0_dbhz=49.0, doppler_hz=620.0, code_start=20001),
+                       dict(prn_row=30, cn0_dbhz=47.0, doppler_hz=-3300.0, code_start=555)], 1.023e6)
+    x = x + clean(b1i_codes, [dict(prn_row=2, cn0_dbhz=50.0, doppler_hz=-870.0, code_start=3000),
+                              dict(prn_row=14, cn0_dbhz=48.0, doppler_hz=2950.0, code_start=6100)], 2.046e6)
+    xq = np.clip(np.round(x.real), -127, 127) + 1j * np.clip(np.round(x.imag), -127, 127)
+    truth = {"gps": {5: 4321, 21: 77}, "e1": {7: 20001, 31: 555}, "b1i": {3: 3000, 15: 6100}}
+    truth_doppler = {"gps": {5: 1130.0, 21: -2210.0}, "e1": {7: 620.0, 31: -3300.0}, "b1i": {3: -870.0, 15: 2950.0}}
+    return dict(fs=fs, D=D, doppler_hz=dop, x=xq, e1=e1, truth=truth, truth_doppler=truth_doppler)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GM_ABI_VERSION 2
+#define GM_ABI_VERSION 3
 
 typedef enum {
     GM_OK = 0,
@@ -194,6 +194,29 @@ int gm_comm_info(gm_comm *c, int *nranks, int *rank);
  * every rank and regroup into d_all = [3][nranks*P][D] (rank-major worker order), the layout gm_acq_decide_dev
  * takes with n_prn = nranks*P.  Every rank obtains the same block, so every rank's decision is identical. */
 int gm_acq_allgather_metrics(gm_acq *a, gm_comm *c, const void *d_local, void *d_all);
+/* Overlapped form: the all-gather + regroup are ordered behind everything enqueued so far on the handle's stream but run
+ * on the communicator's own stream, so the next dwell's kernels need not wait for the collective; gm_comm_wait makes
+ * hip_stream wait (on the device, no host synchronisation) for the last such exchange before d_all is consumed.  The
+ * two buffers must not be reused before that wait. */
+int gm_acq_allgather_metrics_async(gm_acq *a, gm_comm *c, const void *d_local, void *d_all);
+int gm_comm_wait(gm_comm *c, void *hip_stream);
+/* The same exchange for a grid that mixes transform sizes (BASELINE configs[3]: GPS + Galileo-E1 geometry + BeiDou B1I
+ * codes in one family-major list; a rank's contiguous block may span two families, i.e. two gm_acq handles): all-gather
+ * of `words` 32-bit words per rank, d_all = [nranks][words], enqueued on hip_stream (NULL: the default stream). */
+int gm_comm_allgather_words(gm_comm *c, const void *d_local, void *d_all, size_t words, void *hip_stream);
+/* Gathered padded blocks [nranks][3][p_max][n_bins] -> ONE family-major grid d_out = [3][n_rows][n_bins]:
+ * d_row_map[i] = rank * p_max + row of the block that holds code i of the family-major list (device, [n_rows]).
+ * Replaces the per-PRN fan-in of do_acquisition.rs:302-313 for the sharded grid; pure data movement. */
+int gm_grid_assemble_dev(const void *d_gathered, uint32_t nranks, uint32_t p_max, uint32_t n_bins,
+                         const uint32_t *d_row_map, uint32_t n_rows, void *d_out, void *hip_stream);
+/* gm_acq_decide_dev without a handle: the reference's decision (do_acquisition.rs:195-238) for `n_prn` codes of ONE
+ * family from device-resident planes (each [n_prn][n_bins]; e.g. a family's rows inside gm_grid_assemble_dev's output),
+ * d_prn_ids / d_table_freq device arrays, results into caller-owned device arrays.  decision_mode: gm_decision_mode.
+ * Asynchronous on hip_stream. */
+int gm_acq_decide_planes_dev(const float *d_max, const uint32_t *d_argmax, const float *d_sum, uint32_t n_prn,
+                             uint32_t n_bins, const uint8_t *d_prn_ids, const float *d_table_freq, uint32_t fft_size,
+                             float fs, float code_rate, float threshold, int decision_mode, uint64_t local_tail,
+                             gm_acq_result *d_results, uint8_t *d_found, void *hip_stream);
 
 /* Replay the reference's decision (running best + ratio test + early exit) on the GPU from a metrics
  * block laid out as above for `n_prn` workers (e.g. an all-gathered one).  prn_ids: host [n_prn].

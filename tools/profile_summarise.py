@@ -51,7 +51,14 @@ def short(name):
     return k
 
 
-out = {}
+def wgs(row):
+    return int(row["Grid_Size"]) // max(1, int(row["Workgroup_Size"]))
+
+
+# FETCH_SIZE / WRITE_SIZE per (kernel, grid size in workgroups): bench.py's other legs launch acq_corr_kernel<Plan8000> at
+# other grid sizes (the 22-code B1I family of the cfg4 grid: 1320 workgroups; one-PRN searches), so a per-name average
+# would mix shapes.  "headline" = the grid size with the most launches of that kernel name (the timed region's).
+out, by_shape = {}, {}
 for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     files = glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True)
     acc = {}
@@ -60,10 +67,19 @@ for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             if row.get("Counter_Name") != ctr:
                 continue
             k = short(row["Kernel_Name"])
-            a = acc.setdefault(k, [0, 0.0])
+            a = acc.setdefault((k, wgs(row)), [0, 0.0])
             a[0] += 1
             a[1] += float(row["Counter_Value"])
-    out[ctr] = {k: {"launches": n, "avg_counter_KB": v / n} for k, (n, v) in acc.items() if k.startswith("gm::")}
+    per = {}
+    for (k, g), (n, v) in acc.items():
+        if k.startswith("gm::"):
+            per.setdefault(k, {})[g] = {"launches": n, "avg_counter_KB": v / n}
+    by_shape[ctr] = per
+    out[ctr] = {}
+    for k, shapes in per.items():
+        head = max(shapes, key=lambda g: shapes[g]["launches"])
+        out[ctr][k] = dict(shapes[head], workgroups=head,
+                           other_grid_sizes={str(g): v for g, v in sorted(shapes.items()) if g != head})
 json.dump(out, open(os.path.join(dst, f"{rr}_pmc_fetch_write.json"), "w"), indent=1)
 by_grid()
 
@@ -72,38 +88,56 @@ def kb(ctr, k):
     return out[ctr].get(k, {}).get("avg_counter_KB", 0.0)
 
 
+def hbm_bytes(k):
+    return int((2 * kb("FETCH_SIZE", k) + kb("WRITE_SIZE", k)) * 1024)
+
+
 # MI355X_MICROARCH.md §HBM: FETCH_SIZE under-reports coalesced streaming reads by 2x on gfx950 (64 B per 128-B request);
 # WRITE_SIZE is exact.  Units: KB.
 traffic = {
-    "source": f"profiles/{rr}_pmc_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py workload)",
+    "source": f"profiles/{rr}_pmc_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py workload); "
+              "per kernel the launches of its most frequent grid size only (the timed region's shape)",
     "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE exact; KB -> bytes x1024",
-    "acq_corr_kernel_hbm_bytes_per_launch": int((2 * kb("FETCH_SIZE", "gm::acq_corr_kernel") + kb("WRITE_SIZE", "gm::acq_corr_kernel")) * 1024),
-    "acq_mix_fft_kernel_hbm_bytes_per_launch": int((2 * kb("FETCH_SIZE", "gm::acq_mix_fft_kernel") + kb("WRITE_SIZE", "gm::acq_mix_fft_kernel")) * 1024),
-    "trk_persistent_kernel_hbm_bytes_per_launch": int((2 * kb("FETCH_SIZE", "gm::trk_persistent_kernel") + kb("WRITE_SIZE", "gm::trk_persistent_kernel")) * 1024),
+    "acq_corr_kernel_hbm_bytes_per_launch": hbm_bytes("gm::acq_corr_kernel"),
+    "acq_corr_kernel_workgroups": out["FETCH_SIZE"].get("gm::acq_corr_kernel", {}).get("workgroups"),
+    "acq_mix_fft_kernel_hbm_bytes_per_launch": hbm_bytes("gm::acq_mix_fft_kernel"),
+    "trk_persistent_kernel_hbm_bytes_per_launch": hbm_bytes("gm::trk_persistent_kernel"),
+    "trk_persistent_kernel_workgroups": out["FETCH_SIZE"].get("gm::trk_persistent_kernel", {}).get("workgroups"),
+    "acq_corr_kernel_N16368_hbm_bytes_per_launch": hbm_bytes("gm::acq_corr_kernel<N=16368>"),
+    "comp_corr_kernel_hbm_bytes_per_launch": {k: hbm_bytes(k) for k in out["FETCH_SIZE"] if "comp_corr" in k},
     "note": "fabric (L2 memory-side) bytes; Infinity-Cache hits are counted, so true HBM traffic is at most this",
 }
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 
 
-# SQ / LDS counters (tools/pmc_sq.sh -> gpurun_out/pmc_sq/{a,b,c}): per-launch averages per kernel
+# SQ / LDS counters (tools/pmc_sq.sh -> gpurun_out/pmc_sq/{a,b,c}): per-launch averages per (kernel, grid size); the entry of
+# a kernel name is its most frequent grid size (the benchmarked shape), the others are listed under "other_grid_sizes"
 sqdir = os.path.join(root, "gpurun_out", "pmc_sq")
-sq = {}
+sq, sq_shapes = {}, {}
 for f in glob.glob(os.path.join(sqdir, "*", "*counter_collection.csv")):
     acc = {}
     for row in csv.DictReader(open(f)):
         k = short(row["Kernel_Name"])
         if not k.startswith("gm::"):
             continue
-        a = acc.setdefault((k, row["Counter_Name"]), [0, 0.0])
+        a = acc.setdefault((k, wgs(row), row["Counter_Name"]), [0, 0.0])
         a[0] += 1
         a[1] += float(row["Counter_Value"])
-    for (k, c), (n, v) in acc.items():
-        sq.setdefault(k, {})[c] = v / n
-        sq[k]["launches_" + os.path.basename(os.path.dirname(f))] = n
+    for (k, g, c), (n, v) in acc.items():
+        e = sq_shapes.setdefault(k, {}).setdefault(g, {})
+        e[c] = v / n
+        e["launches_" + os.path.basename(os.path.dirname(f))] = n
+for k, shapes in sq_shapes.items():
+    head = max(shapes, key=lambda g: max(v for c, v in shapes[g].items() if c.startswith("launches_")))
+    sq[k] = dict(shapes[head], workgroups=head)
+    others = {str(g): v for g, v in sorted(shapes.items()) if g != head}
+    if others:
+        sq[k]["other_grid_sizes"] = others
 if sq:
     sq["_source"] = ("rocprofv3 --pmc (SQ_* / GRBM_* groups in separate passes, --kernel-trace only) -- python3 bench.py --steps 6 "
-                     "--warmup 2 --no-cpu-baseline; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves")
+                     "--warmup 2 --no-cpu-baseline; per kernel the launches of its most frequent grid size (`workgroups`); "
+                     "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves")
     json.dump(sq, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1, sort_keys=True)
     shutil.copy(os.path.join(dst, "sq_counters.json"), os.path.join(dst, f"{rr}_sq_counters.json"))
     print("sq counters:", sorted(k for k in sq if not k.startswith("_")))
