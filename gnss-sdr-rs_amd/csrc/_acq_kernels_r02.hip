@@ -85,15 +85,10 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     // Doppler bin stay on one XCD (at most two), so that bin's M spectra (M*8N bytes) are served by that XCD's L2,
     // and no XCD gets a whole extra bin (41 bins over 8 XCDs used to give XCD 0 a full third round).
     // Grid tail: the items of an XCD beyond its last FULL round of resident workgroups (slot >= split_from) are cut into
-    // n_int parts of ONE integration each, so the last round is made of short workgroups (1312 items on 512 slots are 2.56
-    // rounds: whole items would take 3).  The parts of an item meet through HBM: each stores its integration's power plane
-    // write-through, and the part whose ticket comes last adds the n_int planes in integration order — the very additions, in
-    // the very order, an uncut item makes in registers — and does the reduction.  So a cell's {max, argmax, sum} do not
-    // depend on whether its item was cut, i.e. not on how many workers share the launch: a sharded grid equals the
-    // single-GPU grid word for word (tests/test_gpu_mixed_grid.py).  (Parts of several integrations would have to store a
-    // plane per integration from inside the m loop; a store pending at the loop's back edge makes hipcc wait for every
-    // pass-0 load at once — loads and stores share vmcnt — which cost N = 16368 23 % and N = 8000 4 % on EVERY item.)
-    // Placement is for speed only: correctness does not depend on where the parts run.
+    // split_k parts of n_int / split_k integrations each, so the last round is made of short workgroups (1312 items on
+    // 512 slots are 2.56 rounds: whole items would take 3, fifths take 2.6).  The parts of an item meet through HBM: each
+    // stores its partial power plane write-through, the one whose ticket comes last adds the split_k planes in part order
+    // and does the reduction.  Placement is for speed only: correctness does not depend on where the parts run.
     const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3;
     int slot = wslot, part = 0, parts = 1;
     if (wslot >= split_from) {
@@ -166,7 +161,6 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     if constexpr (STAMPS) stbase = (blockIdx.x == 0 && (tid & 63) == 0 && PL::T / 64 <= 8) ? g_corr_stamps : nullptr;
     const int wv = tid >> 6;
     const int m_per = n_int / parts, m_begin = part * m_per, m_end = m_begin + m_per;
-    constexpr bool CAN_SPLIT = PL::RL % 4 == 0 && !STAMPS;
     for (int m = m_begin; m < m_end; ++m) {
         // all pass-0 loads of this transform are issued here, pairs as 16-byte loads (PairLayout)
         PLd xq[PL::IT0], cq[(KEEP_CODE || !CODE_PAIRED) ? 1 : PL::IT0];
@@ -210,14 +204,12 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
         }
     }
 
-    if constexpr (CAN_SPLIT) {
-        if (parts > 1) {      // a part of a cut item (one integration): its plane goes out; nothing writes these registers again
-            constexpr int SLAB = PL::ITL * PL::RL * PL::T;                        // floats per power plane, register order
-            // the item's planes: [n_int][SLAB] floats at its own place in the scratch
-            const size_t item_plane0 = (size_t(xcd) * split_items + (slot - split_from)) * size_t(n_int);
-            const __amdgpu_buffer_rsrc_t srs = make_rsrc(split_scratch + item_plane0 * SLAB, unsigned(n_int) * SLAB * 4u);
-            // before the wait below (a `buffer_store_dwordx4 ... sN offen` directly followed by a VALU write of its data registers
-            // stored stale lanes now and then on gfx950 — hipcc inserts no wait state for the scalar-offset form; tools/split_probe.py)
+    if constexpr (PL::RL % 4 == 0 && !STAMPS) {
+        if (parts > 1) {
+            constexpr int SLAB = PL::ITL * PL::RL * PL::T;                        // floats per partial plane, register order
+            const size_t item_slab = (size_t(xcd) * split_items + (slot - split_from)) * parts;
+            const __amdgpu_buffer_rsrc_t srs =
+                make_rsrc(split_scratch + item_slab * SLAB, unsigned(parts) * SLAB * 4u);
 #pragma unroll
             for (int it = 0; it < PL::ITL; ++it)
 #pragma unroll
@@ -237,13 +229,12 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
             }
             __syncthreads();
             if (!s_last) return;
-            // the last arriver: the n_int planes added in integration order — (((0 + p0) + p1) + ...), what an uncut item's
-            // registers hold — whoever comes last; sc1 loads bypass this CU's L1.  (Its own stores completed at the vmcnt(0) above.)
+            // the last arriver: planes added in part order (the same order whoever comes last), sc1 loads bypass this CU's L1
 #pragma unroll
             for (int it = 0; it < PL::ITL; ++it)
 #pragma unroll
                 for (int r = 0; r < PL::RL; ++r) acc[it][r] = 0.0f;
-            for (int q = 0; q < n_int; ++q) {
+            for (int q = 0; q < parts; ++q) {
 #pragma unroll
                 for (int it = 0; it < PL::ITL; ++it)
 #pragma unroll
@@ -553,10 +544,10 @@ template <class PL> struct Launch {
         const int share = map_mode == 0 ? per_xcd_even : (map_mode == 1 ? per_xcd_bins : per_xcd_mixed);
         // Grid tail.  When the queue of an XCD runs dry its resident workgroups finish one by one, and the launch ends a
         // whole workgroup duration (M transforms, ~45 us alone on a CU) after the last one started: about half a duration
-        // of idle slots.  The LAST items of every XCD are therefore cut into n_int parts of one integration each, enough of
-        // them that every resident slot ends on a short workgroup (items * n_int ~ slots).  Measured at configs[1]:
-        // 0.229 -> 0.206 ms per launch; the part count and the item count barely matter between (2, 4) and (10, 8).
-        // GM_CORR_SPLIT = 0 / 1 (no cut) and GM_CORR_SPLIT_ITEMS override for diagnostics.
+        // of idle slots.  The LAST items of every XCD are therefore cut into k parts of n_int / k integrations (k = the
+        // largest divisor of n_int up to 5), enough of them that every resident slot ends on a short workgroup
+        // (items * k ~ slots).  Measured at configs[1]: 0.229 -> 0.206 ms per launch; k and the item count barely matter
+        // between (2, 4) and (10, 8).  GM_CORR_SPLIT = 0 / k and GM_CORR_SPLIT_ITEMS override for diagnostics.
         static const int split_env = getenv("GM_CORR_SPLIT") ? atoi(getenv("GM_CORR_SPLIT")) : -1;
         static const int items_env = getenv("GM_CORR_SPLIT_ITEMS") ? atoi(getenv("GM_CORR_SPLIT_ITEMS")) : -1;
         int split_from = share, split_k = 1, split_items = 0;
@@ -566,15 +557,14 @@ template <class PL> struct Launch {
             // share <= slots: the whole grid is resident at once and (for few workers, e.g. the reference's single-PRN
             // search) leaves most of the chip idle: then EVERY item is cut, which multiplies the parallelism by k
             const bool all = share <= slots;
-            // one integration per part (see the kernel): k = n_int, when the scratch holds the planes
-            if (n_int >= 2 && n_int <= GM_CORR_SPLIT_MAX_K && (!all || share * n_int <= GM_CORR_SPLIT_MAX_SLABS / 8)) split_k = n_int;
-            if (split_env == 1) split_k = 1;
+            for (int k = 2; k <= GM_CORR_SPLIT_MAX_K; ++k)
+                if (n_int % k == 0 && (!all || share * k <= GM_CORR_SPLIT_MAX_SLABS / 8)) split_k = k;
+            if (split_env > 1 && split_env <= GM_CORR_SPLIT_MAX_K && n_int % split_env == 0) split_k = split_env;
             if (split_k > 1) {
                 split_items = items_env > 0 ? items_env : (all ? share : (slots + split_k - 1) / split_k);
                 if (split_items > share) split_items = share;
                 if (split_items > GM_CORR_SPLIT_MAX_ITEMS / 8) split_items = GM_CORR_SPLIT_MAX_ITEMS / 8;
-                if (split_items * n_int > GM_CORR_SPLIT_MAX_SLABS / 8) split_items = GM_CORR_SPLIT_MAX_SLABS / 8 / n_int;   // one plane per integration
-                if (split_items <= 0) { split_items = 0; split_k = 1; }
+                if (split_items * split_k > GM_CORR_SPLIT_MAX_SLABS / 8) split_items = GM_CORR_SPLIT_MAX_SLABS / 8 / split_k;
                 split_from = share - split_items;
             }
         }

@@ -59,10 +59,10 @@ struct PlanOps {
 void launch_fine_mean(hipStream_t, const void* samples, int fmt, uint32_t n, float* d_mean);
 void launch_fine_final(hipStream_t, const float* rowmax, const uint32_t* rowarg, uint32_t n_rows, int n_sats,
                        float* peak_pow, uint32_t* peak_idx);
-// tail split of the correlation grid: per XCD about one resident round of slots (64) worth of parts, at most
-// GM_CORR_SPLIT_MAX_K parts per item; the scratch holds GM_CORR_SPLIT_MAX_SLABS power planes — one per integration of every
-// cut item (the merge then adds them in integration order: the uncut order, bit for bit) — and one ticket per item
-constexpr int GM_CORR_SPLIT_MAX_K = 5;
+// tail split of the correlation grid: per XCD about one resident round of slots (64) worth of parts, one part per
+// integration (up to GM_CORR_SPLIT_MAX_K integrations; longer dwells are not cut); the scratch holds GM_CORR_SPLIT_MAX_SLABS
+// power planes — one per part — and there is one ticket per cut item
+constexpr int GM_CORR_SPLIT_MAX_K = 16;
 constexpr int GM_CORR_SPLIT_MAX_SLABS = 8 * 320;
 constexpr int GM_CORR_SPLIT_MAX_ITEMS = 8 * 80;
 const PlanOps* find_plan(int n);

@@ -7,7 +7,10 @@
 #define LAB_PLAN gm::Plan8000
 #endif
 #define GM_FOR_EACH_PLAN(X) X(LAB_PLAN)
-#include "../../gnss-sdr-rs_amd/csrc/acq_kernels.hip"
+#ifndef LAB_SRC
+#define LAB_SRC "../../gnss-sdr-rs_amd/csrc/acq_kernels.hip"
+#endif
+#include LAB_SRC
 #include <cstdio>
 #include <vector>
 #include <random>
