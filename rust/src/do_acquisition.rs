@@ -4,8 +4,11 @@
 //
 // Two shapes are offered:
 //   * AcquisitionWorker — the reference's per-PRN type with the reference's signatures (:130-226): a drop-in for code
-//     that calls `worker.search_satellite(&chunk, &tables, local_tail, n)` one PRN at a time.  Each worker owns a
-//     one-PRN handle built from the tables it is first called with.
+//     that calls `worker.search_satellite(&chunk, &tables, local_tail, n)` one PRN at a time.  The reference takes the
+//     tables per call (:158-163); here each worker owns a one-PRN handle that holds a device copy of them and is rebuilt
+//     whenever the tables it is called with DIFFER IN CONTENT from the ones it was built for: the key is every table's
+//     doppler_freq_hz and length plus three of its phasors (not its address — a Vec rebuilt at the same address with other
+//     Doppler values must not reuse the handle).  Code that edits phasors in place beyond that calls invalidate().
 //   * AcquisitionEngine — all workers of run() in ONE handle (:268-271): `search` is the body of
 //     `workers.par_iter_mut().enumerate().filter_map(..)` (:302-313) as one batched launch; this is the fast path.
 use crate::acquisition::do_acquisition::{AcqError, AcquisitionResult};
@@ -24,13 +27,36 @@ pub struct AcquisitionWorker {
     fft_size: usize,
     freq_sampling_hz: f32,
     h: *mut GmAcq,                 // built on the first search_satellite from the caller's tables
-    tables_key: (usize, usize, usize),   // (first table's data pointer, number of tables, num_integrations) the handle was built for
+    tables_key: Vec<u32>,          // content fingerprint of the tables (+ num_integrations) the handle was built for
+}
+
+/// what identifies a set of Doppler tables by CONTENT: per table its frequency, its length and the phasors at 1, len/2, len-1
+/// (DopplerShiftTable::new makes every phasor a function of (f_if + doppler, fs, i), doppler_shift.rs:14-18)
+fn tables_fingerprint(doppler_table: &[DopplerShiftTable], num_integrations: usize) -> Vec<u32> {
+    let mut k = Vec::with_capacity(2 + 8 * doppler_table.len());
+    k.push(doppler_table.len() as u32);
+    k.push(num_integrations as u32);
+    for t in doppler_table {
+        k.push(t.doppler_freq_hz.to_bits());
+        k.push(t.table.len() as u32);
+        let n = t.table.len();
+        for i in [1usize.min(n.saturating_sub(1)), n / 2, n.saturating_sub(1)] {
+            if n > 0 { k.push(t.table[i].re.to_bits()); k.push(t.table[i].im.to_bits()); }
+        }
+    }
+    k
 }
 unsafe impl Send for AcquisitionWorker {}     // rayon moves one &mut worker to each task (:302-313)
 
 impl AcquisitionWorker {
     pub fn new(prn: u8, fft_size: usize, freq_sampling_hz: f32) -> Self {
-        Self { prn, fft_size, freq_sampling_hz, h: std::ptr::null_mut(), tables_key: (0, 0, 0) }
+        Self { prn, fft_size, freq_sampling_hz, h: std::ptr::null_mut(), tables_key: Vec::new() }
+    }
+
+    /// forget the cached handle: the next search_satellite rebuilds it from the tables it is given
+    pub fn invalidate(&mut self) {
+        if !self.h.is_null() { unsafe { gm_acq_destroy(self.h); } self.h = std::ptr::null_mut(); }
+        self.tables_key.clear();
     }
 
     pub fn search_satellite(
@@ -40,7 +66,7 @@ impl AcquisitionWorker {
         local_tail: usize,
         num_integrations: usize,
     ) -> Option<AcquisitionResult> {
-        let key = (doppler_table.first().map_or(0, |t| t.table.as_ptr() as usize), doppler_table.len(), num_integrations);
+        let key = tables_fingerprint(doppler_table, num_integrations);
         if self.h.is_null() || key != self.tables_key {
             if !self.h.is_null() { unsafe { gm_acq_destroy(self.h); } self.h = std::ptr::null_mut(); }
             // the caller's tables, laid out [n_bins][fft_size] as gm_acq_cfg.tables wants them

@@ -7,19 +7,24 @@
 //     fields between calls (the reference's tests do) sees the same behaviour.  `update` sizes `data_samples` before it
 //     slices it (as committed the reference slices an empty Vec there and panics, :174-177).
 //   * TrackingManager::process_channels (:351-371) is the fast path: all channels in ONE handle on a device mirror of the
-//     ring, `update` for every active channel and up to LOOP_MS code periods in one persistent launch.
+//     ring, `update` for every active channel and up to LOOP_MS code periods in one persistent launch.  NOTE the one
+//     behavioural difference: the reference runs ONE `update` per active channel per call (:364-371); this runs up to
+//     LOOP_MS = 10 per call (as many as the ring holds samples for).  Under run()'s loop (:391-414) the two are the same
+//     sequence of updates; a caller that interleaves its own work between calls sees channels advance by up to 10 code
+//     periods per call.  `gm_trk_update_all(.., 1, ..)` is the one-epoch form (PROCESS_EPOCHS below).
 use crate::acquisition::do_acquisition::{AcquisitionResult, ChannelState};
 use crate::mi355x::*;
 use crate::tracking::do_tracking::{LoopFilter, TrackingMessage};
 use crate::utilities::multicast_ring_buffer::MulticastRingBuffer;
+use crossbeam_channel::{Receiver, Sender};   // the crate's channels (do_tracking.rs:8, main.rs:183-184)
 use num_complex::Complex32;
-use std::sync::mpsc::{Receiver, Sender};
 use std::sync::Arc;
 
 const NUM_OF_CHANNELS: usize = 15;                  // :18
 const PLL_SUM_CARR: f32 = 0.001;                    // :26
 const DLL_SUM_CODE: f32 = 0.001;                    // :27
 const LOOP_MS: usize = 10;                          // :29
+const PROCESS_EPOCHS: usize = LOOP_MS;              // code periods per process_channels call; 1 = the reference's call granularity
 const CODE_INDEX_FAITHFUL: i32 = 0;                 // GPS_CA_CODE_32_PRN[prn] and the saturating late-arm index, as written (:275-276)
 
 fn trk_cfg(fs: f32, n_channels: u32) -> GmTrkCfg {  // zero = the reference's constants (:16-28)
@@ -228,11 +233,11 @@ impl TrackingManager {
             assert_eq!(st, 0, "gm_ring_write_samples: {}", last_error());
             self.mirrored += n;
         }
-        // channels.par_iter_mut().filter(is_active).for_each(update) (:364-371), up to LOOP_MS code periods per call
+        // channels.par_iter_mut().filter(is_active).for_each(update) (:364-371), up to PROCESS_EPOCHS code periods per call
         let n = self.channels.len();
-        let mut lost = vec![0u8; LOOP_MS * n];
+        let mut lost = vec![0u8; PROCESS_EPOCHS * n];
         let mut done = 0u32;
-        let st = unsafe { gm_trk_update_all(self.h, self.ring, LOOP_MS as u32, std::ptr::null_mut(), std::ptr::null_mut(),
+        let st = unsafe { gm_trk_update_all(self.h, self.ring, PROCESS_EPOCHS as u32, std::ptr::null_mut(), std::ptr::null_mut(),
                                             lost.as_mut_ptr(), &mut done) };
         assert_eq!(st, 0, "gm_trk_update_all: {}", last_error());
         for (i, ch) in self.channels.iter_mut().enumerate() {            // the pub fields follow the device state

@@ -101,6 +101,15 @@ extern "C" {
     pub fn gm_comm_init(nranks: c_int, rank: c_int, id: *const u8, out: *mut *mut GmComm) -> c_int;
     pub fn gm_comm_destroy(c: *mut GmComm) -> c_int;
     pub fn gm_acq_allgather_metrics(a: *mut GmAcq, c: *mut GmComm, d_local: *const c_void, d_all: *mut c_void) -> c_int;
+    pub fn gm_acq_allgather_metrics_async(a: *mut GmAcq, c: *mut GmComm, d_local: *const c_void, d_all: *mut c_void) -> c_int;
+    pub fn gm_comm_wait(c: *mut GmComm, hip_stream: *mut c_void) -> c_int;
+    pub fn gm_comm_allgather_words(c: *mut GmComm, d_local: *const c_void, d_all: *mut c_void, words: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn gm_grid_assemble_dev(d_gathered: *const c_void, nranks: u32, p_max: u32, n_bins: u32, d_row_map: *const u32,
+                                n_rows: u32, d_out: *mut c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn gm_acq_decide_planes_dev(d_max: *const f32, d_argmax: *const u32, d_sum: *const f32, n_prn: u32, n_bins: u32,
+                                    d_prn_ids: *const u8, d_table_freq: *const f32, fft_size: u32, fs: f32, code_rate: f32,
+                                    threshold: f32, decision_mode: c_int, local_tail: u64, d_results: *mut GmAcqResult,
+                                    d_found: *mut u8, hip_stream: *mut c_void) -> c_int;
     pub fn gm_acq_decide_dev(a: *mut GmAcq, d_metrics: *const c_void, n_prn: u32, prn_ids: *const u8, local_tail: u64) -> c_int;
     pub fn gm_acq_fetch_results(a: *mut GmAcq, n_prn: u32, results: *mut GmAcqResult, found: *mut u8) -> c_int;
 }

@@ -204,6 +204,30 @@ def test_rust_binding_source_matches_the_abi(gm):
         f = flat(rs[name])
         for w in want:
             assert flat(w) in f, (name, w)
+    # against the reference's own API surface (tests/golden/reference_api_signatures.json, extracted from the reference's
+    # sources by tests/golden/make_api_signatures.py): a name both files import comes from the SAME path (e.g. the channel
+    # ends are crossbeam_channel's, do_tracking.rs:8, not std::sync::mpsc's), and every pub fn that exists in the reference
+    # under the same type has the reference's signature, parameter types included
+    from rs_api import imports, signatures, strip_comments
+    ref = golden("reference_api_signatures.json")
+    n_sig = 0
+    for name in ("doppler_shift.rs", "do_acquisition.rs", "do_tracking.rs", "fft.rs"):
+        text = strip_comments(rs[name])
+        mine, theirs = imports(text), ref[name]["imports"]
+        for sym, path in mine.items():
+            if sym != "*" and sym in theirs:
+                if (name, sym, path) == ("fft.rs", "Complex", "num_complex"):
+                    assert theirs[sym] == "rustfft::num_complex"      # rustfft's re-export of the same type
+                    continue
+                assert path == theirs[sym], (name, sym, path, theirs[sym])
+        for owner, fns in signatures(text).items():
+            for fn, sig in fns.items():
+                want = ref[name]["pub_fn"].get(owner, {}).get(fn)
+                if want is not None:
+                    assert sig == want, (name, owner, fn, sig, want)
+                    n_sig += 1
+    assert n_sig >= 20, n_sig
+    assert imports(strip_comments(rs["do_tracking.rs"]))["Receiver"] == "crossbeam_channel"
     # TrackingChannel keeps the reference's 22 pub fields, in order (do_tracking.rs:88-116)
     assert rust_fields(rs["do_tracking.rs"], "TrackingChannel") == [
         "id", "prn", "state", "lost_counter", "fs", "next_sample_index", "num_samples_per_code", "ca_code_samples", "data_samples",
