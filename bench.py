@@ -249,10 +249,14 @@ def main():
     # the exchange alone (all-gather + regroup of the 3*P*D-word blocks, no search in front), in order on the stream:
     # what a dwell would pay for it without the overlap
     exchange_us = None
-    if world > 1 and not debug_gloo:
+    if world > 1:
         try:
             def xchg():
-                if native_comm:
+                if debug_gloo:      # rehearsal: through host memory
+                    h = [torch.empty(3 * P * D, dtype=torch.int32) for _ in range(world)]
+                    dist.all_gather(h, met2[0].cpu())
+                    gat2[0].copy_(torch.cat(h))
+                elif native_comm:
                     native_comm.allgather_metrics(eng, gat2[0].data_ptr(), met2[0].data_ptr())
                 else:
                     dist.all_gather_into_tensor(gat2[0], met2[0])
@@ -265,7 +269,7 @@ def main():
             for _ in range(50):
                 xchg()
             torch.cuda.synchronize()
-            txe = torch.tensor([(time.perf_counter() - tx) / 50 * 1e6], dtype=torch.float64, device=dev)
+            txe = torch.tensor([(time.perf_counter() - tx) / 50 * 1e6], dtype=torch.float64, device="cpu" if debug_gloo else dev)
             dist.all_reduce(txe, op=dist.ReduceOp.MAX)
             exchange_us = float(txe.item())
         except Exception as e:
