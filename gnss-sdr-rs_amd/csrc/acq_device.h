@@ -9,21 +9,21 @@ namespace gm {
 
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
 
-template <class PL, bool INV, int S> struct MiddlePasses {
+template <class PL, bool INV, int S, bool PFA = false> struct MiddlePasses {
     // st(k): optional diagnostic stamp hook, called only next to barriers (k = 4.. in program order)
     template <class St = NoStamp>
     static __device__ __forceinline__ void run(cf* lds, const cf* tw, int tid, St st = St()) {
         if constexpr (S <= PL::NP - 2) {
             cf v[PL::IT(S)][PL::R[S]];
-            Fft<PL, INV>::template mid_stage1<S>(v, lds, tw, tid);
+            Fft<PL, INV, PFA>::template mid_stage1<S>(v, lds, tw, tid);
             st(4);
             __syncthreads();   // every lane has read its inputs: the image may be overwritten
             st(5);
-            Fft<PL, INV>::template mid_stage2<S>(v, lds, tid);
+            Fft<PL, INV, PFA>::template mid_stage2<S>(v, lds, tid);
             st(6);
             __syncthreads();
             st(7);
-            MiddlePasses<PL, INV, S + 1>::run(lds, tw, tid);
+            MiddlePasses<PL, INV, S + 1, PFA>::run(lds, tw, tid);
         }
     }
 };
@@ -31,19 +31,21 @@ template <class PL, bool INV, int S> struct MiddlePasses {
 // One length-N transform by the whole workgroup: in(it, r) feeds pass 0, out(it, r, value) receives
 // the natural-order outputs.  Safe to call back to back (the first barrier orders the scatter after
 // the previous transform's last LDS reads and after the twiddle-table load).
-template <class PL, bool INV, class In, class Out>
+// PFA (PL::COPRIME plans only): the prime-factor form across the passes — inputs in Pfa<PL>::in_slot order, outputs at
+// Pfa<PL>::out_index, `tw` unused.
+template <class PL, bool INV, bool PFA = false, class In, class Out>
 __device__ __forceinline__ void lds_transform(In&& in, Out&& out, cf* lds, const cf* tw, int tid) {
     {
         cf v0[PL::IT0][PL::R0];
-        Fft<PL, INV>::pass0_stage1(v0, in, tid);
+        Fft<PL, INV, PFA>::pass0_stage1(v0, in, tid);
         __syncthreads();
-        Fft<PL, INV>::pass0_stage2(v0, lds, tid);
+        Fft<PL, INV, PFA>::pass0_stage2(v0, lds, tid);
     }
     __syncthreads();
-    MiddlePasses<PL, INV, 1>::run(lds, tw, tid);
+    MiddlePasses<PL, INV, 1, PFA>::run(lds, tw, tid);
     cf vl[PL::ITL][PL::RL];
-    Fft<PL, INV>::last_stage1(vl, lds, tw, tid);
-    Fft<PL, INV>::last_stage2(vl, out, tid);
+    Fft<PL, INV, PFA>::last_stage1(vl, lds, tw, tid);
+    Fft<PL, INV, PFA>::last_stage2(vl, out, tid);
 }
 
 template <class PL> __device__ __forceinline__ void load_twiddles(cf* tw_lds, const cf* tw_g, int tid) {
@@ -84,7 +86,48 @@ template <class PL> struct PairLayout {
     }
 };
 
-template <class PL> struct CorrLayout { static constexpr bool CODE_PAIRED = PairLayout<PL>::PAIRED; };
+// What the correlation kernel's inverse transform is: the prime-factor form for plans with pairwise coprime radices.
+template <class PL> struct CorrMode { static constexpr bool PFA = PL::COPRIME; };
+// CODE_PAIRED: the kernel takes BOTH arrays as 16-byte pairs (PairLoad); RELAYOUT: the stored spectra / code spectra are not in
+// natural order (paired, PFA-permuted or both), i.e. the code spectra go through pair_codes_kernel once per handle
+template <class PL> struct CorrLayout {
+    static constexpr bool CODE_PAIRED = PairLayout<PL>::PAIRED;
+    static constexpr bool RELAYOUT = PairLayout<PL>::PAIRED || CorrMode<PL>::PFA;
+    // natural spectrum index k -> element slot of the stored array
+    static __host__ __device__ __forceinline__ int slot(int k) {
+        if constexpr (CorrMode<PL>::PFA) return PairLayout<PL>::pos(Pfa<PL>::in_slot(k));
+        else return PairLayout<PL>::pos(k);
+    }
+};
+
+// slot(b + r * NBL) for the writer of a spectrum (b = tid + it * T, r a compile-time constant after unrolling): for the
+// prime-factor order the residues of b are taken once per butterfly and every r costs an add and a conditional subtract per
+// radix instead of a division
+template <class PL> struct SlotWriter {
+    static constexpr int NP = PL::NP, NBL = PL::NB(PL::NP - 1);
+    int b, res[PL::NP];
+    __device__ __forceinline__ void init(int b_) {
+        b = b_;
+        if constexpr (CorrMode<PL>::PFA) {
+#pragma unroll
+            for (int s = 0; s < NP; ++s) res[s] = b_ % PL::R[s];
+        }
+    }
+    __device__ __forceinline__ int slot(int r) const {
+        if constexpr (CorrMode<PL>::PFA) {
+            int e = 0;
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                int x = res[s] + (r * NBL) % PL::R[s];
+                x = x >= PL::R[s] ? x - PL::R[s] : x;
+                e = e * PL::R[s] + x;
+            }
+            return PairLayout<PL>::pos(e);
+        } else {
+            return PairLayout<PL>::pos(b + r * NBL);
+        }
+    }
+};
 
 // one lane's pass-0 elements of one paired array, in registers: R0/2 16-byte loads (+ one 8-byte load when R0 is odd)
 template <class PL> struct PairLoad {

@@ -30,7 +30,10 @@ __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restri
                                                             const cf* __restrict__ tw_fwd,
                                                             cf* __restrict__ spectra, int n_int,
                                                             uint32_t* __restrict__ clear_tickets) {
-    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    // (prime-factor plans stage their outputs through LDS, one padding element per 32: see below)
+    constexpr int STAGE = CorrMode<PL>::PFA ? PL::N + PL::N / 32 + 1 : 0;
+    constexpr int LDS_N = PL::LDS_ELEMS + PL::TW_TOTAL > STAGE ? PL::LDS_ELEMS + PL::TW_TOTAL : STAGE;
+    __shared__ cf lds[LDS_N];
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
     const int d = blockIdx.x / n_int, m = blockIdx.x % n_int;
@@ -42,16 +45,47 @@ __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restri
     const size_t sbase = size_t(m) * PL::N;
     const cf* tab = tables + size_t(d) * PL::N;
     cf* dst = spectra + size_t(blockIdx.x) * PL::N;   // [d][m][k]
-    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
-    lds_transform<PL, false>(
-        [&](int it, int r) {
-            const int idx = (tid + it * PL::T) + r * NB0;
-            const cf s = load_sample(samples, fmt, sbase + idx);
-            const cf t = tab[idx];
-            // multiply_simd_block (doppler_shift.rs:43-58): a*c + (b*d*(-1)), a*d + (b*c*(+1))
-            return cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);
-        },
-        [&](int it, int r, cf val) { dst[PairLayout<PL>::pos((tid + it * PL::T) + r * NBL)] = val; }, lds, tw, tid);   // paired layout
+    constexpr int NB0 = PL::NB(0);
+    // the spectrum is stored in the order the correlation kernel's inverse transform reads it (CorrLayout: pairs and / or the
+    // prime-factor permutation): a permutation on the writer's side costs nothing on the reader's
+    auto in = [&](int it, int r) {
+        const int idx = (tid + it * PL::T) + r * NB0;
+        const cf s = load_sample(samples, fmt, sbase + idx);
+        const cf t = tab[idx];
+        // multiply_simd_block (doppler_shift.rs:43-58): a*c + (b*d*(-1)), a*d + (b*c*(+1))
+        return cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);
+    };
+    if constexpr (!CorrMode<PL>::PFA) {
+        SlotWriter<PL> sw[PL::ITL];
+#pragma unroll
+        for (int it = 0; it < PL::ITL; ++it) sw[it].init(tid + it * PL::T);
+        lds_transform<PL, false>(in, [&](int it, int r, cf val) { dst[sw[it].slot(r)] = val; }, lds, tw, tid);
+    } else {
+        // Prime-factor order: neighbouring spectrum elements sit N/R_last + ... slots apart, so storing them from the registers
+        // would be one 64-byte memory transaction per 8-byte element (stage F 0.054 -> 0.073 ms at N = 16368).  The outputs go
+        // back into the (now free) LDS buffer in natural order instead — one padding element per 32, so that the strided
+        // read-out below spreads over the banks — and leave in slot order, coalesced.
+        constexpr int NBL = PL::NB(PL::NP - 1);
+        {
+            cf v0[PL::IT0][PL::R0];
+            Fft<PL, false>::pass0_stage1(v0, in, tid);
+            __syncthreads();
+            Fft<PL, false>::pass0_stage2(v0, lds, tid);
+        }
+        __syncthreads();
+        MiddlePasses<PL, false, 1>::run(lds, tw, tid);
+        cf vl[PL::ITL][PL::RL];
+        Fft<PL, false>::last_stage1(vl, lds, tw, tid);
+        __syncthreads();                                       // every lane has gathered its inputs: the image may be overwritten
+        Fft<PL, false>::last_stage2(vl, [&](int it, int r, cf val) {
+            const int k = (tid + it * PL::T) + r * NBL;
+            lds[k + (k >> 5)] = val; }, tid);
+        __syncthreads();
+        for (int e = tid; e < PL::N; e += PL::T) {
+            const int k = Pfa<PL>::slot_to_index(e);
+            dst[e] = lds[k + (k >> 5)];
+        }
+    }
 }
 
 // diagnostic phase stamps of the correlation kernel (gm_acq_debug_stamps): s_memtime of lane 0 of every wave of
@@ -127,10 +161,15 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
         }
     }
 
-    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+    // the inverse transform: the prime-factor form for plans with pairwise coprime radices (no twiddles: nothing to load)
+    constexpr bool PFA = CorrMode<PL>::PFA;
+    __shared__ cf lds[PL::LDS_ELEMS + (PFA ? 0 : PL::TW_TOTAL)];
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
-    load_twiddles<PL>(tw, tw_inv, tid);
+#ifdef GM_LAB_PRIO
+    if (tid >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
+    if constexpr (!PFA) load_twiddles<PL>(tw, tw_inv, tid);
     constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(spectra + size_t(d) * n_int * PL::N, unsigned(n_int) * PL::N * 8u);
@@ -166,7 +205,9 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     if constexpr (STAMPS) stbase = (blockIdx.x == 0 && (tid & 63) == 0 && PL::T / 64 <= 8) ? g_corr_stamps : nullptr;
     const int wv = tid >> 6;
     const int m_per = n_int / parts, m_begin = part * m_per, m_end = m_begin + m_per;
-    constexpr bool CAN_SPLIT = PL::RL % 4 == 0 && !STAMPS;
+    constexpr bool CAN_SPLIT = !STAMPS;
+    constexpr int RL4 = (PL::RL + 3) / 4;                                         // 16-byte groups of a lane's power values (the last one padded)
+    auto acc_or_zero = [&](int it, int r) { return r < PL::RL ? acc[it][r < PL::RL ? r : 0] : 0.0f; };
     for (int m = m_begin; m < m_end; ++m) {
         // all pass-0 loads of this transform are issued here, pairs as 16-byte loads (PairLayout)
         PLd xq[PL::IT0], cq[(KEEP_CODE || !CODE_PAIRED) ? 1 : PL::IT0];
@@ -184,48 +225,66 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
             if constexpr (KEEP_CODE) c = cc[it][r];
             else if constexpr (CODE_PAIRED) { const cf g = cq[it].get(r); c = cf_make(g.x, -g.y); }
             else { const cf g = buf_load_cf(crs, (tid + it * PL::T) * 8, r * NB0 * 8); c = cf_make(g.x, -g.y); }
-            // result_buf[i] *= conj(code[i])  (:184-186), num-complex Mul, no FMA
+            // result_buf[i] *= conj(code[i])  (:184-186).  num-complex multiplies without FMA; here two of the four products are
+            // fused (one rounding less each).  The value feeds the inverse FFT, whose own rounding differs from rustfft's by more
+            // than that, and nothing observable sits in between: 4 instead of 6 instructions per element (GM_CORR_NO_FMA: the
+            // unfused forms, for A/B timing)
+#ifndef GM_CORR_NO_FMA
+            return cf_make(__builtin_fmaf(a.x, c.x, -(a.y * c.y)), __builtin_fmaf(a.x, c.y, a.y * c.x));
+#else
             return cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
+#endif
         };
-        auto out = [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y); };   // += norm_sqr() (:190-192)
+        // acc += norm_sqr() (:190-192): the power with one fused multiply-add, then a plain add — the running sum must stay
+        // `acc + p` with p complete, so that the planes of a cut item (each 0 + p) merge to the very same words (two fused
+        // multiply-adds into acc would save one more instruction and break that)
+#ifndef GM_CORR_NO_FMA
+        auto out = [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + __builtin_fmaf(v.y, v.y, v.x * v.x); };
+#else
+        auto out = [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y); };
+#endif
         if constexpr (!STAMPS) {
-            lds_transform<PL, true>(in, out, lds, tw, tid);
+            lds_transform<PL, true, PFA>(in, out, lds, tw, tid);
         } else {   // diagnostic variant: the same phases with stamps next to the barriers
             auto st = [&](int k) { corr_stamp(stbase, m, wv, k); };
             st(0);
             {
                 cf v0[PL::IT0][PL::R0];
-                Fft<PL, true>::pass0_stage1(v0, in, tid);
+                Fft<PL, true, PFA>::pass0_stage1(v0, in, tid);
                 st(1);
                 __syncthreads();
                 st(2);
-                Fft<PL, true>::pass0_stage2(v0, lds, tid);
+                Fft<PL, true, PFA>::pass0_stage2(v0, lds, tid);
             }
             st(3);
             __syncthreads();
-            MiddlePasses<PL, true, 1>::run(lds, tw, tid, st);
+            MiddlePasses<PL, true, 1, PFA>::run(lds, tw, tid, st);
             cf vl[PL::ITL][PL::RL];
-            Fft<PL, true>::last_stage1(vl, lds, tw, tid);
-            Fft<PL, true>::last_stage2(vl, out, tid);
+            Fft<PL, true, PFA>::last_stage1(vl, lds, tw, tid);
+            Fft<PL, true, PFA>::last_stage2(vl, out, tid);
         }
     }
 
     if constexpr (CAN_SPLIT) {
-        if (parts > 1) {      // a part of a cut item (one integration): its plane goes out; nothing writes these registers again
-            constexpr int SLAB = PL::ITL * PL::RL * PL::T;                        // floats per power plane, register order
+        if (parts > 1) {      // a part of a cut item (one integration): its plane goes out
+            // The whole byte offset travels in the VECTOR offset operand and the scalar offset is the constant 0: a
+            // `buffer_store_dwordx4 v[..], v, s[..], sN offen` (scalar offset REGISTER) directly followed by a VALU write of its
+            // data registers stored the NEW values of a few lanes now and then on gfx950 — the plane sums came out 0.01-0.5 %
+            // low (tools/split_probe.py) — and hipcc's hazard recogniser inserts its wait state only for the forms without a
+            // scalar offset register.  With soffset = 0 it does.
+            constexpr int SLAB = PL::ITL * RL4 * 4 * PL::T;                       // floats per power plane, register order
             // the item's planes: [n_int][SLAB] floats at its own place in the scratch
             const size_t item_plane0 = (size_t(xcd) * split_items + (slot - split_from)) * size_t(n_int);
             const __amdgpu_buffer_rsrc_t srs = make_rsrc(split_scratch + item_plane0 * SLAB, unsigned(n_int) * SLAB * 4u);
-            // before the wait below (a `buffer_store_dwordx4 ... sN offen` directly followed by a VALU write of its data registers
-            // stored stale lanes now and then on gfx950 — hipcc inserts no wait state for the scalar-offset form; tools/split_probe.py)
+            const int voff = tid * 16 + part * SLAB * 4;
 #pragma unroll
             for (int it = 0; it < PL::ITL; ++it)
 #pragma unroll
-                for (int r4 = 0; r4 < PL::RL / 4; ++r4) {
+                for (int r4 = 0; r4 < RL4; ++r4) {
                     u32x4 v;
-                    v.x = __float_as_uint(acc[it][4 * r4 + 0]); v.y = __float_as_uint(acc[it][4 * r4 + 1]);
-                    v.z = __float_as_uint(acc[it][4 * r4 + 2]); v.w = __float_as_uint(acc[it][4 * r4 + 3]);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, srs, tid * 16, (part * SLAB + (it * (PL::RL / 4) + r4) * PL::T * 4) * 4, 16);   // sc1: write-through
+                    v.x = __float_as_uint(acc_or_zero(it, 4 * r4 + 0)); v.y = __float_as_uint(acc_or_zero(it, 4 * r4 + 1));
+                    v.z = __float_as_uint(acc_or_zero(it, 4 * r4 + 2)); v.w = __float_as_uint(acc_or_zero(it, 4 * r4 + 3));
+                    __builtin_amdgcn_raw_buffer_store_b128(v, srs, voff + (it * RL4 + r4) * PL::T * 16, 0, 16);   // sc1: write-through
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left
             __syncthreads();                                         // ... and every wave's
@@ -247,10 +306,12 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
 #pragma unroll
                 for (int it = 0; it < PL::ITL; ++it)
 #pragma unroll
-                    for (int r4 = 0; r4 < PL::RL / 4; ++r4) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srs, tid * 16, (q * SLAB + (it * (PL::RL / 4) + r4) * PL::T * 4) * 4, 16);
-                        acc[it][4 * r4 + 0] += __uint_as_float(v.x); acc[it][4 * r4 + 1] += __uint_as_float(v.y);
-                        acc[it][4 * r4 + 2] += __uint_as_float(v.z); acc[it][4 * r4 + 3] += __uint_as_float(v.w);
+                    for (int r4 = 0; r4 < RL4; ++r4) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srs, tid * 16, (q * SLAB + (it * RL4 + r4) * PL::T * 4) * 4, 16);
+                        if (4 * r4 + 0 < PL::RL) acc[it][4 * r4 + 0] += __uint_as_float(v.x);
+                        if (4 * r4 + 1 < PL::RL) acc[it][4 * r4 + 1 < PL::RL ? 4 * r4 + 1 : 0] += __uint_as_float(v.y);
+                        if (4 * r4 + 2 < PL::RL) acc[it][4 * r4 + 2 < PL::RL ? 4 * r4 + 2 : 0] += __uint_as_float(v.z);
+                        if (4 * r4 + 3 < PL::RL) acc[it][4 * r4 + 3 < PL::RL ? 4 * r4 + 3 : 0] += __uint_as_float(v.w);
                     }
             }
         }
@@ -270,7 +331,7 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
             const int b = tid + it * PL::T;
             if (b < NBL) {
 #pragma unroll
-                for (int r = 0; r < PL::RL; ++r) pl[b + r * NBL] = acc[it][r];
+                for (int r = 0; r < PL::RL; ++r) pl[PFA ? Pfa<PL>::out_index(b, r) : b + r * NBL] = acc[it][r];
             }
         }
         __syncthreads();
@@ -291,14 +352,55 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     // per-lane: first strict maximum + partial sum
     float bv = 0.0f, sum = 0.0f;
     uint32_t bi = 0xffffffffu;
+    if constexpr (!PFA) {
 #pragma unroll
-    for (int it = 0; it < PL::ITL; ++it) {
-        const int b = tid + it * PL::T;
-        if (b < NBL) {
+        for (int it = 0; it < PL::ITL; ++it) {
+            const int b = tid + it * PL::T;
+            if (b < NBL) {
 #pragma unroll
-            for (int r = 0; r < PL::RL; ++r) {
-                take_better(bv, bi, acc[it][r], uint32_t(b + r * NBL));
-                sum += acc[it][r];
+                for (int r = 0; r < PL::RL; ++r) {
+                    take_better(bv, bi, acc[it][r], uint32_t(b + r * NBL));
+                    sum += acc[it][r];
+                }
+            }
+        }
+    } else {
+        // prime-factor order: a register slot's code-phase index is Pfa::out_index(b, r) (a dozen integer operations), so the
+        // scan runs on values and the index is worked out for the winner alone — for every slot that holds the maximum only
+        // when several do (then the lowest index wins, as in take_better: the reference's first strict maximum, :195-202)
+        int bs = -1, ties = 0;
+#pragma unroll
+        for (int it = 0; it < PL::ITL; ++it) {
+            if (tid + it * PL::T < NBL) {
+#pragma unroll
+                for (int r = 0; r < PL::RL; ++r) {
+                    const float v = acc[it][r];
+                    if (v > bv) { bv = v; bs = it * PL::RL + r; }
+                    sum += v;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < PL::ITL; ++it) {
+            if (tid + it * PL::T < NBL) {
+#pragma unroll
+                for (int r = 0; r < PL::RL; ++r) ties += acc[it][r] == bv ? 1 : 0;
+            }
+        }
+        if (ties == 1 && bs >= 0) {
+            bi = uint32_t(Pfa<PL>::out_index(tid + (bs / PL::RL) * PL::T, bs % PL::RL));
+        } else if (ties >= 1) {
+#pragma unroll
+            for (int it = 0; it < PL::ITL; ++it) {
+                const int b = tid + it * PL::T;
+                if (b < NBL) {
+#pragma unroll
+                    for (int r = 0; r < PL::RL; ++r)
+                        if (acc[it][r] == bv) {
+                            const uint32_t i = uint32_t(Pfa<PL>::out_index(b, r));
+                            bi = i < bi ? i : bi;
+                        }
+                }
             }
         }
     }
@@ -352,7 +454,7 @@ __global__ __launch_bounds__(256) void pair_codes_kernel(const cf* __restrict__ 
     for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += size_t(gridDim.x) * 256) {
         const size_t c = i / PL::N;
         const int k = int(i - c * PL::N);
-        paired[c * PL::N + PairLayout<PL>::pos(k)] = nat[i];
+        paired[c * PL::N + CorrLayout<PL>::slot(k)] = nat[i];
     }
 }
 
@@ -534,7 +636,7 @@ template <class PL> struct Launch {
         hipLaunchKernelGGL(acq_mix_fft_kernel<PL>, dim3(n_bins * n_int), dim3(PL::T), 0, st, samples, fmt,
                            tables, tw_fwd, spectra, n_int, clear_tickets);
     }
-    static constexpr int SPLIT_SLAB = (PL::RL % 4 == 0) ? PL::ITL * PL::RL * PL::T : 0;   // floats per partial plane
+    static constexpr int SPLIT_SLAB = PL::ITL * ((PL::RL + 3) / 4) * 4 * PL::T;   // floats per power plane of the tail split
     static void corr(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
                      int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum, int tickets_cleared) {
@@ -611,7 +713,7 @@ template <class PL> struct Launch {
     }
     static constexpr PlanOps ops() {
         return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL), SPLIT_SLAB,
-                       CorrLayout<PL>::CODE_PAIRED ? 1 : 0,
+                       CorrLayout<PL>::RELAYOUT ? 1 : 0,
                        &fill_tw, &mix_fft, &corr, &code_fft, &pair_codes, &fft_batch,
                        POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr, FineRows<PL>::RT};
     }

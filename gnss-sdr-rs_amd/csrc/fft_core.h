@@ -382,9 +382,18 @@ template <int N_, int T_, int... Rs> struct Plan {
     static constexpr bool KEEP_CODE = (IT0 * R0 + ITL * RL) <= 24;
     // workgroups per CU the LDS footprint admits (160 KB per CU), and the waves per SIMD that needs
     static constexpr int LDS_BYTES = 8 * (LDS_ELEMS + TW_TOTAL);
-    static constexpr int WG_PER_CU = (2 * LDS_BYTES <= 160 * 1024 && T <= 512) ? 2 : 1;
+    static constexpr int WG_PER_CU = (2 * LDS_BYTES <= 160 * 1024 && T <= 1024) ? 2 : 1;
     static constexpr int WAVES_PER_EU = (WG_PER_CU * T / 64 + 3) / 4;
     static constexpr bool check() { int p = 1; for (int i = 0; i < NP; ++i) p *= R[i]; return p == N && NP >= 2; }
+    // pairwise coprime radices: the transform can run as a prime-factor (Good-Thomas) algorithm ACROSS the passes — no twiddle
+    // between them at all — on inputs stored in the order Pfa<PL>::in_slot gives (see Pfa below)
+    static constexpr bool coprime() {
+        for (int i = 0; i < NP; ++i)
+            for (int j = i + 1; j < NP; ++j)
+                if (ct::gcd(R[i], R[j]) != 1) return false;
+        return true;
+    }
+    static constexpr bool COPRIME = coprime();
     static_assert(check(), "radices must multiply to N and there must be >= 2 passes");
 };
 
@@ -400,6 +409,14 @@ template <class PL> inline void fill_twiddles(cf* tw, bool inverse, double (*cos
     }
 }
 
+// Which lanes run a MIDDLE pass: butterfly b of pass S is run by lane b + ROT (lanes below ROT sit the pass out).  A
+// workgroup's waves w and w + 4 share a SIMD; a pass with fewer butterflies than lanes leaves its top waves idle, so with
+// ROT = 0 everywhere the SIMD of waves 0 / 4 carries two butterfly streams in EVERY pass (N = 8000: 5, 7 and 8 of 8 waves
+// busy -> 6 / 5 / 5 / 4 wave-passes per SIMD and transform).  Rotating pass 1 by one wave (waves 1..7 instead of 0..6) makes
+// that 5 / 5 / 5 / 5.  Pass 0 and the last pass keep lane = butterfly: their index maps are shared with the callers' loads
+// and stores.  Specialise per plan (fft_plans.h); default: no rotation.
+template <class PL> struct PlanRot { static constexpr int rot(int) { return 0; } };
+
 // ------------------------------------------------------------------ per-thread phases of one transform
 // Every thread of the workgroup calls, in order ('|' = workgroup barrier):
 //   pass0_stage1  | pass0_stage2 | mid_stage1<1> | mid_stage2<1> | ... | last_stage1  last_stage2
@@ -407,8 +424,49 @@ template <class PL> inline void fill_twiddles(cf* tw, bool inverse, double (*cos
 // Element (it, r) of pass S belongs to butterfly b = tid + it*T and is input index b + r*NB(S);
 // outputs of the last pass are output index b + r*NB(last).  The split into phases is also what lets
 // the CPU emulation (tests/cpu) interleave "threads".
-template <class PL, bool INV> struct Fft {
+// Prime-factor form across the passes (PL::COPRIME).  The Stockham data flow above with every twiddle = 1 computes the NP-
+// dimensional DFT over the digits (r_0 .. r_{NP-1}) of the storage index e = ((r_0) R_1 + r_1) R_2 + r_2 ...; for pairwise
+// coprime radices that IS the length-N DFT of the sequence whose element i sits at the slot with digits r_s = i mod R_s
+// (CRT on the input side), with output (q_0 .. q_{NP-1}) being element o = sum_s (N / R_s) q_s mod N (Good's map on the
+// output side): i * o = sum_s i (N/R_s) q_s, and W_N^{i (N/R_s) q_s} = W_{R_s}^{(i mod R_s) q_s}.  The writer of the input
+// (stage F, the code-spectrum re-layout) applies in_slot for free; the reader of the output needs out_index only where an
+// index is reported (the argmax).  No twiddle table, no power tree, no LDS reads for twiddles.
+template <class PL> struct Pfa {
     static constexpr int NP = PL::NP;
+    static GM_HD int in_slot(int i) {
+        int e = 0;
+#pragma unroll
+        for (int s = 0; s < NP; ++s) e = e * PL::R[s] + i % PL::R[s];
+        return e;
+    }
+    // storage slot -> element index (the inverse of in_slot): e has the digits r_s = i mod R_s, so i = sum_s A_s r_s mod N with
+    // A_s = (N/R_s) * ((N/R_s)^-1 mod R_s)  (A_s = 1 mod R_s, = 0 mod every other radix)
+    static constexpr int crt_coeff(int s) { return int((long(PL::N / PL::R[s]) * ct::modinv(PL::N / PL::R[s], PL::R[s])) % PL::N); }
+    static GM_HD int slot_to_index(int e) {
+        long i = 0;
+#pragma unroll
+        for (int s = NP - 1; s >= 0; --s) {
+            i += long(crt_coeff(s)) * (e % PL::R[s]);
+            e /= PL::R[s];
+        }
+        return int(i % PL::N);
+    }
+    // (butterfly b of the last pass, its output q) -> element index; b = sum_{s < NP-1} q_s P(s)
+    static GM_HD int out_index(int b, int q) {
+        int o = (PL::N / PL::R[NP - 1]) * q, k = b;
+#pragma unroll
+        for (int s = 0; s < NP - 1; ++s) {
+            o += (PL::N / PL::R[s]) * (k % PL::R[s]);
+            k /= PL::R[s];
+            o = o >= PL::N ? o - PL::N : o;
+        }
+        return o;
+    }
+};
+
+template <class PL, bool INV, bool PFA = false> struct Fft {
+    static constexpr int NP = PL::NP;
+    static_assert(!PFA || PL::COPRIME, "the prime-factor form needs pairwise coprime radices");
 
     static GM_HD int map01(int e) {
         if constexpr (PL::PAD_Q != 0) return e + e / PL::PAD_Q;
@@ -438,15 +496,32 @@ template <class PL, bool INV> struct Fft {
         }
     }
 
+    // lane -> butterfly of pass S: rotated for middle passes (PlanRot), the identity for pass 0 and the last pass
+    template <int S> static GM_HD int bfly_of(int tid, int it) {
+        constexpr int ROT = (S >= 1 && S <= NP - 2) ? PlanRot<PL>::rot(S) : 0;
+        static_assert(ROT >= 0 && PL::IT(S) * PL::T - ROT >= PL::NB(S), "rotation leaves butterflies without a lane");
+        return tid + it * PL::T - ROT;
+    }
     template <int S> static GM_HD void gather_stage1(cf (&v)[PL::IT(S)][PL::R[S]], const cf* lds, const cf* tw, int tid) {
         constexpr int R = PL::R[S], NB = PL::NB(S), P = PL::P(S);
 #pragma unroll
         for (int it = 0; it < PL::IT(S); ++it) {
-            const int b = tid + it * PL::T;
-            if (b < NB) {
-                TwPow<R> w;
-                w.init(tw[PL::TWOFF(S) + (b % P)]);
-                Bfly<R, INV>::stage1([&](int r) { return w.apply(lds[rd<S>(b + r * NB)], r); }, v[it]);
+            const int b = bfly_of<S>(tid, it);
+            if (unsigned(b) < unsigned(NB)) {
+#ifdef GM_LAB_NOTW      // timing ablation only (tools/corr_lab): no twiddles at all -> wrong results
+                Bfly<R, INV>::stage1([&](int r) { return lds[rd<S>(b + r * NB)]; }, v[it]);
+#elif defined(GM_LAB_TWTAB)   // timing ablation only: one table read + one complex multiply per input (the cost shape of small-table twiddles)
+                const cf* tb = tw + PL::TWOFF(S) + (b % (P < 25 ? P : 25));
+                Bfly<R, INV>::stage1([&](int r) { return r == 0 ? lds[rd<S>(b)] : cf_mul(lds[rd<S>(b + r * NB)], tb[r % 5 * 25 + r]); }, v[it]);
+#else
+                if constexpr (PFA) {
+                    Bfly<R, INV>::stage1([&](int r) { return lds[rd<S>(b + r * NB)]; }, v[it]);
+                } else {
+                    TwPow<R> w;
+                    w.init(tw[PL::TWOFF(S) + (b % P)]);
+                    Bfly<R, INV>::stage1([&](int r) { return w.apply(lds[rd<S>(b + r * NB)], r); }, v[it]);
+                }
+#endif
             }
         }
     }
@@ -457,8 +532,8 @@ template <class PL, bool INV> struct Fft {
         constexpr int R = PL::R[S], NB = PL::NB(S), P = PL::P(S);
 #pragma unroll
         for (int it = 0; it < PL::IT(S); ++it) {
-            const int b = tid + it * PL::T;
-            if (b < NB) {
+            const int b = bfly_of<S>(tid, it);
+            if (unsigned(b) < unsigned(NB)) {
                 const int k = b % P;
                 cf* dst = lds + (b - k) * R + k;
                 Bfly<R, INV>::stage2(v[it], [&](int q, cf val) { dst[q * P] = val; });

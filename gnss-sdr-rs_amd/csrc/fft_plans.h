@@ -12,7 +12,11 @@
 
 namespace gm {
 using Plan8000 = Plan<8000, 512, 25, 20, 16>;
-using Plan16368 = Plan<16368, 768, 33, 31, 16>;   // 12 waves = 3 per SIMD (576 lanes = 9 waves loaded the SIMDs 3/2/2/2); last pass 2 butterflies per thread
+// 16368 = 33 * 16 * 31, pairwise coprime: the correlation kernel runs its inverse as a prime-factor transform ACROSS the
+// passes (fft_core.h Pfa: no twiddles at all).  12 waves = 3 per SIMD (576 lanes = 9 waves loaded the SIMDs 3/2/2/2); the
+// radix-16 pass in the middle (two butterflies per thread), the radix-31 pass last: its 31 outputs go straight into the
+// power sums without an LDS scatter (order [33,31,16]: 0.52 ms per 32-PRN dwell; [33,16,31]: 0.47 before the prime-factor form)
+using Plan16368 = Plan<16368, 768, 33, 16, 31>;
 using Plan4096 = Plan<4096, 256, 16, 16, 16>;
 using Plan2048 = Plan<2048, 256, 8, 16, 16>;
 using Plan1024 = Plan<1024, 128, 8, 8, 16>;
@@ -28,6 +32,9 @@ using Plan15000 = Plan<15000, 1024, 25, 25, 24>;  // 15 Msps
 using Plan16384 = Plan<16384, 1024, 32, 32, 16>;  // 16.384 Msps
 using Plan512 = Plan<512, 64, 8, 8, 8>;           // factors of the long fine-Doppler FFT (2^16 .. 2^19) at low sample rates
 using Plan256 = Plan<256, 64, 16, 16>;
+#ifndef GM_NO_PLAN_ROT
+template <> struct PlanRot<Plan8000> { static constexpr int rot(int s) { return s == 1 ? 64 : 0; } };   // passes run on waves 0-4 / 1-7 / 0-7
+#endif
 }  // namespace gm
 
 #ifndef GM_FOR_EACH_PLAN   // tools/corr_lab restricts the list to one plan for fast experimental builds

@@ -12,27 +12,29 @@
 
 using namespace gm;
 
-template <class PL, bool INV, int S> struct Middle {
+template <class PL, bool INV, int S, bool PFA = false> struct Middle {
     static void run(std::vector<cf>& lds, const std::vector<cf>& tw) {
         if constexpr (S <= PL::NP - 2) {
             constexpr int IT = PL::IT(S), R = PL::R[S];
             std::vector<cf> regs(size_t(PL::T) * IT * R);
             for (int tid = 0; tid < PL::T; ++tid) {   // phase: gather + first half of the butterfly
                 auto& v = *reinterpret_cast<cf(*)[IT][R]>(&regs[size_t(tid) * IT * R]);
-                Fft<PL, INV>::template mid_stage1<S>(v, lds.data(), tw.data(), tid);
+                Fft<PL, INV, PFA>::template mid_stage1<S>(v, lds.data(), tw.data(), tid);
             }
             for (int tid = 0; tid < PL::T; ++tid) {   // barrier; phase: second half + scatter
                 auto& v = *reinterpret_cast<cf(*)[IT][R]>(&regs[size_t(tid) * IT * R]);
-                Fft<PL, INV>::template mid_stage2<S>(v, lds.data(), tid);
+                Fft<PL, INV, PFA>::template mid_stage2<S>(v, lds.data(), tid);
             }
-            Middle<PL, INV, S + 1>::run(lds, tw);
+            Middle<PL, INV, S + 1, PFA>::run(lds, tw);
         }
     }
 };
 
-template <class PL, bool INV> static double run_plan(const char* name) {
+// PFA: the prime-factor form across the passes (plans with pairwise coprime radices): element i of the input sits at storage
+// slot Pfa::in_slot(i), output (b, q) of the last pass is element Pfa::out_index(b, q); no twiddles
+template <class PL, bool INV, bool PFA = false> static double run_plan(const char* name) {
     constexpr int N = PL::N, T = PL::T;
-    std::vector<cf> x(N), y(N), lds(PL::LDS_ELEMS), tw(PL::TW_TOTAL + 1);
+    std::vector<cf> x(N), xs(N), y(N), lds(PL::LDS_ELEMS), tw(PL::TW_TOTAL + 1);
     fill_twiddles<PL>(tw.data(), INV, [](double a) { return std::cos(a); }, [](double a) { return std::sin(a); });
     unsigned s = 12345u + N;
     for (int i = 0; i < N; ++i) {
@@ -40,22 +42,25 @@ template <class PL, bool INV> static double run_plan(const char* name) {
         s = s * 1664525u + 1013904223u; float b = float(int(s >> 8) % 2001 - 1000) / 100.f;
         x[i] = cf_make(a, b);
     }
+    for (int i = 0; i < N; ++i) xs[PFA ? Pfa<PL>::in_slot(i) : i] = x[i];
     {   // pass 0: stage 1 for every thread, (barrier), stage 2 for every thread
         std::vector<cf> regs(size_t(T) * PL::IT0 * PL::R0);
         for (int tid = 0; tid < T; ++tid) {
             auto& v = *reinterpret_cast<cf(*)[PL::IT0][PL::R0]>(&regs[size_t(tid) * PL::IT0 * PL::R0]);
-            Fft<PL, INV>::pass0_stage1(v, [&](int it, int r) { return x[(tid + it * T) + r * PL::NB(0)]; }, tid);
+            Fft<PL, INV, PFA>::pass0_stage1(v, [&](int it, int r) { return xs[(tid + it * T) + r * PL::NB(0)]; }, tid);
         }
         for (int tid = 0; tid < T; ++tid) {
             auto& v = *reinterpret_cast<cf(*)[PL::IT0][PL::R0]>(&regs[size_t(tid) * PL::IT0 * PL::R0]);
-            Fft<PL, INV>::pass0_stage2(v, lds.data(), tid);
+            Fft<PL, INV, PFA>::pass0_stage2(v, lds.data(), tid);
         }
     }
-    Middle<PL, INV, 1>::run(lds, tw);
+    Middle<PL, INV, 1, PFA>::run(lds, tw);
     for (int tid = 0; tid < T; ++tid) {
         cf v[PL::ITL][PL::RL];
-        Fft<PL, INV>::last_stage1(v, lds.data(), tw.data(), tid);
-        Fft<PL, INV>::last_stage2(v, [&](int it, int r, cf val) { y[(tid + it * T) + r * PL::NB(PL::NP - 1)] = val; }, tid);
+        Fft<PL, INV, PFA>::last_stage1(v, lds.data(), tw.data(), tid);
+        Fft<PL, INV, PFA>::last_stage2(v, [&](int it, int r, cf val) {
+            const int b = tid + it * T;
+            y[PFA ? Pfa<PL>::out_index(b, r) : b + r * PL::NB(PL::NP - 1)] = val; }, tid);
     }
     // reference: float64 DFT
     std::vector<std::complex<double>> w(N);
@@ -69,14 +74,15 @@ template <class PL, bool INV> static double run_plan(const char* name) {
         num += std::norm(d); den += std::norm(acc);
     }
     double err = std::sqrt(num / den);
-    std::printf("%-28s N=%6d T=%4d %s rel_l2_err=%.3e lds_elems=%d tw=%d\n", name, N, T, INV ? "inv" : "fwd", err,
+    std::printf("%-28s N=%6d T=%4d %s%s rel_l2_err=%.3e lds_elems=%d tw=%d\n", name, N, T, INV ? "inv" : "fwd", PFA ? " prime-factor" : "", err,
                 PL::LDS_ELEMS, PL::TW_TOTAL);
     return err;
 }
 
 int main() {
     double worst = 0;
-#define RUN(PL) worst = std::fmax(worst, run_plan<PL, false>(#PL)); worst = std::fmax(worst, run_plan<PL, true>(#PL));
+#define RUN(PL) worst = std::fmax(worst, run_plan<PL, false>(#PL)); worst = std::fmax(worst, run_plan<PL, true>(#PL)); \
+    if constexpr (PL::COPRIME) { worst = std::fmax(worst, run_plan<PL, false, true>(#PL)); worst = std::fmax(worst, run_plan<PL, true, true>(#PL)); }
     GM_FOR_EACH_PLAN(RUN)
     std::printf("worst %.3e\n", worst);
     return worst < 7e-7 ? 0 : 1;   // f32 FFT rounding of the largest plans; parity tolerances downstream are 1e-5
