@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libgnss_mi355x.so")
+_LIB_PATH = os.environ.get("GM_LIB_PATH") or os.path.join(_HERE, "lib", "libgnss_mi355x.so")   # GM_LIB_PATH: an A/B build (build.py GM_LIB_SUFFIX), diagnostics only
 
 
 class GmError(RuntimeError):

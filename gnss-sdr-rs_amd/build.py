@@ -27,8 +27,15 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
+    """GM_EXTRA_FLAGS / GM_LIB_SUFFIX (diagnostics): extra hipcc flags and a suffix for the library / object directory, so that an
+    A/B variant (e.g. -DGM_NO_HYBRID_PLANS) can sit beside the product library; load it with GM_LIB_PATH (see _lib.py)."""
+    global LIB
+    extra = os.environ.get("GM_EXTRA_FLAGS", "").split()
+    suffix = os.environ.get("GM_LIB_SUFFIX", "")
+    if suffix:
+        LIB = os.path.join(LIBDIR, "libgnss_mi355x%s.so" % suffix)
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + suffix)
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
@@ -36,7 +43,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src + ".o")
         if force or _stale(o, [s] + hdrs):
-            jobs.append(["hipcc", *FLAGS, "-c", s, "-o", o])
+            jobs.append(["hipcc", *FLAGS, *extra, "-c", s, "-o", o])
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -44,8 +44,13 @@ __global__ __launch_bounds__(PL::T) void comp_fwd_sub_kernel(const void* __restr
                                                              const cf* __restrict__ tables,
                                                              const int8_t* __restrict__ code_samples,
                                                              const cf* __restrict__ tw_fwd, cf* __restrict__ A,
-                                                             uint32_t Q, uint32_t n_int) {
-    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
+                                                             uint32_t Q, uint32_t n_int, const uint16_t* __restrict__ order) {
+    // order != null (base sizes whose correlation plan reads a permuted spectrum): the sub-transform leaves in STORAGE order —
+    // A[item][n1][p] holds element order[p] — staged through the LDS buffer like stage F (acq_kernels.hip), so that
+    // comp_fwd_post_kernel reads and writes position by position, coalesced
+    constexpr int STAGE = CorrMode<typename CompPlanOf<PL>::type>::PERMUTED ? PL::N + PL::N / 32 + 1 : 0;
+    constexpr int LDS_N = PL::LDS_ELEMS + PL::TW_TOTAL > STAGE ? PL::LDS_ELEMS + PL::TW_TOTAL : STAGE;
+    __shared__ cf lds[LDS_N];
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
     load_twiddles<PL>(tw, tw_fwd, tid);
@@ -54,32 +59,59 @@ __global__ __launch_bounds__(PL::T) void comp_fwd_sub_kernel(const void* __restr
     const uint32_t d = item / n_int, m = item % n_int;
     cf* dst = A + size_t(blockIdx.x) * PL::N;
     constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
-    lds_transform<PL, false>(
-        [&](int it, int r) {
-            const size_t n = size_t(Q) * uint32_t((tid + it * PL::T) + r * NB0) + n1;
-            if (code_samples) return cf_make(float(code_samples[size_t(item) * N + n]), 0.0f);
-            const cf s = load_sample(samples, fmt, size_t(m) * N + n);
-            const cf t = tables[size_t(d) * N + n];
-            return cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);           // multiply_simd_block
-        },
-        [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
+    auto in = [&](int it, int r) {
+        const size_t n = size_t(Q) * uint32_t((tid + it * PL::T) + r * NB0) + n1;
+        if (code_samples) return cf_make(float(code_samples[size_t(item) * N + n]), 0.0f);
+        const cf s = load_sample(samples, fmt, size_t(m) * N + n);
+        const cf t = tables[size_t(d) * N + n];
+        return cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);           // multiply_simd_block
+    };
+    if (!STAGE || !order) {
+        lds_transform<PL, false>(in, [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
+    } else {
+        {
+            cf v0[PL::IT0][PL::R0];
+            Fft<PL, false>::pass0_stage1(v0, in, tid);
+            __syncthreads();
+            Fft<PL, false>::pass0_stage2(v0, lds, tid);
+        }
+        __syncthreads();
+        MiddlePasses<PL, false, 1>::run(lds, tw, tid);
+        cf vl[PL::ITL][PL::RL];
+        Fft<PL, false>::last_stage1(vl, lds, tw, tid);
+        __syncthreads();
+        Fft<PL, false>::last_stage2(vl, [&](int it, int r, cf val) {
+            const int k = (tid + it * PL::T) + r * NBL;
+            lds[k + (k >> 5)] = val; }, tid);
+        __syncthreads();
+        for (int p = tid; p < PL::N; p += PL::T) {
+            const int k = order[p];
+            dst[p] = lds[k + (k >> 5)];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ forward, step 2
-// grid (ceil(Nb / CT), n_items): X[item][k1][place(k2)] = sum_n1 W_Q^{n1 k1} W_N^{n1 k2} A[item][n1][k2];
-// place = PairLayout<PL>::pos (paired != 0) or the identity.
+// grid (ceil(Nb / CT), n_items): X[item][k1][place] = sum_n1 W_Q^{n1 k1} W_N^{n1 k2} A[item][n1][..] for element k2 of the block;
+// place: the element's position in the stored block — CorrLayout<CP>::slot(k2) (paired != 0: pairs, and the permutation of a
+// prime-factor / hybrid correlation plan) or k2 (paired == 0: natural order, the API's view of the code spectra).
+// order != null: A is already in storage order (comp_fwd_sub_kernel), thread = position, k2 = order[position].
 template <class PL, uint32_t Q>
-__global__ __launch_bounds__(CT) void comp_fwd_post_kernel(const cf* __restrict__ A, cf* __restrict__ X, int paired) {
-    const uint32_t k2 = blockIdx.x * CT + threadIdx.x;
-    if (k2 >= uint32_t(PL::N)) return;
+__global__ __launch_bounds__(CT) void comp_fwd_post_kernel(const cf* __restrict__ A, cf* __restrict__ X, int paired,
+                                                           const uint16_t* __restrict__ order) {
+    using CL = CorrLayout<typename CompPlanOf<PL>::type>;
+    const uint32_t t = blockIdx.x * CT + threadIdx.x;
+    if (t >= uint32_t(PL::N)) return;
     const uint32_t item = blockIdx.y, Nb = PL::N, N = Q * Nb;
+    const uint32_t k2 = order ? uint32_t(order[t]) : t;
+    const uint32_t src = order ? t : k2;
     cf a[Q], wq[Q];
 #pragma unroll
     for (uint32_t j = 0; j < Q; ++j) wq[j] = unit_root(j, Q, false);
 #pragma unroll
     for (uint32_t n1 = 0; n1 < Q; ++n1)
-        a[n1] = cf_mul(A[(size_t(item) * Q + n1) * Nb + k2], unit_root(uint32_t((uint64_t(n1) * k2) % N), N, false));
-    const uint32_t place = paired ? uint32_t(PairLayout<PL>::pos(int(k2))) : k2;
+        a[n1] = cf_mul(A[(size_t(item) * Q + n1) * Nb + src], unit_root(uint32_t((uint64_t(n1) * k2) % N), N, false));
+    const uint32_t place = order ? t : (paired ? uint32_t(CL::slot(int(k2))) : k2);
 #pragma unroll
     for (uint32_t k1 = 0; k1 < Q; ++k1) {
         cf acc = a[0];
@@ -110,11 +142,14 @@ __global__ __launch_bounds__(256) void comp_code_comb_kernel(const cf* __restric
 // ------------------------------------------------------------------------------------ inverse, fused
 // One workgroup per (worker, bin).  spectra [d][m][k1][paired k2], code [p][k1][paired k2], twn [n1][paired k2] =
 // W_N^{-n1 k2} (e^{+...}: inverse).
-template <class PL, uint32_t Q>
-__global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void comp_corr_kernel(
+template <class PLX, uint32_t Q>
+__global__ __launch_bounds__(CompPlanOf<PLX>::type::T, CompPlanOf<PLX>::type::WAVES_PER_EU) void comp_corr_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ twn, const cf* __restrict__ tw_inv,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
     const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int) {
+    using PL = typename CompPlanOf<PLX>::type;      // the base size's plan for this path (acq_device.h): plain or hybrid
+    constexpr bool HYB = CorrMode<PL>::HYBRID;
+    static_assert(!CorrMode<PL>::PFA, "composite bases: plain or hybrid correlation plans");
     static_assert(PL::IT0 == 1 && PairLayout<PL>::PAIRED, "composite base plans: one pass-0 butterfly per lane, paired layout");
     // equal contiguous share of the bin-major item list per XCD (blocks b and b + 8 share an XCD: speed only)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -126,7 +161,7 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void comp_corr_kernel(
     __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
-    load_twiddles<PL>(tw, tw_inv, tid);
+    if constexpr (!HYB) load_twiddles<PL>(tw, tw_inv, tid);
     constexpr int Nb = PL::N, NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1), NPAIR = PL::R0 / 2;
     constexpr bool ODD0 = (PL::R0 & 1) != 0;
     constexpr uint32_t N = Q * uint32_t(Nb);
@@ -182,11 +217,14 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void comp_corr_kernel(
         // this sub-transform's outputs are y[Q n2 + n1]: fold them into the lane's running first strict maximum / sum
 #pragma unroll
         for (int it = 0; it < PL::ITL; ++it) {
-            const int b = tid + it * PL::T;
-            if (b < NBL) {
+            bool mine;
+            if constexpr (HYB) mine = PL::last_active(tid); else mine = tid + it * PL::T < NBL;
+            if (mine) {
 #pragma unroll
                 for (int r = 0; r < PL::RL; ++r) {
-                    take_better(bv, bi, acc[it][r], Q * uint32_t(b + r * NBL) + n1);
+                    uint32_t e;                                  // this slot's element of the sub-transform's output
+                    if constexpr (HYB) e = uint32_t(PL::out_index(tid, r)); else e = uint32_t((tid + it * PL::T) + r * NBL);
+                    take_better(bv, bi, acc[it][r], Q * e + n1);
                     sum += acc[it][r];
                 }
             }
@@ -219,13 +257,18 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void comp_corr_kernel(
 }
 
 template <class PL, uint32_t Q> struct CompLaunch {
-    static void fwd_sub(hipStream_t st, const void* samples, int fmt, const cf* tables, const int8_t* code_samples,
-                        const cf* tw_fwd, cf* A, uint32_t n_items, uint32_t n_int) {
-        hipLaunchKernelGGL(comp_fwd_sub_kernel<PL>, dim3(n_items * Q), dim3(PL::T), 0, st, samples, fmt, tables, code_samples,
-                           tw_fwd, A, Q, n_int);
+    using CP = typename CompPlanOf<PL>::type;
+    static int fill_order(uint16_t* order) { return fill_order_table<CP>(order); }
+    static void relayout(hipStream_t st, const cf* nat, cf* stored, int n_blocks) {
+        hipLaunchKernelGGL(relayout_kernel<CP>, dim3(n_blocks * 4 < 1024 ? n_blocks * 4 : 1024), dim3(256), 0, st, nat, stored, n_blocks);
     }
-    static void fwd_post(hipStream_t st, const cf* A, cf* X, uint32_t n_items, int paired) {
-        hipLaunchKernelGGL((comp_fwd_post_kernel<PL, Q>), dim3((PL::N + CT - 1) / CT, n_items), dim3(CT), 0, st, A, X, paired);
+    static void fwd_sub(hipStream_t st, const void* samples, int fmt, const cf* tables, const int8_t* code_samples,
+                        const cf* tw_fwd, cf* A, uint32_t n_items, uint32_t n_int, const uint16_t* order) {
+        hipLaunchKernelGGL(comp_fwd_sub_kernel<PL>, dim3(n_items * Q), dim3(PL::T), 0, st, samples, fmt, tables, code_samples,
+                           tw_fwd, A, Q, n_int, order);
+    }
+    static void fwd_post(hipStream_t st, const cf* A, cf* X, uint32_t n_items, int paired, const uint16_t* order) {
+        hipLaunchKernelGGL((comp_fwd_post_kernel<PL, Q>), dim3((PL::N + CT - 1) / CT, n_items), dim3(CT), 0, st, A, X, paired, order);
     }
     static void corr(hipStream_t st, const cf* spectra, const cf* code_paired, const cf* twn, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int) {
@@ -240,16 +283,20 @@ template <class PL, uint32_t Q> struct CompLaunch {
         for (uint32_t n1 = 0; n1 < Q; ++n1)
             for (uint32_t k2 = 0; k2 < Nb; ++k2) {
                 const double a = 2.0 * ct::kPi * double((uint64_t(n1) * k2) % N) / double(N);
-                out[size_t(n1) * Nb + PairLayout<PL>::pos(int(k2))] = cf_make(float(::cos(a)), float(::sin(a)));
+                out[size_t(n1) * Nb + CorrLayout<CP>::slot(int(k2))] = cf_make(float(::cos(a)), float(::sin(a)));
             }
     }
     static void comb(hipStream_t st, const cf* code_paired, const cf* twn, cf* out, uint32_t n_codes) {
         hipLaunchKernelGGL((comp_code_comb_kernel<PL, Q>), dim3((PL::N + 255) / 256, n_codes * Q), dim3(256), 0, st, code_paired, twn, out);
     }
-    static constexpr CompOps ops() { return CompOps{PL::N, int(Q), &fwd_sub, &fwd_post, &corr, &fill_twn, &comb}; }
+    static constexpr CompOps ops() { return CompOps{PL::N, int(Q), &fwd_sub, &fwd_post, &corr, &fill_twn, &comb, &fill_order, &relayout}; }
 };
 }  // namespace
 
+// the Galileo geometry's base: the plain plan wins in comp_corr_kernel (see CompPlanOf, acq_device.h)
+}  // namespace gm
+namespace gm { template <> struct CompPlanOf<Plan16000> { using type = Plan16000; }; }
+namespace gm {
 // base plans of the composite sizes: first radix <= 25 (paired layout), one pass-0 butterfly per lane
 #define GM_COMP_ENTRY(PL)                                                                            \
     CompLaunch<PL, 2>::ops(), CompLaunch<PL, 3>::ops(), CompLaunch<PL, 4>::ops(), CompLaunch<PL, 5>::ops(), \

@@ -84,50 +84,72 @@ template <class PL> struct PairLayout {
         const int r = k / NB0, b = k - r * NB0;
         return r < 2 * NPAIR ? ((r >> 1) * NB0 + b) * 2 + (r & 1) : 2 * NPAIR * NB0 + b;
     }
+    static __host__ __device__ __forceinline__ int unpos(int p) {      // the inverse of pos
+        if constexpr (!PAIRED) return p;
+        if (p >= 2 * NPAIR * NB0) return (p - 2 * NPAIR * NB0) + (R0 - 1) * NB0;
+        const int pair = p >> 1, rp = pair / NB0, b = pair - rp * NB0;
+        return b + (2 * rp + (p & 1)) * NB0;
+    }
 };
 
-// What the correlation kernel's inverse transform is: the prime-factor form for plans with pairwise coprime radices.
-template <class PL> struct CorrMode { static constexpr bool PFA = PL::COPRIME; };
+// The plan the correlation kernel runs its inverse transform on.  Default: the plan of the size itself; fft_plans.h names a
+// HybridPlan for sizes whose factorisation allows one (N = 8000 = 125 * 64).  The forward transforms (stage F, the code
+// spectra) always run the plain plan on natural-order input and produce natural-order output; what differs is the ORDER in
+// which that output is stored (CorrLayout), chosen by the reader.
+template <class PL> struct CorrPlanOf { using type = PL; };
+
+// keyed on the CORRELATION plan CP:
+template <class CP> struct CorrMode {
+    static constexpr bool HYBRID = CP::HYBRID;                       // HybridPlan: prime-factor across A x B, constant twiddles inside
+    static constexpr bool PFA = CP::COPRIME && !CP::HYBRID;          // generic plan with pairwise coprime radices: no twiddles at all
+    static constexpr bool PERMUTED = HYBRID || PFA;                  // stored spectra are not in natural element order
+};
 // CODE_PAIRED: the kernel takes BOTH arrays as 16-byte pairs (PairLoad); RELAYOUT: the stored spectra / code spectra are not in
-// natural order (paired, PFA-permuted or both), i.e. the code spectra go through pair_codes_kernel once per handle
-template <class PL> struct CorrLayout {
-    static constexpr bool CODE_PAIRED = PairLayout<PL>::PAIRED;
-    static constexpr bool RELAYOUT = PairLayout<PL>::PAIRED || CorrMode<PL>::PFA;
-    // natural spectrum index k -> element slot of the stored array
-    static __host__ __device__ __forceinline__ int slot(int k) {
-        if constexpr (CorrMode<PL>::PFA) return PairLayout<PL>::pos(Pfa<PL>::in_slot(k));
-        else return PairLayout<PL>::pos(k);
+// natural order (paired, permuted or both), i.e. the code spectra go through pair_codes_kernel once per handle
+template <class CP> struct CorrLayout {
+    static constexpr bool CODE_PAIRED = PairLayout<CP>::PAIRED;
+    static constexpr bool RELAYOUT = PairLayout<CP>::PAIRED || CorrMode<CP>::PERMUTED;
+    // spectrum element index k -> storage slot e of the inverse transform's input, and back
+    static __host__ __device__ __forceinline__ int perm(int k) {
+        if constexpr (CorrMode<CP>::HYBRID) return CP::in_slot(k);
+        else if constexpr (CorrMode<CP>::PFA) return Pfa<CP>::in_slot(k);
+        else return k;
     }
+    static __host__ __device__ __forceinline__ int unperm(int e) {
+        if constexpr (CorrMode<CP>::HYBRID) return CP::slot_to_index(e);
+        else if constexpr (CorrMode<CP>::PFA) return Pfa<CP>::slot_to_index(e);
+        else return e;
+    }
+    // element index -> position in the stored array (pairs applied on top of the permutation), and back
+    static __host__ __device__ __forceinline__ int slot(int k) { return PairLayout<CP>::pos(perm(k)); }
+    static __host__ __device__ __forceinline__ int index_at(int p) { return unperm(PairLayout<CP>::unpos(p)); }
 };
 
-// slot(b + r * NBL) for the writer of a spectrum (b = tid + it * T, r a compile-time constant after unrolling): for the
-// prime-factor order the residues of b are taken once per butterfly and every r costs an add and a conditional subtract per
-// radix instead of a division
-template <class PL> struct SlotWriter {
-    static constexpr int NP = PL::NP, NBL = PL::NB(PL::NP - 1);
-    int b, res[PL::NP];
-    __device__ __forceinline__ void init(int b_) {
-        b = b_;
-        if constexpr (CorrMode<PL>::PFA) {
-#pragma unroll
-            for (int s = 0; s < NP; ++s) res[s] = b_ % PL::R[s];
-        }
+// The composite path (acq_composite.hip) picks its base size's correlation plan separately: measured at the configs[3] Galileo
+// geometry (N = 2 x 16000, 36 codes) the hybrid 16000 plan runs comp_corr_kernel at 0.396 ms where the plain [25, 20, 32] plan
+// takes 0.353 (the pass-0 inputs are formed from 2Q loads per element there and the 128-register cap of 1024 lanes bites
+// first), while the fused kernel at N = 16000 gains 37 % from it and N = 5 x 8000 gains 5 %.
+template <class PL> struct CompPlanOf { using type = typename CorrPlanOf<PL>::type; };
+
+// natural-order spectra [n][N] -> the stored order of correlation plan CP (pairs and / or permutation), once per handle
+template <class CP>
+__global__ __launch_bounds__(256) void relayout_kernel(const cf* __restrict__ nat, cf* __restrict__ stored, int n) {
+    const size_t total = size_t(n) * CP::N;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += size_t(gridDim.x) * 256) {
+        const size_t c = i / CP::N;
+        const int k = int(i - c * CP::N);
+        stored[c * CP::N + CorrLayout<CP>::slot(k)] = nat[i];
     }
-    __device__ __forceinline__ int slot(int r) const {
-        if constexpr (CorrMode<PL>::PFA) {
-            int e = 0;
-#pragma unroll
-            for (int s = 0; s < NP; ++s) {
-                int x = res[s] + (r * NBL) % PL::R[s];
-                x = x >= PL::R[s] ? x - PL::R[s] : x;
-                e = e * PL::R[s] + x;
-            }
-            return PairLayout<PL>::pos(e);
-        } else {
-            return PairLayout<PL>::pos(b + r * NBL);
-        }
+}
+// host: order[p] = the spectrum element stored at position p (PERMUTED layouts; returns 0 and writes nothing otherwise)
+template <class CP> inline int fill_order_table(uint16_t* order) {
+    if constexpr (!CorrMode<CP>::PERMUTED) return 0;
+    else {
+        static_assert(CP::N <= 65536, "16-bit element indices");
+        if (order) for (int p = 0; p < CP::N; ++p) order[p] = uint16_t(CorrLayout<CP>::index_at(p));
+        return CP::N;
     }
-};
+}
 
 // one lane's pass-0 elements of one paired array, in registers: R0/2 16-byte loads (+ one 8-byte load when R0 is odd)
 template <class PL> struct PairLoad {

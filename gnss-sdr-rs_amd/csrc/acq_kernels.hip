@@ -29,9 +29,12 @@ __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restri
                                                             const cf* __restrict__ tables,
                                                             const cf* __restrict__ tw_fwd,
                                                             cf* __restrict__ spectra, int n_int,
-                                                            uint32_t* __restrict__ clear_tickets) {
-    // (prime-factor plans stage their outputs through LDS, one padding element per 32: see below)
-    constexpr int STAGE = CorrMode<PL>::PFA ? PL::N + PL::N / 32 + 1 : 0;
+                                                            uint32_t* __restrict__ clear_tickets,
+                                                            const uint16_t* __restrict__ order) {
+    // (permuted storage orders stage the outputs through LDS, one padding element per 32: see below)
+    using CP = typename CorrPlanOf<PL>::type;
+    constexpr bool PERMUTED = CorrMode<CP>::PERMUTED;
+    constexpr int STAGE = PERMUTED ? PL::N + PL::N / 32 + 1 : 0;
     constexpr int LDS_N = PL::LDS_ELEMS + PL::TW_TOTAL > STAGE ? PL::LDS_ELEMS + PL::TW_TOTAL : STAGE;
     __shared__ cf lds[LDS_N];
     cf* tw = lds + PL::LDS_ELEMS;
@@ -55,16 +58,15 @@ __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restri
         // multiply_simd_block (doppler_shift.rs:43-58): a*c + (b*d*(-1)), a*d + (b*c*(+1))
         return cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);
     };
-    if constexpr (!CorrMode<PL>::PFA) {
-        SlotWriter<PL> sw[PL::ITL];
-#pragma unroll
-        for (int it = 0; it < PL::ITL; ++it) sw[it].init(tid + it * PL::T);
-        lds_transform<PL, false>(in, [&](int it, int r, cf val) { dst[sw[it].slot(r)] = val; }, lds, tw, tid);
+    if constexpr (!PERMUTED) {
+        constexpr int NBL = PL::NB(PL::NP - 1);
+        lds_transform<PL, false>(in, [&](int it, int r, cf val) { dst[PairLayout<CP>::pos((tid + it * PL::T) + r * NBL)] = val; }, lds, tw, tid);
     } else {
-        // Prime-factor order: neighbouring spectrum elements sit N/R_last + ... slots apart, so storing them from the registers
-        // would be one 64-byte memory transaction per 8-byte element (stage F 0.054 -> 0.073 ms at N = 16368).  The outputs go
-        // back into the (now free) LDS buffer in natural order instead — one padding element per 32, so that the strided
-        // read-out below spreads over the banks — and leave in slot order, coalesced.
+        // Permuted order (prime-factor / hybrid correlation plans): neighbouring spectrum elements sit far apart in the stored
+        // array, so storing them from the registers would be one 64-byte memory transaction per 8-byte element (stage F
+        // 0.054 -> 0.073 ms at N = 16368).  The outputs go back into the (now free) LDS buffer in natural order instead — one
+        // padding element per 32, so that the strided read-out below spreads over the banks — and leave in storage order,
+        // coalesced; `order[p]` = the element index stored at position p (CorrLayout::index_at, tabulated once per handle).
         constexpr int NBL = PL::NB(PL::NP - 1);
         {
             cf v0[PL::IT0][PL::R0];
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restri
             const int k = (tid + it * PL::T) + r * NBL;
             lds[k + (k >> 5)] = val; }, tid);
         __syncthreads();
-        for (int e = tid; e < PL::N; e += PL::T) {
-            const int k = Pfa<PL>::slot_to_index(e);
-            dst[e] = lds[k + (k >> 5)];
+        for (int p = tid; p < PL::N; p += PL::T) {
+            const int k = order[p];
+            dst[p] = lds[k + (k >> 5)];
         }
     }
 }
@@ -107,8 +109,8 @@ void set_corr_stamps(long long* d_ptr) {
 }
 
 // ------------------------------------------------------------------------------------ stage C
-template <class PL, bool KEEP_CODE, bool STAMPS>
-__global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
+template <class PLX, bool KEEP_CODE, bool STAMPS>
+__global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WAVES_PER_EU) void acq_corr_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ tw_inv,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
     const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int map_mode,
@@ -161,16 +163,25 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
         }
     }
 
-    // the inverse transform: the prime-factor form for plans with pairwise coprime radices (no twiddles: nothing to load)
-    constexpr bool PFA = CorrMode<PL>::PFA;
-    __shared__ cf lds[PL::LDS_ELEMS + (PFA ? 0 : PL::TW_TOTAL)];
+    // the inverse transform runs on the size's CORRELATION plan: the plain plan, its prime-factor form (pairwise coprime radices:
+    // no twiddles, nothing to load) or a hybrid plan (constant twiddles in the code)
+    using PL = typename CorrPlanOf<PLX>::type;
+    constexpr bool PFA = CorrMode<PL>::PFA, HYB = CorrMode<PL>::HYBRID;
+    __shared__ cf lds[PL::LDS_ELEMS + ((PFA || HYB) ? 0 : PL::TW_TOTAL)];
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
 #ifdef GM_LAB_PRIO
     if (tid >= 256) __builtin_amdgcn_s_setprio(1);
 #endif
-    if constexpr (!PFA) load_twiddles<PL>(tw, tw_inv, tid);
+    if constexpr (!PFA && !HYB) load_twiddles<PL>(tw, tw_inv, tid);
     constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    // does lane (tid, it) own outputs of the last pass, and which element is its output r
+    auto last_active = [&](int it) { if constexpr (HYB) return PL::last_active(tid); else return tid + it * PL::T < NBL; };
+    auto out_index = [&](int it, int r) {
+        if constexpr (HYB) return PL::out_index(tid, r);
+        else if constexpr (PFA) return Pfa<PL>::out_index(tid + it * PL::T, r);
+        else return (tid + it * PL::T) + r * NBL;
+    };
 
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(spectra + size_t(d) * n_int * PL::N, unsigned(n_int) * PL::N * 8u);
     const __amdgpu_buffer_rsrc_t crs = make_rsrc(code_fft + size_t(p) * PL::N, PL::N * 8u);
@@ -328,10 +339,9 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
         float* pl = reinterpret_cast<float*>(lds);
 #pragma unroll
         for (int it = 0; it < PL::ITL; ++it) {
-            const int b = tid + it * PL::T;
-            if (b < NBL) {
+            if (last_active(it)) {
 #pragma unroll
-                for (int r = 0; r < PL::RL; ++r) pl[PFA ? Pfa<PL>::out_index(b, r) : b + r * NBL] = acc[it][r];
+                for (int r = 0; r < PL::RL; ++r) pl[out_index(it, r)] = acc[it][r];
             }
         }
         __syncthreads();
@@ -352,14 +362,13 @@ __global__ __launch_bounds__(PL::T, PL::WAVES_PER_EU) void acq_corr_kernel(
     // per-lane: first strict maximum + partial sum
     float bv = 0.0f, sum = 0.0f;
     uint32_t bi = 0xffffffffu;
-    if constexpr (!PFA) {
+    if constexpr (!PFA) {      // plain and hybrid plans: the element index of a slot is an add (plain) or a handful of integer operations
 #pragma unroll
         for (int it = 0; it < PL::ITL; ++it) {
-            const int b = tid + it * PL::T;
-            if (b < NBL) {
+            if (last_active(it)) {
 #pragma unroll
                 for (int r = 0; r < PL::RL; ++r) {
-                    take_better(bv, bi, acc[it][r], uint32_t(b + r * NBL));
+                    take_better(bv, bi, acc[it][r], uint32_t(out_index(it, r)));
                     sum += acc[it][r];
                 }
             }
@@ -445,17 +454,6 @@ __global__ __launch_bounds__(PL::T) void acq_code_fft_kernel(const int8_t* __res
     constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
     lds_transform<PL, false>([&](int it, int r) { return cf_make(float(src[(tid + it * PL::T) + r * NB0]), 0.0f); },
                              [&](int it, int r, cf val) { dst[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
-}
-
-// natural-order code spectra [P][N] -> the paired layout acq_corr_kernel reads (once, at gm_acq_create)
-template <class PL>
-__global__ __launch_bounds__(256) void pair_codes_kernel(const cf* __restrict__ nat, cf* __restrict__ paired, int n_codes) {
-    const size_t total = size_t(n_codes) * PL::N;
-    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += size_t(gridDim.x) * 256) {
-        const size_t c = i / PL::N;
-        const int k = int(i - c * PL::N);
-        paired[c * PL::N + CorrLayout<PL>::slot(k)] = nat[i];
-    }
 }
 
 // ------------------------------------------------------------------------------------ plain batched FFT
@@ -631,12 +629,15 @@ template <class PL> struct Launch {
     static void fill_tw(cf* tw, bool inverse) {
         fill_twiddles<PL>(tw, inverse, [](double a) { return ::cos(a); }, [](double a) { return ::sin(a); });
     }
+    using CP = typename CorrPlanOf<PL>::type;      // the plan acq_corr_kernel's inverse runs on (acq_device.h)
+    static_assert(CP::T == PL::T && CP::N == PL::N, "the correlation plan keeps the size and the workgroup");
     static void mix_fft(hipStream_t st, const void* samples, int fmt, const cf* tables, const cf* tw_fwd,
-                        cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets) {
+                        cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets, const uint16_t* order) {
         hipLaunchKernelGGL(acq_mix_fft_kernel<PL>, dim3(n_bins * n_int), dim3(PL::T), 0, st, samples, fmt,
-                           tables, tw_fwd, spectra, n_int, clear_tickets);
+                           tables, tw_fwd, spectra, n_int, clear_tickets, order);
     }
-    static constexpr int SPLIT_SLAB = PL::ITL * ((PL::RL + 3) / 4) * 4 * PL::T;   // floats per power plane of the tail split
+    static int fill_order(uint16_t* order) { return fill_order_table<CP>(order); }
+    static constexpr int SPLIT_SLAB = CP::ITL * ((CP::RL + 3) / 4) * 4 * CP::T;   // floats per power plane of the tail split
     static void corr(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
                      int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum, int tickets_cleared) {
@@ -646,7 +647,7 @@ template <class PL> struct Launch {
         // geometry: P = 12: 125 -> 88 us, P = 24: 195 -> 165 us with equal shares; P = 32: whole bins 3 % faster.
         static const int forced = getenv("GM_CORR_MAP") ? atoi(getenv("GM_CORR_MAP")) : -1;   // diagnostic override
         const int per_xcd_bins = ((n_bins + 7) / 8) * n_workers, per_xcd_even = (n_bins * n_workers + 7) / 8;
-        const int slots = 32 * PL::WG_PER_CU;
+        const int slots = 32 * CP::WG_PER_CU;
         const int q = n_bins / 8, left = (n_bins - 8 * q) * n_workers;
         const int per_xcd_mixed = q * n_workers + (left + 7) / 8;
         int map_mode = ((per_xcd_bins + slots - 1) / slots > (per_xcd_even + slots - 1) / slots) ? 0 : 1;
@@ -686,11 +687,11 @@ template <class PL> struct Launch {
         // at the start of its allocation (cdna_hip_programming.md G16 "Re-initialise every call")
         if (split_k > 1 && !tickets_cleared) (void)hipMemsetAsync(split_counter, 0, size_t(GM_CORR_SPLIT_MAX_ITEMS) * sizeof(uint32_t), st);
         if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
-            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, true>), dim3(grid), dim3(PL::T), 0, st,
+            hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, true>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
                                split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
         else
-            hipLaunchKernelGGL((acq_corr_kernel<PL, PL::KEEP_CODE, false>), dim3(grid), dim3(PL::T), 0, st,
+            hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, false>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
                                split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
     }
@@ -698,7 +699,7 @@ template <class PL> struct Launch {
         hipLaunchKernelGGL(acq_code_fft_kernel<PL>, dim3(n_codes), dim3(PL::T), 0, st, code_samples, tw_fwd, out);
     }
     static void pair_codes(hipStream_t st, const cf* nat, cf* paired, int n_codes) {
-        hipLaunchKernelGGL(pair_codes_kernel<PL>, dim3(n_codes * 4 < 1024 ? n_codes * 4 : 1024), dim3(256), 0, st, nat, paired, n_codes);
+        hipLaunchKernelGGL(relayout_kernel<CP>, dim3(n_codes * 4 < 1024 ? n_codes * 4 : 1024), dim3(256), 0, st, nat, paired, n_codes);
     }
     static void fft_batch(hipStream_t st, cf* data, const cf* tw, int inverse, int batch) {
         if (inverse) hipLaunchKernelGGL((fft_batch_kernel<PL, true>), dim3(batch), dim3(PL::T), 0, st, data, tw);
@@ -713,8 +714,8 @@ template <class PL> struct Launch {
     }
     static constexpr PlanOps ops() {
         return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL), SPLIT_SLAB,
-                       CorrLayout<PL>::RELAYOUT ? 1 : 0,
-                       &fill_tw, &mix_fft, &corr, &code_fft, &pair_codes, &fft_batch,
+                       CorrLayout<CP>::RELAYOUT ? 1 : 0,
+                       &fill_tw, &fill_order, &mix_fft, &corr, &code_fft, &pair_codes, &fft_batch,
                        POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr, FineRows<PL>::RT};
     }
 };

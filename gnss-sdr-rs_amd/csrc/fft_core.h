@@ -394,6 +394,7 @@ template <int N_, int T_, int... Rs> struct Plan {
         return true;
     }
     static constexpr bool COPRIME = coprime();
+    static constexpr bool HYBRID = false;                     // (HybridPlan below is the other kind of plan)
     static_assert(check(), "radices must multiply to N and there must be >= 2 passes");
 };
 
@@ -551,6 +552,148 @@ template <class PL, bool INV, bool PFA = false> struct Fft {
             const int b = tid + it * PL::T;
             if (b < PL::NB(NP - 1)) Bfly<PL::RL, INV>::stage2(v[it], [&](int q, cf val) { out(it, q, val); });
         }
+    }
+};
+
+// u * W_M^{K r} (exponent sign by INV) for r known after unrolling: a compile-time table of the R constants, trivial cases folded
+template <bool INV, int K, int M, int R> struct ConstTw {
+    struct Arr { float c[R], s[R]; };
+    static constexpr Arr make() {
+        Arr a{};
+        for (int r = 0; r < R; ++r) {
+            const ct::cs v = ct::cossin2pi(long(r) * K, M);
+            a.c[r] = float(v.c);
+            a.s[r] = float(INV ? v.s : -v.s);
+        }
+        return a;
+    }
+    static constexpr Arr tab = make();
+    static GM_HD cf mul(cf u, int r) {
+        const int e = int((long(r) * K) % M);
+        if (e == 0) return u;
+        if (4 * e == M) return cf_mulj<INV>(u);
+        if (2 * e == M) return cf_make(-u.x, -u.y);
+        if (4 * e == 3 * M) return cf_mulj<!INV>(u);
+        return cf_mul(u, cf_make(tab.c[r], tab.s[r]));
+    }
+};
+
+// ------------------------------------------------------------------ hybrid prime-factor / Cooley-Tukey plan
+// N = A * B with gcd(A, B) = 1, A = A1 * A2, B = B1 * B2, gcd(A1, B1) = 1.  Across the two dimensions the transform is a
+// prime-factor (Good-Thomas) one — no twiddles between A and B — and inside each dimension a two-step Cooley-Tukey one:
+//   pass 0  radix A1*B1 : the FIRST factors of both dimensions as one 2-D butterfly (the radix-(A1 B1) Good-Thomas butterfly)
+//   pass 1  radix A2    : second factor of A, inputs twiddled by W_A^{n2 k1},  k1 in [0, A1)
+//   pass 2  radix B2    : second factor of B, inputs twiddled by W_B^{m2 j1},  j1 in [0, B1)
+// The twiddles depend on k1 / j1 only — A1 and B1 values — so the butterflies of a pass are dealt to the waves by that digit:
+// every wave holds ONE k1 (pass 1) or ONE j1 (pass 2) and its twiddles are compile-time constants of its code path
+// (mul_wconst: literals, trivial cases folded; k1 = 0 / j1 = 0 cost nothing).  No twiddle table, no power tree, no LDS reads
+// for twiddles: N = 8000 = 125 * 64 as [20, 25, 16] spends ~740 wave-instructions per transform on twiddles where the
+// plain [25, 20, 16] plan spends ~1960 (generation + application).
+// Digits.  Storage slot of the input e = (r0 R1 + r1) R2 + r2 (what lane b0 = r1 R2 + r2 of pass 0 loads as element r0),
+// r0 = (B1 n1 + A1 m1) mod R0 (Good's map inside the first butterfly), r1 = n2, r2 = m2, where the element's index i has
+// iA = i mod A = A2 n1 + n2 and iB = i mod B = B2 m1 + m2 (CRT on the input side).  Outputs: q0 <-> (k1 = q0 mod A1,
+// j1 = q0 mod B1), q1 = k2, q2 = j2; oA = k1 + A1 k2, oB = j1 + B1 j2, element o = (B oA + A oB) mod N (Good's map on the
+// output side).  LDS images between the passes are laid out for conflict-free access by the lane order of the pass that
+// reads them (see pos1 / pos2).
+template <int N_, int T_, int A1_, int A2_, int B1_, int B2_> struct HybridPlan {
+    static constexpr int N = N_, T = T_, NP = 3;
+    static constexpr int A1 = A1_, A2 = A2_, B1 = B1_, B2 = B2_, A = A1_ * A2_, B = B1_ * B2_;
+    static constexpr int R[3] = {A1_ * B1_, A2_, B2_};
+    static constexpr int P(int s) { int p = 1; for (int i = 0; i < s; ++i) p *= R[i]; return p; }
+    static constexpr int NB(int s) { return N / R[s]; }
+    static constexpr int IT(int s) { return (NB(s) + T - 1) / T; }
+    static constexpr int TWOFF(int) { return 0; }
+    static constexpr int TW_TOTAL = 0, PAD_Q = 0;
+    static constexpr int R0 = R[0], IT0 = IT(0), RL = R[2], ITL = IT(2);
+    // image after pass 0: (q0, r1, r2) at r1*STR1 + k1*GS1 + j1*R2 + r2; after pass 1: (q0, q1, r2) at r2*STR2 + j1*A + k1*A2 + q1
+    static constexpr int STR1 = R[0] * R[2], GS1 = B1_ * R[2], STR2 = R[0] * R[1] + 1;
+    static constexpr int LDS_ELEMS = (A2_ * STR1 > B2_ * STR2) ? A2_ * STR1 : B2_ * STR2;
+    static constexpr int GW1 = GS1 / 64;                      // waves per k1 group of pass 1
+    static constexpr int GW2 = (A + 63) / 64;                 // waves per j1 group of the last pass
+    static constexpr bool KEEP_CODE = false, COPRIME = false, HYBRID = true;
+    static constexpr int LDS_BYTES = 8 * LDS_ELEMS;
+    static constexpr int WG_PER_CU = (2 * LDS_BYTES <= 160 * 1024 && T <= 1024) ? 2 : 1;
+    static constexpr int WAVES_PER_EU = (WG_PER_CU * T / 64 + 3) / 4;
+    static_assert(A1_ * A2_ * B1_ * B2_ == N_ && ct::gcd(A1_ * A2_, B1_ * B2_) == 1 && ct::gcd(A1_, B1_) == 1, "N = A*B, A and B coprime");
+    static_assert(IT(0) == 1 && IT(1) == 1 && IT(2) == 1, "one butterfly per lane and pass");
+    static_assert(GS1 % 64 == 0 && A1_ * GW1 * 64 <= T_ && B1_ * GW2 * 64 <= T_, "wave groups must fit the workgroup");
+
+    // element index -> storage slot, and back; (lane of the last pass, output q2) -> element index
+    static GM_HD int in_slot(int i) {
+        const int ia = i % A, ib = i % B;
+        const int n1 = ia / A2_, n2 = ia % A2_, m1 = ib / B2_, m2 = ib % B2_;
+        const int r0 = (B1_ * n1 + A1_ * m1) % R[0];
+        return (r0 * R[1] + n2) * R[2] + m2;
+    }
+    static GM_HD int slot_to_index(int e) {
+        const int m2 = e % R[2], n2 = (e / R[2]) % R[1], r0 = e / (R[1] * R[2]);
+        // r0 = (B1 n1 + A1 m1) mod R0  ->  n1 = r0 * B1^-1 mod A1, m1 = r0 * A1^-1 mod B1
+        const int n1 = (r0 * int(ct::modinv(B1_, A1_))) % A1_, m1 = (r0 * int(ct::modinv(A1_, B1_))) % B1_;
+        const int ia = A2_ * n1 + n2, ib = B2_ * m1 + m2;
+        // i = ia mod A, ib mod B
+        constexpr long ca = long(B) * ct::modinv(B, A), cb = long(A) * ct::modinv(A, B);
+        return int((ca * ia + cb * ib) % N);
+    }
+    // last pass: wave group j1, lane-in-group beta = k1*A2 + q1
+    static GM_HD int last_j1(int tid) { return (tid >> 6) / GW2; }
+    static GM_HD int last_beta(int tid) { return ((tid >> 6) % GW2) * 64 + (tid & 63); }
+    static GM_HD bool last_active(int tid) { return last_j1(tid) < B1_ && last_beta(tid) < A; }
+    static GM_HD int out_index(int tid, int q2) {
+        const int beta = last_beta(tid), j1 = last_j1(tid);
+        const int oa = beta / A2_ + A1_ * (beta % A2_), ob = j1 + B1_ * q2;
+        return (B * oa + A * ob) % N;
+    }
+};
+
+template <int N_, int T_, int A1, int A2, int B1, int B2, bool INV>
+struct Fft<HybridPlan<N_, T_, A1, A2, B1, B2>, INV, false> {
+    using PL = HybridPlan<N_, T_, A1, A2, B1, B2>;
+    static constexpr int R0 = PL::R[0], R1 = PL::R[1], R2 = PL::R[2];
+
+    template <class In> static GM_HD void pass0_stage1(cf (&v)[1][R0], In&& in, int tid) {
+        if (tid < PL::NB(0)) Bfly<R0, INV>::stage1([&](int r) { return in(0, r); }, v[0]);
+    }
+    static GM_HD void pass0_stage2(const cf (&v)[1][R0], cf* lds, int tid) {
+        if (tid < PL::NB(0)) {
+            cf* dst = lds + (tid / R2) * PL::STR1 + tid % R2;           // lane b0 = r1 R2 + r2
+            Bfly<R0, INV>::stage2(v[0], [&](int q0, cf val) { dst[(q0 % A1) * PL::GS1 + (q0 % B1) * R2] = val; });
+        }
+    }
+    // pass 1: wave group k1 = wave / GW1, lane-in-group lambda = j1 R2 + r2
+    template <int K1> static GM_HD void p1_s1(cf (&v)[R1], const cf* lds, int lam) {
+        const cf* src = lds + K1 * PL::GS1 + lam;
+        Bfly<R1, INV>::stage1([&](int r) { return ConstTw<INV, K1, PL::A, R1>::mul(src[r * PL::STR1], r); }, v);
+    }
+    template <int K1> static GM_HD void p1_disp(cf (&v)[R1], const cf* lds, int k1, int lam) {
+        if (k1 == K1) p1_s1<K1>(v, lds, lam);
+        else if constexpr (K1 + 1 < A1) p1_disp<K1 + 1>(v, lds, k1, lam);
+    }
+    template <int S> static GM_HD void mid_stage1(cf (&v)[1][R1], const cf* lds, const cf*, int tid) {
+        static_assert(S == 1, "three passes");
+        const int wave = tid >> 6, k1 = wave / PL::GW1, lam = (wave % PL::GW1) * 64 + (tid & 63);
+        if (k1 < A1) p1_disp<0>(v[0], lds, k1, lam);
+    }
+    template <int S> static GM_HD void mid_stage2(const cf (&v)[1][R1], cf* lds, int tid) {
+        const int wave = tid >> 6, k1 = wave / PL::GW1, lam = (wave % PL::GW1) * 64 + (tid & 63);
+        if (k1 < A1) {
+            cf* dst = lds + (lam % R2) * PL::STR2 + (lam / R2) * PL::A + k1 * A2;   // r2, j1 of lambda
+            Bfly<R1, INV>::stage2(v[0], [&](int q1, cf val) { dst[q1] = val; });
+        }
+    }
+    template <int J1> static GM_HD void p2_s1(cf (&v)[R2], const cf* lds, int beta) {
+        const cf* src = lds + J1 * PL::A + beta;
+        Bfly<R2, INV>::stage1([&](int r) { return ConstTw<INV, J1, PL::B, R2>::mul(src[r * PL::STR2], r); }, v);
+    }
+    template <int J1> static GM_HD void p2_disp(cf (&v)[R2], const cf* lds, int j1, int beta) {
+        if (j1 == J1) p2_s1<J1>(v, lds, beta);
+        else if constexpr (J1 + 1 < B1) p2_disp<J1 + 1>(v, lds, j1, beta);
+    }
+    static GM_HD void last_stage1(cf (&v)[1][R2], const cf* lds, const cf*, int tid) {
+        if (PL::last_active(tid)) p2_disp<0>(v[0], lds, PL::last_j1(tid), PL::last_beta(tid));
+    }
+    // out(0, q2, value): element PL::out_index(tid, q2)
+    template <class Out> static GM_HD void last_stage2(const cf (&v)[1][R2], Out&& out, int tid) {
+        if (PL::last_active(tid)) Bfly<R2, INV>::stage2(v[0], [&](int q, cf val) { out(0, q, val); });
     }
 };
 

@@ -37,6 +37,9 @@ template <> struct PlanRot<Plan8000> { static constexpr int rot(int s) { return 
 #endif
 }  // namespace gm
 
+// correlation plans (acq_device.h CorrPlanOf): 8000 = 125 * 64 as the hybrid [5*4, 25, 16] with constant twiddles per wave
+#include "acq_corr_plans.h"
+
 #ifndef GM_FOR_EACH_PLAN   // tools/corr_lab restricts the list to one plan for fast experimental builds
 #define GM_FOR_EACH_PLAN(X) \
     X(gm::Plan8000) X(gm::Plan16368) X(gm::Plan4096) X(gm::Plan2048) X(gm::Plan1024) \

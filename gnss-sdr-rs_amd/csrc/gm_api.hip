@@ -209,6 +209,7 @@ struct gm_acq {
     std::vector<uint8_t> prn_ids, dev_prn_ids;
     cf *d_tables = nullptr, *d_tw_fwd = nullptr, *d_tw_inv = nullptr, *d_code_fft = nullptr, *d_spectra = nullptr;
     cf* d_code_fft_paired = nullptr;   // Q == 1: the code spectra in the layout acq_corr_kernel reads (PairLayout)
+    uint16_t* d_order = nullptr;       // Q == 1, permuted storage orders: element index stored at each position (PlanOps::fill_order)
     float* d_table_freq = nullptr;
     int8_t* d_code_samples = nullptr;
     void* d_samples = nullptr;
@@ -483,7 +484,7 @@ int gm_acq_destroy(gm_acq* a) {
     hipFree(a->fine.d_rowmax); hipFree(a->fine.d_rowarg); hipFree(a->fine.d_sat_worker); hipFree(a->fine.d_sat_cp);
     hipFree(a->fine.d_peak_pow); hipFree(a->fine.d_peak_idx);
     if (a->device >= 0) hipSetDevice(a->device);
-    hipFree(a->d_tables); hipFree(a->d_tw_fwd); hipFree(a->d_tw_inv); hipFree(a->d_code_fft); hipFree(a->d_code_fft_paired);
+    hipFree(a->d_tables); hipFree(a->d_tw_fwd); hipFree(a->d_tw_inv); hipFree(a->d_code_fft); hipFree(a->d_code_fft_paired); hipFree(a->d_order);
     hipFree(a->d_spectra); hipFree(a->d_table_freq); hipFree(a->d_code_samples); hipFree(a->d_samples);
     hipFree(a->d_metrics); hipFree(a->d_worker_list); hipFree(a->d_results); hipFree(a->d_found);
     hipFree(a->d_prn_ids);
@@ -594,6 +595,13 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     HIPA(hipMemcpy(a->d_prn_ids, a->prn_ids.data(), P, hipMemcpyHostToDevice));
     a->dev_prn_ids = a->prn_ids;
     // replica spectra: forward FFT of the resampled code (:136-138)
+    int (*fill_order)(uint16_t*) = a->Q == 1 ? pl->fill_order : comp->fill_order;
+    if (const int n_order = fill_order(nullptr)) {      // this (base) size's correlation plan reads a permuted spectrum
+        std::vector<uint16_t> order(static_cast<size_t>(n_order), 0);
+        fill_order(order.data());
+        HIPA(hipMalloc(&a->d_order, order.size() * sizeof(uint16_t)));
+        HIPA(hipMemcpy(a->d_order, order.data(), order.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     if (a->Q == 1) {
         pl->code_fft(a->stream, a->d_code_samples, a->d_tw_fwd, a->d_code_fft, int(P));
         HIPA(hipMalloc(&a->d_code_fft_paired, P * N * 8));
@@ -606,9 +614,9 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
         std::vector<gm::cf> twn(N);
         comp->fill_twn(twn.data());
         HIPA(hipMemcpy(a->d_comp_twn, twn.data(), N * 8, hipMemcpyHostToDevice));
-        comp->fwd_sub(a->stream, nullptr, GM_FMT_C32, nullptr, a->d_code_samples, a->d_tw_fwd, a->d_comp_tmp, uint32_t(P), 1);
-        comp->fwd_post(a->stream, a->d_comp_tmp, a->d_code_fft, uint32_t(P), 0);
-        pl->pair_codes(a->stream, a->d_code_fft, a->d_code_fft_paired, int(P * a->Q));
+        comp->fwd_sub(a->stream, nullptr, GM_FMT_C32, nullptr, a->d_code_samples, a->d_tw_fwd, a->d_comp_tmp, uint32_t(P), 1, nullptr);
+        comp->fwd_post(a->stream, a->d_comp_tmp, a->d_code_fft, uint32_t(P), 0, nullptr);
+        comp->relayout(a->stream, a->d_code_fft, a->d_code_fft_paired, int(P * a->Q));
         HIPA(hipMalloc(&a->d_code_comb, P * a->Q * N * 8));      // [code][n1][k1][pos]: the whole code-side factor per sub-transform
         comp->comb(a->stream, a->d_code_fft_paired, a->d_comp_twn, a->d_code_comb, uint32_t(P));
     }
@@ -647,10 +655,10 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     hipEvent_t* ev = t ? &a->tm.ev[size_t(a->tm.count % Timing::CAP) * 4] : nullptr;
     if (t) HIPC(hipEventRecord(ev[0], a->stream));
     if (a->Q == 1) {
-        a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_fwd, a->d_spectra, int(a->D), int(a->M), a->d_split_counter);
+        a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_fwd, a->d_spectra, int(a->D), int(a->M), a->d_split_counter, a->d_order);
     } else {
-        a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_fwd, a->d_comp_tmp, a->D * a->M, a->M);
-        a->comp->fwd_post(a->stream, a->d_comp_tmp, a->d_spectra, a->D * a->M, 1);
+        a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_fwd, a->d_comp_tmp, a->D * a->M, a->M, a->d_order);
+        a->comp->fwd_post(a->stream, a->d_comp_tmp, a->d_spectra, a->D * a->M, 1, a->d_order);
     }
     if (t) HIPC(hipEventRecord(ev[1], a->stream));
     if (a->Q == 1) {

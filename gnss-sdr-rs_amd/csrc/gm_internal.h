@@ -32,12 +32,16 @@ struct PlanOps {
     int split_slab;    // floats of one partial power plane of the tail split (0: this plan cannot split)
     int code_paired;   // 1: corr() takes the code spectra in the paired layout (pair_codes), 0: in natural order
     void (*fill_tw)(cf* tw, bool inverse);
+    // order[p] = the spectrum element index stored at position p of a stored spectrum, for sizes whose correlation plan reads its
+    // input in a permuted order (prime-factor / hybrid plans); returns the table length (0: natural or merely paired order,
+    // no table).  order == nullptr: just the length.
+    int (*fill_order)(uint16_t* order);
     // stage F: carrier mix (apply_doppler_shift, doppler_shift.rs:25-58) fused into the forward FFT
     // (do_acquisition.rs:177-182).  One workgroup per (doppler bin, ms block); shared by all PRNs.
     // clear_tickets (may be null): the tail split's ticket counters, zeroed by the first workgroup for the corr() launch
     // that follows on the same stream (saves that launch its own hipMemsetAsync: ~8 us per dwell)
     void (*mix_fft)(hipStream_t, const void* samples, int fmt, const cf* tables, const cf* tw_fwd,
-                    cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets);
+                    cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets, const uint16_t* order);
     // stage C (spectra and code_fft in the PAIRED layout): x conj(code spectrum) -> inverse FFT -> |.|^2 accumulated over the integrations ->
     // {max, first argmax, sum} per (worker, bin)  (do_acquisition.rs:184-202, 229-235)
     void (*corr)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
@@ -75,10 +79,11 @@ void set_corr_stamps(long long* d_ptr);
 struct CompOps {
     int nb, q;         // base in-LDS plan length and the factor: N = q * nb
     // forward step 1: Q in-LDS transforms per item over the decimated inputs (signal: carrier mix fused; codes: int8 chips)
+    // order (may be null): the base plan's PlanOps::fill_order table -> A leaves in storage order (permuted correlation plans)
     void (*fwd_sub)(hipStream_t, const void* samples, int fmt, const cf* tables, const int8_t* code_samples,
-                    const cf* tw_fwd, cf* A, uint32_t n_items, uint32_t n_int);
+                    const cf* tw_fwd, cf* A, uint32_t n_items, uint32_t n_int, const uint16_t* order);
     // forward step 2: twiddle + Q-point DFTs -> natural block order; paired != 0 stores each block in the paired layout
-    void (*fwd_post)(hipStream_t, const cf* A, cf* X, uint32_t n_items, int paired);
+    void (*fwd_post)(hipStream_t, const cf* A, cf* X, uint32_t n_items, int paired, const uint16_t* order);
     // inverse, fused: {max, first argmax, sum} per (worker, bin) straight from the spectra
     void (*corr)(hipStream_t, const cf* spectra, const cf* code_paired, const cf* twn, const cf* tw_inv, float* mmax,
                  uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int);
@@ -86,6 +91,10 @@ struct CompOps {
     // once per handle: comb[p][n1][k1][pos] = conj(code_paired[p][k1][pos]) * W_Q^{-n1 k1} * twn[n1][pos], the whole code-side
     // factor of sub-transform n1 (the codes are static, so corr multiplies a spectrum value by ONE table entry)
     void (*comb)(hipStream_t, const cf* code_paired, const cf* twn, cf* comb, uint32_t n_codes);
+    // the stored order of a block of Nb spectrum elements on THIS path (its plan may differ from the fused kernels': CompPlanOf):
+    // order table as PlanOps::fill_order, and natural -> stored re-layout of n_blocks blocks
+    int (*fill_order)(uint16_t* order);
+    void (*relayout)(hipStream_t, const cf* natural, cf* stored, int n_blocks);
 };
 const CompOps* find_comp(uint32_t n);
 

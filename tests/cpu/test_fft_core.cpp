@@ -79,8 +79,61 @@ template <class PL, bool INV, bool PFA = false> static double run_plan(const cha
     return err;
 }
 
+// hybrid prime-factor / Cooley-Tukey plans (fft_core.h HybridPlan): element i at slot in_slot(i), output (lane, q2) is element
+// out_index(lane, q2); slot_to_index must invert in_slot
+template <class HP, bool INV> static double run_hybrid(const char* name) {
+    constexpr int N = HP::N, T = HP::T;
+    std::vector<cf> x(N), xs(N), y(N, cf_make(1e30f, 1e30f)), lds(HP::LDS_ELEMS);
+    unsigned s = 777u + N;
+    for (int i = 0; i < N; ++i) {
+        s = s * 1664525u + 1013904223u; float a = float(int(s >> 8) % 2001 - 1000) / 100.f;
+        s = s * 1664525u + 1013904223u; float b = float(int(s >> 8) % 2001 - 1000) / 100.f;
+        x[i] = cf_make(a, b);
+    }
+    std::vector<char> seen(N, 0);
+    for (int i = 0; i < N; ++i) {
+        const int e = HP::in_slot(i);
+        if (e < 0 || e >= N || seen[e] || HP::slot_to_index(e) != i) { std::printf("%s: in_slot / slot_to_index broken at %d\n", name, i); return 1.0; }
+        seen[e] = 1;
+        xs[e] = x[i];
+    }
+    using F = Fft<HP, INV>;
+    {
+        std::vector<cf> regs(size_t(T) * HP::R0);
+        for (int tid = 0; tid < T; ++tid)
+            F::pass0_stage1(*reinterpret_cast<cf(*)[1][HP::R0]>(&regs[size_t(tid) * HP::R0]), [&](int, int r) { return xs[tid + r * HP::NB(0)]; }, tid);
+        for (int tid = 0; tid < T; ++tid) F::pass0_stage2(*reinterpret_cast<cf(*)[1][HP::R0]>(&regs[size_t(tid) * HP::R0]), lds.data(), tid);
+    }
+    {
+        std::vector<cf> regs(size_t(T) * HP::R[1]);
+        for (int tid = 0; tid < T; ++tid) F::template mid_stage1<1>(*reinterpret_cast<cf(*)[1][HP::R[1]]>(&regs[size_t(tid) * HP::R[1]]), lds.data(), nullptr, tid);
+        for (int tid = 0; tid < T; ++tid) F::template mid_stage2<1>(*reinterpret_cast<cf(*)[1][HP::R[1]]>(&regs[size_t(tid) * HP::R[1]]), lds.data(), tid);
+    }
+    for (int tid = 0; tid < T; ++tid) {
+        cf v[1][HP::RL];
+        F::last_stage1(v, lds.data(), nullptr, tid);
+        F::last_stage2(v, [&](int, int q, cf val) { y[HP::out_index(tid, q)] = val; }, tid);
+    }
+    std::vector<std::complex<double>> w(N);
+    for (int i = 0; i < N; ++i) w[i] = std::polar(1.0, (INV ? 2.0 : -2.0) * M_PI * i / N);
+    double num = 0, den = 0;
+    for (int k = 0; k < N; ++k) {
+        std::complex<double> acc = 0;
+        size_t idx = 0;
+        for (int n = 0; n < N; ++n) { acc += std::complex<double>(x[n].x, x[n].y) * w[idx]; idx += k; if (idx >= size_t(N)) idx -= N; }
+        std::complex<double> d = acc - std::complex<double>(y[k].x, y[k].y);
+        num += std::norm(d); den += std::norm(acc);
+    }
+    const double err = std::sqrt(num / den);
+    std::printf("%-28s N=%6d T=%4d %s hybrid rel_l2_err=%.3e lds_elems=%d\n", name, N, T, INV ? "inv" : "fwd", err, HP::LDS_ELEMS);
+    return err;
+}
+
 int main() {
     double worst = 0;
+    worst = std::fmax(worst, run_hybrid<HybridPlan<8000, 512, 5, 25, 4, 16>, true>("Hybrid8000 [20,25,16]"));
+    worst = std::fmax(worst, run_hybrid<HybridPlan<8000, 512, 5, 25, 4, 16>, false>("Hybrid8000 [20,25,16]"));
+    worst = std::fmax(worst, run_hybrid<HybridPlan<16000, 1024, 5, 25, 4, 32>, true>("Hybrid16000 [20,25,32]"));
 #define RUN(PL) worst = std::fmax(worst, run_plan<PL, false>(#PL)); worst = std::fmax(worst, run_plan<PL, true>(#PL)); \
     if constexpr (PL::COPRIME) { worst = std::fmax(worst, run_plan<PL, false, true>(#PL)); worst = std::fmax(worst, run_plan<PL, true, true>(#PL)); }
     GM_FOR_EACH_PLAN(RUN)
