@@ -284,8 +284,41 @@ def test_native_comm_single_rank_allgather_and_decide(gpu, hipbuf):
     key = lambda r: r and (r["prn"], r["code_phase_samples"], r["doppler_bin"], r["mag_relative"])
     assert [key(r) for r in got] == [key(r) for r in ref]
     assert sum(r is not None for r in got) == 2
+    # the overlapped form (exchange on the communicator's own stream, gm_comm_wait before the block is read) and the raw
+    # word all-gather the mixed-constellation grid uses (gm_comm_allgather_words)
+    from gnss_sdr_rs_amd._lib import lib, check
+    d_all2 = hipbuf.alloc(3 * P * D * 4, fill=0xEE)
+    eng.set_stream(0)                              # the handle on the NULL stream, which is also what gm_comm_wait is given below
+    eng.search_dev(d_x, A.FMT_C32, d_met)
+    comm.allgather_metrics_async(eng, d_all2, d_met)
+    comm.wait(0)
+    eng.decide_dev(d_all2, n_prn=P, prn_ids=np.asarray(prns, np.uint8))
+    got2 = eng.fetch_results(P)
+    assert (hipbuf.download(d_all2, 3 * P * D * 4, np.uint32) == hipbuf.download(d_met, 3 * P * D * 4, np.uint32)).all()
+    assert [key(r) for r in got2] == [key(r) for r in ref]
+    d_raw = hipbuf.alloc(3 * P * D * 4, fill=0x11)
+    eng.synchronize()
+    comm.allgather_words(d_met, d_raw, 3 * P * D, 0)
+    assert (hipbuf.download(d_raw, 3 * P * D * 4, np.uint32) == hipbuf.download(d_met, 3 * P * D * 4, np.uint32)).all()
     comm.close()
     eng.close()
+
+
+def test_composite_sizes_accepted_and_rejected(gpu):
+    """The transform sizes beyond one LDS buffer the acquisition handle takes are exactly Q x base with Q in {2,3,4,5,6,8} and
+    base in {16000, 8000, 8192, 6000, 5000, 4000} (acq_composite.hip); everything else — e.g. 2 x 16368, 8 x 16384, whose
+    base plans start with a radix above 25 — is GM_ERR_UNSUPPORTED_N, not a silent fallback."""
+    from gnss_sdr_rs_amd import acquisition as A, GmError
+    dop = np.array([0.0], np.float32)
+    ok, bad = (32000, 25000, 40000, 48000, 65536), (32736, 49104, 131072, 34000, 30000 * 3)
+    for n in ok:
+        eng = A.AcquisitionEngine(float(n) * 1000.0, 0.0, n, doppler_hz=dop, prn_ids=[1], n_integrations=1)
+        assert eng.fft_size == n
+        eng.close()
+    for n in bad:
+        with pytest.raises(GmError) as e:
+            A.AcquisitionEngine(float(n) * 1000.0, 0.0, n, doppler_hz=dop, prn_ids=[1], n_integrations=1)
+        assert e.value.status in (-2, -6), str(e.value)      # GM_ERR_UNSUPPORTED_N / GM_ERR_ALIGNMENT
 
 
 def test_finer_doppler_vs_oracle_cfg2(gpu, oracle):
