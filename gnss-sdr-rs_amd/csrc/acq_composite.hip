@@ -22,6 +22,7 @@
 // algorithmic bytes).  Here every spectrum element is re-read Q times from L2 (once per n1), which costs pass-0 load
 // slots but no HBM traffic: the working set is the spectra (D*M*N*8 B) and the code spectra (P*N*8 B).
 #include "acq_device.h"
+#include <cstdlib>
 #include <vector>
 
 namespace gm {
@@ -146,16 +147,29 @@ template <class PLX, uint32_t Q>
 __global__ __launch_bounds__(CompPlanOf<PLX>::type::T, CompPlanOf<PLX>::type::WAVES_PER_EU) void comp_corr_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ twn, const cf* __restrict__ tw_inv,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
-    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int) {
+    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int cb, int rows_max) {
     using PL = typename CompPlanOf<PLX>::type;      // the base size's plan for this path (acq_device.h): plain or hybrid
     constexpr bool HYB = CorrMode<PL>::HYBRID;
     static_assert(!CorrMode<PL>::PFA, "composite bases: plain or hybrid correlation plans");
     static_assert(PL::IT0 == 1 && PairLayout<PL>::PAIRED, "composite base plans: one pass-0 butterfly per lane, paired layout");
-    // equal contiguous share of the bin-major item list per XCD (blocks b and b + 8 share an XCD: speed only)
+    // Equal contiguous share of the bin-major item list per XCD (blocks b and b + 8 share an XCD: speed only).  Inside an XCD
+    // the share — a strip of rows_max Doppler bins, ragged at both ends — is walked in blocks of `cb` workers: the ~32
+    // workgroups resident on the XCD at a time then cover cb workers x all of the strip's bins, so every combined code table
+    // (Q*N*8 bytes per worker) is shared by ~5 workgroups and every bin's spectra by cb of them, instead of 32 workers x 1 bin
+    // (each table read by one workgroup only: 1.59 GB of fabric traffic per dwell at the configs[3] Galileo geometry).
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int items = n_bins * n_workers, share = (items + 7) >> 3;
-    const int item = xcd * share + slot;
-    if (slot >= share || item >= items) return;
+    const int it_lo = xcd * share, it_hi = it_lo + share < items ? it_lo + share : items;
+    int item;
+    if (cb <= 0) {
+        item = it_lo + slot;
+        if (slot >= share || item >= it_hi) return;
+    } else {
+        const int d_lo = it_lo / n_workers, per_blk = rows_max * cb;
+        const int blk = slot / per_blk, rem = slot - blk * per_blk, dr = rem / cb, w = blk * cb + (rem - dr * cb);
+        item = (d_lo + dr) * n_workers + w;
+        if (w >= n_workers || item < it_lo || item >= it_hi) return;
+    }
     const int d = item / n_workers, p = int(worker_list[item - d * n_workers]);
 
     __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];
@@ -273,9 +287,16 @@ template <class PL, uint32_t Q> struct CompLaunch {
     static void corr(hipStream_t st, const cf* spectra, const cf* code_paired, const cf* twn, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int) {
         if (n_workers <= 0) return;
-        const int share = (n_workers * n_bins + 7) / 8;
-        hipLaunchKernelGGL((comp_corr_kernel<PL, Q>), dim3(8 * share), dim3(PL::T), 0, st, spectra, code_paired, twn, tw_inv,
-                           mmax, margmax, msum, worker_list, n_workers, n_bins, n_int);
+        static const int cb_env = getenv("GM_COMP_CB") ? atoi(getenv("GM_COMP_CB")) : -1;   // diagnostic: workers per block (0: plain order)
+        const int items = n_workers * n_bins, share = (items + 7) / 8;
+        // measured at 36 codes x 41 bins x N = 2 x 16000: plain order 0.351 ms, blocks of 4 / 8 / 12 workers 0.313 / 0.314 / 0.314,
+        // blocks of 2 or 6 no gain (6 x ~5 bins is exactly the resident set: every workgroup of a round then starts a new table)
+        const int cb = cb_env >= 0 ? cb_env : (n_workers > 4 ? 4 : 0);
+        // bins a strip can touch: a share of `share` items starting anywhere in a row
+        const int rows_max = (share + n_workers - 2) / n_workers + 1;
+        const int slots = cb > 0 ? ((n_workers + cb - 1) / cb) * rows_max * cb : share;
+        hipLaunchKernelGGL((comp_corr_kernel<PL, Q>), dim3(8 * slots), dim3(PL::T), 0, st, spectra, code_paired, twn, tw_inv,
+                           mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, cb, rows_max);
     }
     // W_N^{-n1 k2} (inverse sign) for n1 < Q, in the paired position of k2: built in double on the host
     static void fill_twn(cf* out) {

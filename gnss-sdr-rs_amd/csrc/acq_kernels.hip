@@ -145,6 +145,17 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
         if (slot >= share || item >= items) return;
         d = item / n_workers;
         p = int(worker_list[item - d * n_workers]);
+    } else if (map_mode >= 16) {  // equal shares as in mode 0, walked in blocks of cb = map_mode >> 4 workers x the share's strip of bins
+        // (the workgroups resident on an XCD at a time then share code spectra AND bin spectra; see comp_corr_kernel)
+        const int cb = map_mode >> 4, rows_max = map_mode & 15;
+        const int items = n_bins * n_workers, share = (items + 7) >> 3;
+        const int it_lo = xcd * share, it_hi = it_lo + share < items ? it_lo + share : items;
+        const int d_lo = it_lo / n_workers, per_blk = rows_max * cb;
+        const int blk = slot / per_blk, rem = slot - blk * per_blk, dr = rem / cb, w = blk * cb + (rem - dr * cb);
+        const int item = (d_lo + dr) * n_workers + w;
+        if (w >= n_workers || item < it_lo || item >= it_hi) return;
+        d = d_lo + dr;
+        p = int(worker_list[w]);
     } else if (map_mode == 1) {   // whole bins per XCD (bin d on XCD d % 8)
         d = xcd + 8 * (slot / n_workers);
         if (d >= n_bins) return;
@@ -653,7 +664,17 @@ template <class PL> struct Launch {
         int map_mode = ((per_xcd_bins + slots - 1) / slots > (per_xcd_even + slots - 1) / slots) ? 0 : 1;
         if (map_mode == 1 && per_xcd_mixed < per_xcd_bins) map_mode = 2;   // same locality, balanced leftovers
         if (forced >= 0) map_mode = forced;
-        const int share = map_mode == 0 ? per_xcd_even : (map_mode == 1 ? per_xcd_bins : per_xcd_mixed);
+        // GM_CORR_CB = cb (diagnostic, and the default for one-workgroup-per-CU plans below): tiled walk of the equal shares
+        static const int cb_env = getenv("GM_CORR_CB") ? atoi(getenv("GM_CORR_CB")) : -1;
+        int cb = cb_env >= 0 ? cb_env : 0;
+        int share = map_mode == 0 ? per_xcd_even : (map_mode == 1 ? per_xcd_bins : per_xcd_mixed);
+        if (cb > 0) {
+            const int rows_max = (per_xcd_even + n_workers - 2) / n_workers + 1;
+            if (rows_max <= 15 && cb <= 1000) {
+                map_mode = (cb << 4) | rows_max;
+                share = ((n_workers + cb - 1) / cb) * rows_max * cb;       // slots per XCD, the ragged ends' empty ones included
+            }
+        }
         // Grid tail.  When the queue of an XCD runs dry its resident workgroups finish one by one, and the launch ends a
         // whole workgroup duration (M transforms, ~45 us alone on a CU) after the last one started: about half a duration
         // of idle slots.  The LAST items of every XCD are therefore cut into n_int parts of one integration each, enough of
@@ -671,6 +692,9 @@ template <class PL> struct Launch {
             const bool all = share <= slots;
             // one integration per part (see the kernel): k = n_int, when the scratch holds the planes
             if (n_int >= 2 && n_int <= GM_CORR_SPLIT_MAX_K && (!all || share * n_int <= GM_CORR_SPLIT_MAX_SLABS / 8)) split_k = n_int;
+            // one workgroup per CU (N = 16368 ...): the cut tail does not pay on a grid of several rounds (0.440 against 0.432 ms
+            // per 32-PRN launch with and without); it stays for grids that fit the chip at once, where it multiplies the parallelism
+            if (CP::WG_PER_CU == 1 && !all && split_env < 0) split_k = 1;
             if (split_env == 1) split_k = 1;
             if (split_k > 1) {
                 split_items = items_env > 0 ? items_env : (all ? share : (slots + split_k - 1) / split_k);
