@@ -428,7 +428,7 @@ def main():
             out["tracking"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ the same kernel with 256 channels (informative)
-    if rank == 0 and world == 1 and not args.no_tracking:
+    if rank == 0 and world == 1 and not args.no_tracking and os.environ.get("GM_BENCH_NO_TRK256") != "1":   # (off in the counter passes: same grid size as C = 32)
         try:
             t256 = tracking_leg(torch, dev, stream, ca, T, synth, 1, dist, 0.0, C=256)
             out["tracking_256ch"] = {k: t256[k] for k in ("value", "unit", "channels_per_gpu", "ms_per_epoch", "channels_locked", "roofline")}

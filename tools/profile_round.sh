@@ -16,6 +16,7 @@ echo "bench done"
 cd /tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $R/bench.py > $OUT/stats_stdout.log 2>&1 || exit 2
 echo "stats done"
+export GM_BENCH_NO_TRK256=1   # the 256-channel tracking leg launches the same kernel at the same grid size as configs[2]: keep the counter averages per shape
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o run -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || exit 3
 echo "fetch done"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o run -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || exit 4
