@@ -9,6 +9,12 @@ namespace gm {
 
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
 
+// hybrid plans run their middle pass in place per wave group (fft_core.h): a one-wave group orders its own LDS reads before its
+// writes by program order alone
+template <class PL> constexpr bool mid_pass_needs_barrier() {
+    if constexpr (PL::HYBRID) return PL::P1_NEEDS_BARRIER;
+    else return true;
+}
 template <class PL, bool INV, int S, bool PFA = false> struct MiddlePasses {
     // st(k): optional diagnostic stamp hook, called only next to barriers (k = 4.. in program order)
     template <class St = NoStamp>
@@ -17,7 +23,9 @@ template <class PL, bool INV, int S, bool PFA = false> struct MiddlePasses {
             cf v[PL::IT(S)][PL::R[S]];
             Fft<PL, INV, PFA>::template mid_stage1<S>(v, lds, tw, tid);
             st(4);
-            __syncthreads();   // every lane has read its inputs: the image may be overwritten
+            if constexpr (mid_pass_needs_barrier<PL>()) __syncthreads();   // every lane has read its inputs: the image may be overwritten
+            else __builtin_amdgcn_sched_barrier(0);   // no hardware barrier, but the two halves stay apart in the schedule (the
+                                                      // butterfly's second half pulled over the first cost 65 spilled registers)
             st(5);
             Fft<PL, INV, PFA>::template mid_stage2<S>(v, lds, tid);
             st(6);

@@ -605,10 +605,17 @@ template <int N_, int T_, int A1_, int A2_, int B1_, int B2_> struct HybridPlan 
     static constexpr int TWOFF(int) { return 0; }
     static constexpr int TW_TOTAL = 0, PAD_Q = 0;
     static constexpr int R0 = R[0], IT0 = IT(0), RL = R[2], ITL = IT(2);
-    // image after pass 0: (q0, r1, r2) at r1*STR1 + k1*GS1 + j1*R2 + r2; after pass 1: (q0, q1, r2) at r2*STR2 + j1*A + k1*A2 + q1
-    static constexpr int STR1 = R[0] * R[2], GS1 = B1_ * R[2], STR2 = R[0] * R[1] + 1;
-    static constexpr int LDS_ELEMS = (A2_ * STR1 > B2_ * STR2) ? A2_ * STR1 : B2_ * STR2;
+    // ONE image: cell (row, group k1, column u = j1*R2 + r2) at row*STR1 + k1*GS1 + u, STR1 = R0*R2 + 1.
+    //   after pass 0: row = r1 (input digit of pass 1);  after pass 1: row = q1 (its output digit) — pass 1 is IN PLACE PER LANE:
+    //   lane u of group k1 reads the A2 cells of its own column and writes its A2 outputs back into them, so no barrier of any
+    //   kind separates its reads from its writes (program order of one lane's LDS operations is enough).
+    //   last pass: lane beta = k1*A2 + q1 of group j1 reads row q1, group k1, columns j1*R2 + r2.
+    // The odd row stride spreads the last pass's reads (consecutive q1) over the banks; seven lanes of a 32-lane read group
+    // meet a second address on their bank where beta crosses from one k1 to the next.
+    static constexpr int GS1 = B1_ * R[2], STR1 = R[0] * R[2] + 1;
+    static constexpr int LDS_ELEMS = A2_ * STR1;
     static constexpr int GW1 = GS1 / 64;                      // waves per k1 group of pass 1
+    static constexpr bool P1_NEEDS_BARRIER = false;           // in place per lane
     static constexpr int GW2 = (A + 63) / 64;                 // waves per j1 group of the last pass
     static constexpr bool KEEP_CODE = false, COPRIME = false, HYBRID = true;
     static constexpr int LDS_BYTES = 8 * LDS_ELEMS;
@@ -676,13 +683,15 @@ struct Fft<HybridPlan<N_, T_, A1, A2, B1, B2>, INV, false> {
     template <int S> static GM_HD void mid_stage2(const cf (&v)[1][R1], cf* lds, int tid) {
         const int wave = tid >> 6, k1 = wave / PL::GW1, lam = (wave % PL::GW1) * 64 + (tid & 63);
         if (k1 < A1) {
-            cf* dst = lds + (lam % R2) * PL::STR2 + (lam / R2) * PL::A + k1 * A2;   // r2, j1 of lambda
-            Bfly<R1, INV>::stage2(v[0], [&](int q1, cf val) { dst[q1] = val; });
+            cf* dst = lds + k1 * PL::GS1 + lam;                      // the lane's own column: output q1 replaces input r1 = q1
+            Bfly<R1, INV>::stage2(v[0], [&](int q1, cf val) { dst[q1 * PL::STR1] = val; });
         }
     }
+    // last pass: lane beta = k1*A2 + q1 of group J1 reads input r2 from row q1, group k1, column J1*R2 + r2
     template <int J1> static GM_HD void p2_s1(cf (&v)[R2], const cf* lds, int beta) {
-        const cf* src = lds + J1 * PL::A + beta;
-        Bfly<R2, INV>::stage1([&](int r) { return ConstTw<INV, J1, PL::B, R2>::mul(src[r * PL::STR2], r); }, v);
+        const int k1 = beta / A2, q1 = beta - k1 * A2;
+        const cf* src = lds + q1 * PL::STR1 + k1 * PL::GS1 + J1 * R2;
+        Bfly<R2, INV>::stage1([&](int r) { return ConstTw<INV, J1, PL::B, R2>::mul(src[r], r); }, v);
     }
     template <int J1> static GM_HD void p2_disp(cf (&v)[R2], const cf* lds, int j1, int beta) {
         if (j1 == J1) p2_s1<J1>(v, lds, beta);
