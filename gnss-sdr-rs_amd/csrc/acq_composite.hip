@@ -316,7 +316,9 @@ template <class PL, uint32_t Q> struct CompLaunch {
 
 // the Galileo geometry's base: the plain plan wins in comp_corr_kernel (see CompPlanOf, acq_device.h)
 }  // namespace gm
+#ifndef GM_COMP_HYBRID_16000      // (A/B switch)
 namespace gm { template <> struct CompPlanOf<Plan16000> { using type = Plan16000; }; }
+#endif
 namespace gm {
 // base plans of the composite sizes: first radix <= 25 (paired layout), one pass-0 butterfly per lane
 #define GM_COMP_ENTRY(PL)                                                                            \

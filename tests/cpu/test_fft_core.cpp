@@ -98,6 +98,7 @@ template <class HP, bool INV> static double run_hybrid(const char* name) {
         xs[e] = x[i];
     }
     using F = Fft<HP, INV>;
+    constexpr int IT1 = HP::IT(1);
     {
         std::vector<cf> regs(size_t(T) * HP::R0);
         for (int tid = 0; tid < T; ++tid)
@@ -105,9 +106,10 @@ template <class HP, bool INV> static double run_hybrid(const char* name) {
         for (int tid = 0; tid < T; ++tid) F::pass0_stage2(*reinterpret_cast<cf(*)[1][HP::R0]>(&regs[size_t(tid) * HP::R0]), lds.data(), tid);
     }
     {
-        std::vector<cf> regs(size_t(T) * HP::R[1]);
-        for (int tid = 0; tid < T; ++tid) F::template mid_stage1<1>(*reinterpret_cast<cf(*)[1][HP::R[1]]>(&regs[size_t(tid) * HP::R[1]]), lds.data(), nullptr, tid);
-        for (int tid = 0; tid < T; ++tid) F::template mid_stage2<1>(*reinterpret_cast<cf(*)[1][HP::R[1]]>(&regs[size_t(tid) * HP::R[1]]), lds.data(), tid);
+        // (the middle pass is in place per lane: running every lane's reads before any lane's writes is one legal order)
+        std::vector<cf> regs(size_t(T) * IT1 * HP::R[1]);
+        for (int tid = 0; tid < T; ++tid) F::template mid_stage1<1>(*reinterpret_cast<cf(*)[IT1][HP::R[1]]>(&regs[size_t(tid) * IT1 * HP::R[1]]), lds.data(), nullptr, tid);
+        for (int tid = 0; tid < T; ++tid) F::template mid_stage2<1>(*reinterpret_cast<cf(*)[IT1][HP::R[1]]>(&regs[size_t(tid) * IT1 * HP::R[1]]), lds.data(), tid);
     }
     for (int tid = 0; tid < T; ++tid) {
         cf v[1][HP::RL];
