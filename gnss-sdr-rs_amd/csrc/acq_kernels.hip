@@ -692,8 +692,10 @@ template <class PL> struct Launch {
             const bool all = share <= slots;
             // one integration per part (see the kernel): k = n_int, when the scratch holds the planes
             if (n_int >= 2 && n_int <= GM_CORR_SPLIT_MAX_K && (!all || share * n_int <= GM_CORR_SPLIT_MAX_SLABS / 8)) split_k = n_int;
-            // (one-workgroup-per-CU plans, N = 16368: the lab harness on random data showed the cut tail 2 % slower on a multi-round
-            // grid, rocprofv3 inside bench.py 4 % FASTER — 413 against 430 us; it stays on)
+            // one workgroup per CU (N = 16368 ...): the cut tail does not pay on a grid of several rounds (same box, back to back:
+            // 0.440 against 0.432 ms per 32-PRN launch with and without; comparisons ACROSS gpurun boxes are worthless for a
+            // 2 % question — the chips differ by more); it stays for grids that fit the chip at once, where it multiplies the parallelism
+            if (CP::WG_PER_CU == 1 && !all && split_env < 0) split_k = 1;
             if (split_env == 1) split_k = 1;
             if (split_k > 1) {
                 split_items = items_env > 0 ? items_env : (all ? share : (slots + split_k - 1) / split_k);
