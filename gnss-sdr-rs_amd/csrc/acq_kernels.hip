@@ -482,6 +482,47 @@ __global__ __launch_bounds__(PL::T) void fft_batch_kernel(cf* __restrict__ data,
                            [&](int it, int r, cf val) { x[(tid + it * PL::T) + r * NBL] = val; }, lds, tw, tid);
 }
 
+// ------------------------------------------------------------------------------------ long power-of-two FFT (FFT<T>, fft.rs:5-30)
+// Lengths above one LDS buffer, L = N1 * N2 with both factors in-LDS power-of-two plans (four-step; the same decomposition as
+// the fine-Doppler transform below, without its fused inputs and reduction): n = N2*n1 + n2, k = k1 + N1*k2,
+//   X[k] = sum_n2 W_N2^{n2 k2} * [ W_L^{n2 k1} * sum_n1 x[N2 n1 + n2] W_N1^{n1 k1} ].
+// API parity for FFT<T> of any length (through Bluestein, gm_api.hip), not a hot path: strided accesses as they come.
+template <class PL, bool INV>
+__global__ __launch_bounds__(PL::T) void big_cols_kernel(const cf* __restrict__ x, cf* __restrict__ B, const cf* __restrict__ tw_g, uint32_t N2) {
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];     // grid N2; PL::N == N1
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    const uint32_t n2 = blockIdx.x, L = uint32_t(PL::N) * N2;
+    load_twiddles<PL>(tw, tw_g, tid);
+    cf* dst = B + size_t(n2) * PL::N;
+    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    const float inv_l = 2.0f / float(L);
+    lds_transform<PL, INV>(
+        [&](int it, int r) { return x[size_t(N2) * uint32_t((tid + it * PL::T) + r * NB0) + n2]; },
+        [&](int it, int r, cf v) {
+            const uint32_t k1 = uint32_t((tid + it * PL::T) + r * NBL);
+            const uint32_t t = (n2 * k1) & (L - 1u);                 // exact phase index mod L (L <= 2^28)
+            float sn, cs;
+            sincospif(float(t) * inv_l, &sn, &cs);                   // W_L^{-+ n2 k1}
+            if (INV) sn = -sn;
+            dst[k1] = cf_make(__builtin_fmaf(v.x, cs, v.y * sn), __builtin_fmaf(v.y, cs, -(v.x * sn)));
+        },
+        lds, tw, tid);
+}
+template <class PL, bool INV>
+__global__ __launch_bounds__(PL::T) void big_rows_kernel(const cf* __restrict__ B, cf* __restrict__ X, const cf* __restrict__ tw_g, uint32_t N1) {
+    __shared__ cf lds[PL::LDS_ELEMS + PL::TW_TOTAL];     // grid N1; PL::N == N2
+    cf* tw = lds + PL::LDS_ELEMS;
+    const int tid = threadIdx.x;
+    const uint32_t k1 = blockIdx.x;
+    load_twiddles<PL>(tw, tw_g, tid);
+    constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
+    lds_transform<PL, INV>(
+        [&](int it, int r) { return B[size_t(uint32_t((tid + it * PL::T) + r * NB0)) * N1 + k1]; },
+        [&](int it, int r, cf v) { X[size_t(N1) * uint32_t((tid + it * PL::T) + r * NBL) + k1] = v; },
+        lds, tw, tid);
+}
+
 // ------------------------------------------------------------------------------------ fine Doppler
 // finer_doppler (acquisition_bk.rs:215-302): X = FFT_{N1*N2}( zero-pad( (s[cp+n] - mean) * chip(n) ) ), peak of |X|.
 // n = N2*n1 + n2, k = k1 + N1*k2:  X[k] = sum_n2 W_N2^{n2 k2} * [ W_N^{n2 k1} * sum_n1 x[N2 n1 + n2] W_N1^{n1 k1} ].
@@ -731,6 +772,19 @@ template <class PL> struct Launch {
         else hipLaunchKernelGGL((fft_batch_kernel<PL, false>), dim3(batch), dim3(PL::T), 0, st, data, tw);
     }
     static constexpr bool POW2 = (PL::N & (PL::N - 1)) == 0;
+    // four-step passes of the long power-of-two FFT: this plan as N1 (columns, grid N2) / as N2 (rows, grid N1)
+    static void big_cols(hipStream_t st, const cf* x, cf* B, const cf* tw, uint32_t n2, int inverse) {
+        if constexpr (POW2) {
+            if (inverse) hipLaunchKernelGGL((big_cols_kernel<PL, true>), dim3(n2), dim3(PL::T), 0, st, x, B, tw, n2);
+            else hipLaunchKernelGGL((big_cols_kernel<PL, false>), dim3(n2), dim3(PL::T), 0, st, x, B, tw, n2);
+        }
+    }
+    static void big_rows(hipStream_t st, const cf* B, cf* X, const cf* tw, uint32_t n1, int inverse) {
+        if constexpr (POW2) {
+            if (inverse) hipLaunchKernelGGL((big_rows_kernel<PL, true>), dim3(n1), dim3(PL::T), 0, st, B, X, tw, n1);
+            else hipLaunchKernelGGL((big_rows_kernel<PL, false>), dim3(n1), dim3(PL::T), 0, st, B, X, tw, n1);
+        }
+    }
     static void fine_cols(hipStream_t st, const FineArgs& a, int n_sats) {
         if constexpr (POW2) hipLaunchKernelGGL(fine_cols_kernel<PL>, dim3(a.N2, n_sats), dim3(PL::T), 0, st, a);
     }
@@ -741,7 +795,8 @@ template <class PL> struct Launch {
         return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL), SPLIT_SLAB,
                        CorrLayout<CP>::RELAYOUT ? 1 : 0,
                        &fill_tw, &fill_order, &mix_fft, &corr, &code_fft, &pair_codes, &fft_batch,
-                       POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr, FineRows<PL>::RT};
+                       POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr, FineRows<PL>::RT,
+                       POW2 ? &big_cols : nullptr, POW2 ? &big_rows : nullptr};
     }
 };
 

@@ -369,9 +369,42 @@ int gm_apply_doppler_shift(const gm_c32* samples, const gm_c32* table, gm_c32* o
 // ---------------------------------------------------------------- FFT<T> / RealFFT<T>
 int gm_fft_supported_sizes(uint32_t* sizes, int cap) { return gm::list_plans(sizes, cap); }
 
+// power-of-two lengths above one LDS buffer: L = N1 * N2, both in-LDS power-of-two plans (N1 >= N2, as balanced as they come)
+static bool pow2_split(size_t n, const gm::PlanOps** p1, const gm::PlanOps** p2) {
+    if (n < 2 || (n & (n - 1)) || n > (size_t(1) << 28)) return false;
+    for (size_t n2 = 256; n2 * n2 <= n || n2 <= 16384; n2 *= 2) {
+        if (n % n2) continue;
+        const size_t n1 = n / n2;
+        if (n1 < n2) break;
+        const gm::PlanOps *a = n1 <= 16384 ? gm::find_plan(int(n1)) : nullptr, *b = gm::find_plan(int(n2));
+        if (a && b && a->big_cols && b->big_rows) { *p1 = a; *p2 = b; return true; }
+    }
+    return false;
+}
+static int fft_run_big(size_t n, int dir, cf* d_data, size_t batch, hipStream_t st) {
+    const gm::PlanOps *p1 = nullptr, *p2 = nullptr;
+    if (!pow2_split(n, &p1, &p2)) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this length");
+    std::vector<cf> t1(size_t(p1->tw_total) + 1), t2(size_t(p2->tw_total) + 1);
+    p1->fill_tw(t1.data(), dir != 0);
+    p2->fill_tw(t2.data(), dir != 0);
+    cf *d_t1 = nullptr, *d_t2 = nullptr, *d_b = nullptr;
+    auto done = [&](int code) { hipFree(d_t1); hipFree(d_t2); hipFree(d_b); return code; };
+    if (hipMalloc(&d_t1, t1.size() * 8) != hipSuccess || hipMalloc(&d_t2, t2.size() * 8) != hipSuccess || hipMalloc(&d_b, n * 8) != hipSuccess)
+        return done(set_err(GM_ERR_NOMEM, "hipMalloc (long FFT)"));
+    if (hipMemcpy(d_t1, t1.data(), t1.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_t2, t2.data(), t2.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return done(set_err(GM_ERR_HIP, "hipMemcpy"));
+    for (size_t it = 0; it < batch; ++it) {
+        cf* x = d_data + it * n;
+        p1->big_cols(st, x, d_b, d_t1, uint32_t(p2->n), dir != 0);
+        p2->big_rows(st, d_b, x, d_t2, uint32_t(p1->n), dir != 0);
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return done(set_err(GM_ERR_HIP, "long FFT kernels"));
+    return done(GM_OK);
+}
+
 static int fft_run(size_t n, int dir, cf* d_data, size_t batch, hipStream_t st) {
     const gm::PlanOps* pl = gm::find_plan(int(n));
-    if (!pl) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this length");
+    if (!pl) return fft_run_big(n, dir, d_data, batch, st);
     std::vector<cf> tw(size_t(pl->tw_total) + 1);
     pl->fill_tw(tw.data(), dir != 0);
     cf* d_tw = nullptr;
@@ -388,11 +421,17 @@ static int fft_run(size_t n, int dir, cf* d_data, size_t batch, hipStream_t st) 
 // through Bluestein's chirp-z identity on the smallest power-of-two plan L >= 2N - 1:
 //   X[k] = c[k] * sum_n (x[n] c[n]) conj(c[k - n]),   c[n] = exp(-j pi n^2 / N)   (phase from n^2 mod 2N: exact in integers)
 // i.e. one length-L circular convolution = two forward transforms (the chirp's is cached per N) and one inverse on the
-// device; the three O(N) chirp products are host loops (this entry takes and returns host buffers).  N <= 8192.
+// device; the three O(N) chirp products are host loops (this entry takes and returns host buffers).  L up to 2^24 (N <= 2^23):
+// powers of two above one LDS buffer run as a four-step transform (fft_run_big).
 static int fft_bluestein(size_t n, int dir, gm_c32* inout, size_t batch) {
     size_t L = 256;
     while (L < 2 * n - 1) L *= 2;
-    if (L > 16384 || !gm::find_plan(int(L))) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this length, and 2N-1 > 16384 (Bluestein)");
+    {   // the next power of two that has a transform (32768 = 256 x 128 has no two in-LDS factors: 65536 then)
+        const gm::PlanOps *p1 = nullptr, *p2 = nullptr;
+        while (L <= (size_t(1) << 24) && !gm::find_plan(int(L)) && !pow2_split(L, &p1, &p2)) L *= 2;
+        if (L > (size_t(1) << 24))
+            return set_err(GM_ERR_UNSUPPORTED_N, "length above 2^23: no FFT plan (Bluestein needs a power of two >= 2N - 1, at most 2^24)");
+    }
     std::vector<cf> c(n), b(L, gm::cf_make(0.f, 0.f));
     for (size_t i = 0; i < n; ++i) {
         const double a = M_PI * double((uint64_t(i) * i) % (2 * n)) / double(n);
@@ -434,7 +473,10 @@ static int fft_bluestein(size_t n, int dir, gm_c32* inout, size_t batch) {
 int gm_fft_c2c_f32(size_t n, int dir, gm_c32* inout, size_t batch) {
     if (!inout || !n || !batch) return set_err(GM_ERR_INVALID_ARG, "null or empty");
     if (int rc = ensure_device(g_device)) return rc;
-    if (!gm::find_plan(int(n))) return fft_bluestein(n, dir, inout, batch);
+    {
+        const gm::PlanOps *p1 = nullptr, *p2 = nullptr;
+        if (!gm::find_plan(int(n)) && !pow2_split(n, &p1, &p2)) return fft_bluestein(n, dir, inout, batch);
+    }
     cf* d = nullptr;
     HIPC(hipMalloc(&d, n * batch * 8));
     HIPC(hipMemcpy(d, inout, n * batch * 8, hipMemcpyHostToDevice));
@@ -447,7 +489,8 @@ int gm_fft_c2c_f32(size_t n, int dir, gm_c32* inout, size_t batch) {
 int gm_fft_power_spectrum_f32(size_t n, gm_c32* inout, float* power) {
     if (!inout || !power || !n) return set_err(GM_ERR_INVALID_ARG, "null or empty");
     if (int rc = ensure_device(g_device)) return rc;
-    if (!gm::find_plan(int(n))) {            // any other length: Bluestein, then |X|^2 on the host
+    const gm::PlanOps *pp1 = nullptr, *pp2 = nullptr;
+    if (!gm::find_plan(int(n)) && !pow2_split(n, &pp1, &pp2)) {            // any other length: Bluestein, then |X|^2 on the host
         if (int rc = fft_bluestein(n, 0, inout, 1)) return rc;
         for (size_t i = 0; i < n; ++i) power[i] = inout[i].re * inout[i].re + inout[i].im * inout[i].im;   // norm_sqr (fft.rs:28)
         return GM_OK;

@@ -58,6 +58,9 @@ struct PlanOps {
     void (*fine_cols)(hipStream_t, const FineArgs&, int n_sats);
     void (*fine_rows)(hipStream_t, const FineArgs&, int n_sats);
     int fine_rows_per_wg;   // rows of the row pass one workgroup takes (its results: N1 / this per satellite)
+    // long power-of-two FFT, four-step (power-of-two plans only, else null): columns x -> B[n2][k1] (twiddled), rows B -> X natural
+    void (*big_cols)(hipStream_t, const cf* x, cf* B, const cf* tw, uint32_t n2, int inverse);
+    void (*big_rows)(hipStream_t, const cf* B, cf* X, const cf* tw, uint32_t n1, int inverse);
 };
 // mean of the snapshot (finer_doppler :236) and the final per-satellite reduction over the rows
 void launch_fine_mean(hipStream_t, const void* samples, int fmt, uint32_t n, float* d_mean);

@@ -61,10 +61,27 @@ def test_fft_arbitrary_lengths_bluestein(gpu, oracle):
     assert np.allclose(fft.RealFFT(1000).execute(r), np.fft.rfft(r.astype(np.float64)), rtol=0, atol=2e-3)
 
 
+def test_fft_long_lengths(gpu):
+    """FFT<T> above one LDS buffer (src/fft.rs:5-30 is generic over the length): powers of two up to 2^28 as a four-step
+    transform of two in-LDS plans (32768 = 256 x 128 ... ), every other length up to 2^23 by Bluestein on such a transform:
+    8200 (was GM_ERR_UNSUPPORTED_N), the reference's N = 16368 doubled, a prime above 2^16; forward and inverse vs float64."""
+    from gnss_sdr_rs_amd import fft
+    rng = np.random.default_rng(23)
+    for n in (32768, 65536, 1 << 18, 8200, 32736, 65537, 100003):
+        assert n not in fft.supported_sizes()
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        for inv in (False, True):
+            y = fft.FFT(n).execute(x.copy(), inverse=inv)
+            xd = x.astype(np.complex128)
+            ref = np.fft.ifft(xd) * n if inv else np.fft.fft(xd)
+            assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 4e-6, (n, inv)
+
+
 def test_fft_unsupported_size(gpu):
     from gnss_sdr_rs_amd import fft, GmError
+    n = (1 << 23) + 1                                                # 2n - 1 > 2^24: beyond Bluestein's largest transform
     with pytest.raises(GmError) as e:
-        fft.FFT(8200).execute(np.zeros(8200, np.complex64))     # no plan, and 2n - 1 > 16384
+        fft.FFT(n).execute(np.zeros(n, np.complex64))
     assert e.value.status == -2
 
 
