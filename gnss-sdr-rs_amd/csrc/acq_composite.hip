@@ -151,7 +151,8 @@ __global__ __launch_bounds__(CompPlanOf<PLX>::type::T, CompPlanOf<PLX>::type::WA
     using PL = typename CompPlanOf<PLX>::type;      // the base size's plan for this path (acq_device.h): plain or hybrid
     constexpr bool HYB = CorrMode<PL>::HYBRID;
     static_assert(!CorrMode<PL>::PFA, "composite bases: plain or hybrid correlation plans");
-    static_assert(PL::IT0 == 1 && PairLayout<PL>::PAIRED, "composite base plans: one pass-0 butterfly per lane, paired layout");
+    static_assert(PL::IT0 == 1, "composite base plans: one pass-0 butterfly per lane");
+    constexpr bool PAIRED = PairLayout<PL>::PAIRED;      // first radix <= 25: 16-byte pair loads; else (16368, 16384) plain 8-byte loads
     // Equal contiguous share of the bin-major item list per XCD (blocks b and b + 8 share an XCD: speed only).  Inside an XCD
     // the share — a strip of rows_max Doppler bins, ragged at both ends — is walked in blocks of `cb` workers: the ~32
     // workgroups resident on the XCD at a time then cover cb workers x all of the strip's bins, so every combined code table
@@ -199,8 +200,22 @@ __global__ __launch_bounds__(CompPlanOf<PLX>::type::T, CompPlanOf<PLX>::type::WA
             // vals[r] = sum over k1 of X[m][k1][k] * comb[n1][k1][k]: the Q-point inverse DFT row, the inverse twiddle and
             // conj(code) (:184-186) are all inside the table
             cf vals[PL::R0];
+            if constexpr (!PAIRED) {
 #pragma unroll
-            for (int rp = 0; rp < NPAIR; ++rp) {
+                for (int r = 0; r < PL::R0; ++r) {
+                    cf s0 = cf_make(0.f, 0.f);
+#pragma unroll
+                    for (uint32_t k1 = 0; k1 < Q; ++k1) {
+                        const cf x1 = buf_load_cf(xrs, v8, ((m * int(Q) + int(k1)) * Nb + r * NB0) * 8);
+                        const cf c1 = buf_load_cf(crs, v8, (int(k1) * Nb + r * NB0) * 8);
+                        const cf p0 = cf_mul(x1, c1);
+                        s0 = k1 == 0 ? p0 : cf_add(s0, p0);
+                    }
+                    vals[r] = s0;
+                }
+            }
+#pragma unroll
+            for (int rp = 0; rp < (PAIRED ? NPAIR : 0); ++rp) {
                 cf s0 = cf_make(0.f, 0.f), s1 = s0;
 #pragma unroll
                 for (uint32_t k1 = 0; k1 < Q; ++k1) {
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(CompPlanOf<PLX>::type::T, CompPlanOf<PLX>::type::WA
                 vals[2 * rp] = s0;
                 vals[2 * rp + 1] = s1;
             }
-            if constexpr (ODD0) {
+            if constexpr (ODD0 && PAIRED) {
                 cf s0 = cf_make(0.f, 0.f);
 #pragma unroll
                 for (uint32_t k1 = 0; k1 < Q; ++k1) {
@@ -316,16 +331,18 @@ template <class PL, uint32_t Q> struct CompLaunch {
 
 // the Galileo geometry's base: the plain plan wins in comp_corr_kernel (see CompPlanOf, acq_device.h)
 }  // namespace gm
+// 16368's generic plan runs here with its twiddles (AsPlain: the prime-factor form is the fused kernel's)
+namespace gm { template <> struct CompPlanOf<Plan16368> { using type = AsPlain<Plan16368>; }; }
 #ifndef GM_COMP_HYBRID_16000      // (A/B switch)
 namespace gm { template <> struct CompPlanOf<Plan16000> { using type = Plan16000; }; }
 #endif
 namespace gm {
-// base plans of the composite sizes: first radix <= 25 (paired layout), one pass-0 butterfly per lane
+// base plans of the composite sizes: one pass-0 butterfly per lane; first radix <= 25 -> paired 16-byte loads, else 8-byte loads
 #define GM_COMP_ENTRY(PL)                                                                            \
     CompLaunch<PL, 2>::ops(), CompLaunch<PL, 3>::ops(), CompLaunch<PL, 4>::ops(), CompLaunch<PL, 5>::ops(), \
         CompLaunch<PL, 6>::ops(), CompLaunch<PL, 8>::ops(),
-static const CompOps g_comp[] = {GM_COMP_ENTRY(Plan16000) GM_COMP_ENTRY(Plan8000) GM_COMP_ENTRY(Plan8192) GM_COMP_ENTRY(Plan6000) GM_COMP_ENTRY(Plan5000)
-                                     GM_COMP_ENTRY(Plan4000)};
+static const CompOps g_comp[] = {GM_COMP_ENTRY(Plan16384) GM_COMP_ENTRY(Plan16368) GM_COMP_ENTRY(Plan16000) GM_COMP_ENTRY(Plan8000) GM_COMP_ENTRY(Plan8192)
+                                     GM_COMP_ENTRY(Plan6000) GM_COMP_ENTRY(Plan5000) GM_COMP_ENTRY(Plan4000)};
 
 // N = Q * Nb: the largest base plan first (fewest sub-transform passes over the spectra)
 const CompOps* find_comp(uint32_t n) {

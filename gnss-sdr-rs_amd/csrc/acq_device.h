@@ -133,6 +133,9 @@ template <class CP> struct CorrLayout {
     static __host__ __device__ __forceinline__ int index_at(int p) { return unperm(PairLayout<CP>::unpos(p)); }
 };
 
+// a generic plan with pairwise coprime radices, run WITH its twiddles and natural element order (not as a prime-factor transform)
+template <class PL> struct AsPlain : PL { static constexpr bool COPRIME = false; };
+
 // The composite path (acq_composite.hip) picks its base size's correlation plan separately: measured at the configs[3] Galileo
 // geometry (N = 2 x 16000, 36 codes) the hybrid 16000 plan runs comp_corr_kernel at 0.396 ms where the plain [25, 20, 32] plan
 // takes 0.353 (the pass-0 inputs are formed from 2Q loads per element there and the 128-register cap of 1024 lanes bites

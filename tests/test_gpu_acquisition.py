@@ -323,11 +323,11 @@ def test_native_comm_single_rank_allgather_and_decide(gpu, hipbuf):
 
 def test_composite_sizes_accepted_and_rejected(gpu):
     """The transform sizes beyond one LDS buffer the acquisition handle takes are exactly Q x base with Q in {2,3,4,5,6,8} and
-    base in {16000, 8000, 8192, 6000, 5000, 4000} (acq_composite.hip); everything else — e.g. 2 x 16368, 8 x 16384, whose
-    base plans start with a radix above 25 — is GM_ERR_UNSUPPORTED_N, not a silent fallback."""
+    base in {16384, 16368, 16000, 8000, 8192, 6000, 5000, 4000} (acq_composite.hip; 16368 and 16384 — whose plans start with a
+    radix above 25 — through 8-byte instead of paired loads); everything else is GM_ERR_UNSUPPORTED_N, not a silent fallback."""
     from gnss_sdr_rs_amd import acquisition as A, GmError
     dop = np.array([0.0], np.float32)
-    ok, bad = (32000, 25000, 40000, 48000, 65536), (32736, 49104, 131072, 34000, 30000 * 3)
+    ok, bad = (32000, 25000, 40000, 48000, 65536, 32736, 49104, 131072), (34000, 90000, 7 * 16368, 9 * 8000)
     for n in ok:
         eng = A.AcquisitionEngine(float(n) * 1000.0, 0.0, n, doppler_hz=dop, prn_ids=[1], n_integrations=1)
         assert eng.fft_size == n
