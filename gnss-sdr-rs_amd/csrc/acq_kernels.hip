@@ -238,10 +238,15 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
             // no branch around the loads (values that live across control flow made hipcc spill 68 VGPRs): lanes without a
             // pass-0 butterfly get an offset beyond the descriptor's range, which the buffer unit drops without a memory request
             const int b = tid + it * PL::T;
+#ifndef GM_LAB_NOLOAD
             if constexpr (CODE_PAIRED) xq[it].load(xrs, b, m * PL::N);
             if constexpr (!KEEP_CODE && CODE_PAIRED) cq[it].load(crs, b, 0);
+#endif
         }
         auto in = [&](int it, int r) {
+#ifdef GM_LAB_NOLOAD      // timing ablation only (tools/corr_lab): inputs made up in registers, no pass-0 loads
+            { const float f = float(tid + m); return cf_make(f * 1e-3f + float(r), f * 2e-3f - float(it)); }
+#endif
             const cf a = CODE_PAIRED ? xq[it].get(r) : buf_load_cf(xrs, (tid + it * PL::T) * 8, (m * PL::N + r * NB0) * 8);
             cf c;
             if constexpr (KEEP_CODE) c = cc[it][r];
