@@ -870,13 +870,49 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0,
     bytes_per_epoch = C * n * 8
     gbs = bytes_per_epoch * epochs / dt / 1e9
     mgr.close()
+    strict = None
+    if world == 1 and C == 32 and os.environ.get("GM_BENCH_NO_STRICT") != "1":
+        # what gm_trk_cfg.strict_libm costs (the carrier's cos / sin as glibc's cosf / sinf, f64, sample by sample): informative,
+        # never part of `value`
+        try:
+            ms = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED, strict_libm=True)
+            ms.set_stream(stream)
+            mgr, se = ms, 120
+            st = []
+            for _ in range(3):
+                restart()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ms.update_all_dev(ring, se)
+                ms.synchronize()
+                st.append(time.perf_counter() - t0)
+            strict = {"us_per_epoch": float(np.median(st[1:])) / se * 1e6, "epochs": se,
+                      "note": "strict_libm = 1: per-sample products bit-identical to the reference host's (tests/test_gpu_tracking_shapes.py)"}
+            ms.close()
+            # ... and with the reference's sequential sums as well: sums and channel state bit-identical, free-running
+            ms = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED, strict_libm=True, strict_sum_order=True)
+            ms.set_stream(stream)
+            mgr, se2 = ms, 40
+            st = []
+            for _ in range(3):
+                restart()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ms.update_all_dev(ring, se2)
+                ms.synchronize()
+                st.append(time.perf_counter() - t0)
+            strict["with_strict_sum_order_us_per_epoch"] = float(np.median(st[1:])) / se2 * 1e6
+            strict["with_strict_sum_order_x_real_time"] = 1e3 / strict["with_strict_sum_order_us_per_epoch"]
+            ms.close()
+        except Exception as e:      # informative leg: never fails the bench
+            strict = {"error": repr(e)}
     ring.close()
     trk_cpu = None
     if world == 1 and cpu_seconds > 0 and C == 32:
         trk_cpu = tracking_cpu_baseline(sc, fs, n, cpu_seconds)
     return {"metric": "tracking ch×Msps", "cpu_baseline": trk_cpu, "value": ch_msps * world, "unit": "ch*Msps", "channels_per_gpu": C,
             "fs_msps": 25.0, "epochs": epochs, "ms_per_epoch": dt / epochs * 1e3, "channels_locked": locked,
-            "roofline": trk_roofline(gbs, bytes_per_epoch, epochs, C)}
+            "strict_libm": strict, "roofline": trk_roofline(gbs, bytes_per_epoch, epochs, C)}
 
 
 def trk_roofline(gbs, bytes_per_epoch, epochs, C):

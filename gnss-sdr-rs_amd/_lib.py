@@ -58,7 +58,7 @@ class TrkCfg(C.Structure):
                 ("n_codes", C.c_uint32), ("code_len", C.c_uint32), ("nominal_code_rate", C.c_float),
                 ("pll_bw", C.c_float), ("pll_zeta", C.c_float), ("pll_gain", C.c_float), ("dll_bw", C.c_float),
                 ("dll_zeta", C.c_float), ("dll_gain", C.c_float), ("pll_dt", C.c_float), ("dll_dt", C.c_float),
-                ("lock_threshold", C.c_float), ("max_lost_epochs", C.c_uint32)]
+                ("lock_threshold", C.c_float), ("max_lost_epochs", C.c_uint32), ("strict_libm", C.c_int32), ("strict_sum_order", C.c_int32)]
 
 
 FMT_C32, FMT_I8_IQ, FMT_I8_REAL = 0, 1, 2

@@ -1210,6 +1210,7 @@ struct gm_trk {
     float* d_partials = nullptr;
     uint8_t* d_ready = nullptr;
     cf* d_scratch = nullptr; size_t scratch_cap = 0;
+    float* d_terms = nullptr; size_t terms_cap = 0;   // strict_sum_order: [C][2 * arms][terms_cap] per-sample products of one epoch
     gm_trk_out* d_outs = nullptr; uint8_t *d_proc = nullptr, *d_lost = nullptr, *d_lostprn = nullptr;
     uint32_t epochs_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1224,6 +1225,15 @@ struct gm_trk {
 };
 
 static int trk_check_error(gm_trk* t);
+// strict_sum_order: room for `samples` per-sample products per sum and channel
+static int trk_reserve_terms(gm_trk* t, size_t samples) {
+    if (!t->dc.strict_sum_order || samples <= t->terms_cap) return GM_OK;
+    HIPC(hipStreamSynchronize(t->stream));
+    hipFree(t->d_terms); t->d_terms = nullptr; t->terms_cap = 0;
+    HIPC(hipMalloc(&t->d_terms, size_t(t->C) * 2 * size_t(t->dc.n_arms) * samples * sizeof(float)));
+    t->terms_cap = samples;
+    return GM_OK;
+}
 static int trk_reserve_epochs(gm_trk* t, uint32_t e) {
     if (e <= t->epochs_cap) return GM_OK;
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
@@ -1251,7 +1261,7 @@ float gm_loop_filter_update(float tau1, float tau2, float d_err, float err, floa
 int gm_trk_destroy(gm_trk* t) {
     if (!t) return GM_OK;
     if (t->device >= 0) hipSetDevice(t->device);
-    hipFree(t->d_codes); hipFree(t->d_states); hipFree(t->d_partials); hipFree(t->d_ready); hipFree(t->d_scratch);
+    hipFree(t->d_codes); hipFree(t->d_states); hipFree(t->d_partials); hipFree(t->d_ready); hipFree(t->d_scratch); hipFree(t->d_terms);
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
     hipFree(t->d_xchg); if (t->d_error) hipHostFree(t->d_error); hipFree(t->d_error_dev); hipFree(t->d_stamps);
     if (t->ev0) hipEventDestroy(t->ev0);
@@ -1282,6 +1292,8 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
     d.el_space = cfg->early_late_space > 0 ? cfg->early_late_space : 0.5f;
     d.vel_space = cfg->very_early_late_space > 0 ? cfg->very_early_late_space : 1.0f;
     d.code_index_mode = cfg->code_index_mode; d.boc11 = cfg->boc11;
+    d.strict_libm = cfg->strict_libm ? 1 : 0;
+    d.strict_sum_order = cfg->strict_sum_order ? 1 : 0;
     d.gps_ca = cfg->codes ? 0 : 1;
     d.code_len = cfg->codes ? int(cfg->code_len) : 1023;
     d.code_len_f = float(d.code_len);
@@ -1457,6 +1469,7 @@ static int trk_unit(gm_trk* t, uint32_t ch, const gm_c32* samples, size_t n, int
         HIPC(hipMalloc(&t->d_scratch, need * 8 * 2));
         t->scratch_cap = need * 2;
     }
+    if (int rc = trk_reserve_terms(t, need)) return rc;
     HIPC(hipMemcpyAsync(t->d_scratch, samples, need * 8, hipMemcpyHostToDevice, t->stream));
     // the unit entries run regardless of ChannelState (the reference's early_late_correlation/do_work do not test it)
     const uint8_t was_active = s.active;
@@ -1464,7 +1477,7 @@ static int trk_unit(gm_trk* t, uint32_t ch, const gm_c32* samples, size_t n, int
     gm::TrkSrc src;
     src.base = t->d_scratch; src.mask = ~0ull; src.head = 0; src.linear = 1; src.only_channel = int(ch);
     gm::launch_trk_epoch(t->stream, t->dc, t->d_codes, t->d_states, src, t->slices, t->d_partials, t->d_ready, mode,
-                         t->d_outs, t->d_proc, t->d_lost, t->d_lostprn);
+                         t->d_outs, t->d_proc, t->d_lost, t->d_lostprn, t->d_terms, t->terms_cap, t->d_error);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(t->stream));
     HIPC(hipMemcpy(out, t->d_outs + ch, sizeof(*out), hipMemcpyDeviceToHost));
@@ -1503,6 +1516,23 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
     if (t->device != ring->device) return set_err(GM_ERR_INVALID_ARG, "ring lives on another device");
     if (int rc = ensure_device(t->device)) return rc;
     if (int rc = trk_reserve_epochs(t, epochs)) return rc;
+    if (t->dc.strict_sum_order) {
+        // the reference's sequential sums: three launches per pass (products, one serial wave per channel, scalar epilogue)
+        // instead of the persistent kernel; the data gate of every pass reads the head as of this call, like the persistent form
+        const float nn = roundf(t->dc.fs / (t->dc.nominal_code_rate / t->dc.code_len_f));
+        if (int rc = trk_reserve_terms(t, (nn > 0 ? size_t(nn * 1.01f) : 0) + 64)) return rc;
+        if (t->timing) HIPC(hipEventRecord(t->ev0, t->stream));
+        gm::TrkSrc src;
+        src.base = ring->d_buf; src.mask = ring->mask; src.head = ring->head.load(std::memory_order_acquire); src.linear = 0; src.only_channel = -1;
+        for (uint32_t e = 0; e < epochs; ++e) {
+            const size_t o = size_t(e) * t->C;
+            gm::launch_trk_epoch(t->stream, t->dc, t->d_codes, t->d_states, src, t->slices, t->d_partials, t->d_ready, gm::TRK_MODE_DO_WORK,
+                                 t->d_outs + o, t->d_proc + o, t->d_lost + o, t->d_lostprn + o, t->d_terms, t->terms_cap, t->d_error);
+        }
+        if (t->timing) { HIPC(hipEventRecord(t->ev1, t->stream)); t->timed_launches = epochs; }
+        HIPC(hipGetLastError());
+        return GM_OK;
+    }
     PersistChain& chain = g_persist_chain[t->device & 15];
     std::lock_guard<std::mutex> chain_lock(chain.mu);
     if (!chain.ev) HIPC(hipEventCreateWithFlags(&chain.ev, hipEventDisableTiming));
@@ -1554,6 +1584,7 @@ static int trk_check_error(gm_trk* t) {
         *t->d_error = 0;
         (void)hipMemsetAsync(t->d_error_dev, 0, sizeof(int), t->stream);
         (void)hipStreamSynchronize(t->stream);
+        if (err == 2) return set_err(GM_ERR_OUT_OF_RANGE, "tracking (strict_sum_order): a code period longer than the product streams were sized for (nominal + 1 %)");
         return set_err(GM_ERR_HIP, "tracking: inter-workgroup exchange timed out (workgroups of a channel not co-resident?)");
     }
     return GM_OK;

@@ -139,6 +139,8 @@ struct TrkDevCfg {
     float inv_fs, inv_len, inv_2pi;
     float pll_dt_tau1, pll_tau2_tau1, dll_dt_tau1, dll_tau2_tau1;   // dt/tau1, tau2/tau1 (LoopFilter::update :68-70)
     int div_fs_ok;            // fs significand not all ones: div_const(x, fs) is the correctly rounded quotient
+    int strict_libm;          // gm_trk_cfg.strict_libm: carrier cos / sin by gm_libm.h's sincosf_glibc
+    int strict_sum_order;     // gm_trk_cfg.strict_sum_order: the six / ten sums added sample by sample (trk_serial_sum_kernel)
 };
 inline void fill_trk_derived(TrkDevCfg& d) {
     d.inv_fs = 1.0f / d.fs; d.inv_len = 1.0f / d.code_len_f; d.inv_2pi = 1.0f / (2.0f * 3.14159265358979323846f);
@@ -155,7 +157,8 @@ struct TrkSrc {
 };
 void launch_trk_epoch(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_trk_state* d_states,
                       const TrkSrc&, int slices, float* d_partials, uint8_t* d_ready, int mode,
-                      gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost, uint8_t* d_lost_prn);
+                      gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost, uint8_t* d_lost_prn,
+                      float* d_terms = nullptr, size_t terms_cap = 0, int* d_error = nullptr);   // (strict_sum_order: per-sample product streams)
 
 // Persistent tracking geometry: workgroups of TRK_PERSIST_THREADS lanes, TRK_PERSIST_WG_PER_CU of them per CU.
 // Two independent workgroups per CU let one channel's serial exchange + loop-filter epilogue (one wave) overlap

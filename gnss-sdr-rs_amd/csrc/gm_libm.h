@@ -167,4 +167,82 @@ GM_LIBM_HD void sincos_cw(float x, float& s, float& c) {
     c = f32_from_bits(f32_bits(cv) ^ (((q + 1u) << 30) & 0x80000000u));
 }
 
+// sinf(y) and cosf(y) as glibc 2.35 computes them on an x86-64 host with FMA (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c and
+// sincosf.h built as the multiarch *_fma variants, which the ifunc resolver of libm.so.6 picks on every CPU with FMA and
+// AVX2 — both boxes this repository runs on): the reference's `phase.cos()` / `phase.sin()` (do_tracking.rs:234-235) are
+// these two functions.  All arithmetic is f64: the argument is reduced to |x| <= pi/4 with a quadrant count n — below 120
+// by one multiply and one fused multiply-subtract (reduce_fast), above by the 96-bit fixed-point product with 4/pi
+// (reduce_large) — then an odd (sine) or even (cosine) polynomial in x^2, and ONE rounding to f32 at the end.  The fused
+// multiply-adds below are the ones the compiler contracted in the shipped binary (read from its disassembly: every
+// `a + b*c` of the source became one FMA, the plain products stayed products); a restatement without them differs from
+// the host's functions in the last bit of the f64 result, which now and then decides the f32 rounding.
+// tests/cpu/test_libm.cpp compares both results with the host's sinf / cosf bit for bit (all three argument ranges).
+// Constants: __sincosf_table[0] / [1] and __inv_pio4 of sincosf_data.c, as hexadecimal literals.
+struct SincosfPoly { double c0, c1, c2, c3, c4, s1, s2, s3; };
+GM_LIBM_HD double sincosf_sinpoly(double xs, double x2, const SincosfPoly& p) {
+    const double x3 = x2 * xs;
+    const double s1 = __builtin_fma(p.s3, x2, p.s2);
+    const double x7 = x2 * x3;
+    const double s = __builtin_fma(x3, p.s1, xs);
+    return __builtin_fma(s1, x7, s);
+}
+GM_LIBM_HD double sincosf_cospoly(double x2, const SincosfPoly& p) {
+    const double x4 = x2 * x2;
+    const double c1 = __builtin_fma(p.c1, x2, p.c0);
+    const double c2 = __builtin_fma(p.c4, x2, p.c3);
+    const double x6 = x2 * x4;
+    const double c = __builtin_fma(x4, p.c2, c1);
+    return __builtin_fma(c2, x6, c);
+}
+GM_LIBM_HD void sincosf_glibc(float y, float& sn, float& cs) {
+    static constexpr uint32_t inv_pio4[24] = {0xa2u,       0xa2f9u,     0xa2f983u,   0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u,
+                                              0x6e4e4415u, 0x4e441529u, 0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u,
+                                              0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u, 0x34ddc0dbu, 0xddc0db62u,
+                                              0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16, S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    const uint32_t yi = f32_bits(y), top = (yi >> 20) & 0x7ffu;      // abstop12
+    double x = double(y);
+    if (top < 0x3f4u) {                                               // |y| < pi/4
+        const double x2 = x * x;
+        if (top < 0x398u) { sn = y; cs = 1.0f; return; }              // |y| < 2^-12
+        const SincosfPoly p = {C0, C1, C2, C3, C4, S1, S2, S3};
+        sn = float(sincosf_sinpoly(x, x2, p));
+        cs = float(sincosf_cospoly(x2, p));
+        return;
+    }
+    int n, q;                                                         // quadrant count (parity picks the polynomial), sign / table selector
+    if (top < 0x42fu) {                                               // |y| < 120: reduce_fast
+        const double r = x * 0x1.45F306DC9C883p+23;                   // 2/pi * 2^24
+        n = (int32_t(r) + 0x800000) >> 24;                            // truncating conversion, arithmetic shift
+        x = __builtin_fma(-double(n), 0x1.921FB54442D18p0, x);
+        q = n;
+    } else if (top < 0x7f8u) {                                        // finite: reduce_large
+        const uint32_t* arr = &inv_pio4[(yi >> 26) & 15u];
+        const int shift = int((yi >> 23) & 7u);
+        uint32_t m = (yi & 0x7fffffu) | 0x800000u;
+        m <<= shift;
+        uint64_t res0 = uint64_t(uint32_t(m * arr[0]));
+        const uint64_t res1 = uint64_t(m) * arr[4], res2 = uint64_t(m) * arr[8];
+        res0 = (res2 >> 32) | (res0 << 32);
+        res0 += res1;
+        const uint64_t nn = (res0 + (1ull << 61)) >> 62;
+        res0 -= nn << 62;
+        x = double(int64_t(res0)) * 0x1.921FB54442D18p-62;
+        n = int(nn);
+        q = n + int(yi >> 31);
+    } else {                                                          // inf / NaN
+        sn = cs = y - y;
+        return;
+    }
+    const double sg = ((q + 1) & 2) ? -1.0 : 1.0;                     // sign[q & 3] = {1, -1, -1, 1}
+    const double k = (q & 2) ? -1.0 : 1.0;                            // __sincosf_table[1]: the cosine coefficients negated
+    const SincosfPoly p = {k * C0, k * C1, k * C2, k * C3, k * C4, S1, S2, S3};
+    const double x2 = x * x;
+    const double a = sincosf_sinpoly(x * sg, x2, p), b = sincosf_cospoly(x2, p);
+    sn = float((n & 1) ? b : a);                                      // sinf: sinf_poly(x * s, x * x, p, n)
+    cs = float((n & 1) ? a : b);                                      // cosf: sinf_poly(x * s, x * x, p, n ^ 1)
+}
+
+
 }  // namespace gm

@@ -121,7 +121,7 @@ __device__ __forceinline__ void reset_state(gm_trk_state& s) {
 // per-epoch constants of one channel, derived from its state exactly once per epoch
 struct EpochConsts {
     float carrier_phase, two_pi_f, code_phase, step, fs, inv_fs, lenf, el, vel;
-    int len, mode, boc11;
+    int len, mode, boc11, strict;
 };
 __device__ __forceinline__ EpochConsts epoch_consts(const TrkDevCfg& cfg, const gm_trk_state& st) {
     EpochConsts c;
@@ -132,6 +132,7 @@ __device__ __forceinline__ EpochConsts epoch_consts(const TrkDevCfg& cfg, const 
     c.inv_fs = cfg.inv_fs;                              // correctly rounded reciprocal for div_by_fs()
     c.fs = cfg.fs; c.lenf = cfg.code_len_f; c.len = cfg.code_len; c.mode = cfg.code_index_mode;
     c.boc11 = cfg.boc11; c.el = cfg.el_space; c.vel = cfg.vel_space;
+    c.strict = cfg.strict_libm;
     return c;
 }
 
@@ -182,7 +183,7 @@ template <class CT> __device__ __forceinline__ float chip_at(const CT* t, int k)
 template <> __device__ __forceinline__ float chip_at<int8_t>(const int8_t* t, int k) { return float(t[k]); }
 template <> __device__ __forceinline__ float chip_at<float>(const float* t, int k) { return t[k + 1]; }
 
-template <int ARMS, bool FAST, int MODE_T = -1, int BOC_T = -1, class CT = int8_t>
+template <int ARMS, bool FAST, int MODE_T = -1, int BOC_T = -1, class CT = int8_t, int STRICT_T = -1>
 __device__ __forceinline__ void correlate_sample(const EpochConsts& c, const CT* chips, cf d, uint32_t i,
                                                  float (&acc)[2 * ARMS]) {
     const int mode = MODE_T >= 0 ? MODE_T : c.mode;
@@ -191,7 +192,10 @@ __device__ __forceinline__ void correlate_sample(const EpochConsts& c, const CT*
     const float w = c.two_pi_f * fi;
     const float phase = c.carrier_phase + (FAST ? div_by_fs(w, c.fs, c.inv_fs) : __fdiv_rn(w, c.fs));
     float sn, cs;
-    sincos_f32_via_f64(phase, sn, cs);
+    // gm_trk_cfg.strict_libm: glibc's cosf / sinf bit for bit.  STRICT_T: compile-time in the persistent kernel (its default
+    // instantiations carry no trace of the f64 path), run-time in the unit-entry kernels (a uniform branch)
+    if (STRICT_T >= 0 ? (STRICT_T != 0) : (c.strict != 0)) sincosf_glibc(phase, sn, cs);
+    else sincos_f32_via_f64(phase, sn, cs);
     const float wc = cs, ws = -sn;                          // Complex32::new(cos_p, -sin)
     const float xr = d.x * wc - d.y * ws;                   // num-complex Mul
     const float xi = d.x * ws + d.y * wc;
@@ -453,6 +457,113 @@ __global__ __launch_bounds__(256) void trk_correlate_kernel(TrkDevCfg cfg, const
     __syncthreads();
     if (tid < NV) pout[tid] = ((wsum[0][tid] + wsum[1][tid]) + wsum[2][tid]) + wsum[3][tid];
     if (slice == 0 && tid == 0) ready[ch] = 1;
+}
+
+
+// ---- gm_trk_cfg.strict_sum_order: the correlator sums in the reference's own order ------------------------------------
+// early_late_correlation adds the products of sample 0, 1, 2, ... into each of its six sums one after the other in f32
+// (`i_p += re * p_chip`, do_tracking.rs:256-262); a parallel sum is a different (and more accurate) rounding sequence,
+// ~7e-6 of the envelope away at n = 25 000 — the whole of what separates this library's tracking from the reference's once
+// the carrier's cos / sin are glibc's (strict_libm).  With the switch on an epoch is three launches instead of the
+// persistent kernel's loop: trk_terms_kernel — every sample's products (the same correlate_sample as everywhere else, on a
+// zeroed accumulator: x * (+-1) is exact), stored as one contiguous stream per sum; trk_serial_sum_kernel — ONE wave per
+// channel, lane k walks stream k from sample 0 to n - 1 (n dependent f32 adds, ~8 cycles each: ~95 us at n = 25 000, all
+// channels side by side), the streams staged through LDS by the workgroup's other three waves; trk_update_kernel — the
+// scalar epilogue as before.  The sums, and with strict_libm every word of the channel state, then equal the reference's
+// bit for bit, free-running, for as many epochs as one likes (tests/test_gpu_tracking_shapes.py).  ~35x the persistent
+// kernel's time per epoch at BASELINE configs[2]: a parity switch, not the production path.
+template <int ARMS>
+__global__ __launch_bounds__(256) void trk_terms_kernel(TrkDevCfg cfg, const int8_t* __restrict__ codes,
+                                                        const gm_trk_state* __restrict__ states, TrkSrc src, int slices,
+                                                        float* __restrict__ terms, unsigned long long cap,
+                                                        uint8_t* __restrict__ ready, int* __restrict__ error_flag) {
+    constexpr int NV = 2 * ARMS;
+    const int ch = src.only_channel >= 0 ? src.only_channel : int(blockIdx.y);
+    const int slice = blockIdx.x, tid = threadIdx.x;
+    const gm_trk_state st = states[ch];
+    uint64_t n = st.num_samples_per_code;                                  // as in trk_correlate_kernel (:165-166, :232)
+    if (!src.linear) n = samples_per_code(cfg.fs, st.code_rate, cfg.code_len_f);
+    const int row = code_row(cfg, st);
+    bool run = st.active && n > 0 && n < (1ull << 31) && row >= 0 && row < cfg.n_codes;
+    if (run && !src.linear) run = (int64_t)(src.head - (st.next_sample_index + n)) >= 0;   // (:170-172)
+    if (run && n > cap) {            // the code rate has left the +1 % the streams were sized for: reported, never skipped silently
+        if (slice == 0 && tid == 0) *error_flag = 2;
+        run = false;
+    }
+    if (!run) {
+        if (slice == 0 && tid == 0) ready[ch] = 0;
+        return;
+    }
+    extern __shared__ int8_t chips[];
+    const int8_t* crow = codes + size_t(row) * cfg.code_len;
+    for (int i = tid; i < cfg.code_len; i += 256) chips[i] = crow[i];
+    __syncthreads();
+    const EpochConsts ec = epoch_consts(cfg, st);
+    const uint32_t per = uint32_t(((n + slices - 1) / slices + 255) / 256 * 256);
+    const uint32_t i0 = uint32_t(slice) * per;
+    const uint32_t i1 = (uint64_t(i0) + per < n) ? i0 + per : uint32_t(n);
+    const uint64_t base = src.linear ? 0 : st.next_sample_index;
+    float* out = terms + size_t(ch) * NV * cap;
+    const bool fast = fast_code_range(ec, n);
+    for (uint32_t i = i0 + tid; i < i1; i += 256) {
+        float acc[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[k] = 0.0f;
+        if (fast) correlate_sample<ARMS, true>(ec, chips, src.base[(base + i) & src.mask], i, acc);
+        else correlate_sample<ARMS, false>(ec, chips, src.base[(base + i) & src.mask], i, acc);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) out[size_t(k) * cap + i] = acc[k];
+    }
+    if (slice == 0 && tid == 0) ready[ch] = 1;
+}
+
+template <int ARMS> constexpr int trk_serial_chunk() { return ARMS == 5 ? 512 : 1024; }   // samples per LDS stage (x NV streams x 2 buffers: 48 / 40 KB)
+template <int ARMS>
+__global__ __launch_bounds__(256) void trk_serial_sum_kernel(TrkDevCfg cfg, const gm_trk_state* __restrict__ states, TrkSrc src,
+                                                             const float* __restrict__ terms, unsigned long long cap,
+                                                             const uint8_t* __restrict__ ready, float* __restrict__ partials) {
+    constexpr int NV = 2 * ARMS, CH = trk_serial_chunk<ARMS>();
+    const int ch = src.only_channel >= 0 ? src.only_channel : int(blockIdx.x);
+    const int tid = threadIdx.x;
+    float* pout = partials + size_t(ch) * NV;                              // one "slice" per channel
+    if (!ready[ch]) {
+        if (tid < NV) pout[tid] = 0.0f;
+        return;
+    }
+    const gm_trk_state st = states[ch];
+    uint64_t n64 = st.num_samples_per_code;
+    if (!src.linear) n64 = samples_per_code(cfg.fs, st.code_rate, cfg.code_len_f);
+    const uint32_t n = uint32_t(n64);
+    __shared__ float stage[2 * NV * CH];                                   // [2][NV][CH]
+    const float* in = terms + size_t(ch) * NV * cap;
+    auto fetch = [&](uint32_t c, int t0, int nt) {                         // chunk c -> buffer c & 1, by threads t0 .. t0 + nt - 1
+        float* dst = stage + size_t(c & 1u) * NV * CH;
+        const uint32_t s0 = c * CH, cnt = n - s0 < uint32_t(CH) ? n - s0 : uint32_t(CH);
+        for (int k = 0; k < NV; ++k)
+            for (uint32_t j = uint32_t(tid - t0); j < cnt; j += uint32_t(nt)) dst[k * CH + j] = in[size_t(k) * cap + s0 + j];
+    };
+    const uint32_t chunks = (n + CH - 1) / CH;
+    fetch(0, 0, 256);
+    __syncthreads();
+    float acc = 0.0f;                                                      // let mut i_p = 0.0_f32 (:244-249)
+    for (uint32_t c = 0; c < chunks; ++c) {
+        if (tid >= 64) { if (c + 1 < chunks) fetch(c + 1, 64, 192); }      // waves 1-3 stage the next chunk
+        else if (tid < NV) {                                               // lane k: sum k, sample by sample
+            const float* srcp = stage + size_t(c & 1u) * NV * CH + tid * CH;
+            const uint32_t s0 = c * CH, cnt = n - s0 < uint32_t(CH) ? n - s0 : uint32_t(CH);
+            uint32_t j = 0;
+            for (; j + 16 <= cnt; j += 16) {
+                float t[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) t[q] = srcp[j + q];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = acc + t[q];             // i_p += re * p_chip, in sample order
+            }
+            for (; j < cnt; ++j) acc = acc + srcp[j];
+        }
+        __syncthreads();
+    }
+    if (tid < NV) pout[tid] = acc;
 }
 
 // The reference's scalar epilogue of one epoch: early_late_correlation's phase advances (:240-242,
@@ -758,7 +869,7 @@ __device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t hea
     sh.fast_code = (fast_code_ok(ec, n) && float(uint32_t(n)) <= n_cap) ? 1 : 0;
 }
 
-template <int ARMS, int MODE_T, int BOC_T, int T>
+template <int ARMS, int MODE_T, int BOC_T, int T, int STRICT>
 // second launch bound = waves per SIMD with TRK_PERSIST_WG_PER_CU workgroups resident: the co-residency the exchange relies
 // on must not be lost to a register count above 512 / that
 __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persistent_kernel(TrkPersistArgs a) {
@@ -857,7 +968,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             float acc[NV], acc2[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) { acc[k] = 0.0f; acc2[k] = 0.0f; }
-            if (sh.fast_car & sh.fast_code) {
+            if (!STRICT && (sh.fast_car & sh.fast_code)) {
                 // A lane's samples are b0 + j*T, j < tot (tot = full, or full + 1 on the lanes of the ragged last pass).  They
                 // are processed FOUR at a time as one straight-line block with four accumulator sets, so the scheduler
                 // interleaves four independent dependent chains (division, f64 reduction, LDS look-ups): the phase is bound by
@@ -905,9 +1016,13 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     else
                         correlate_block_fast<ARMS, BOC_T, 1>(ec, chips, reinterpret_cast<const cf(&)[1]>(dd), reinterpret_cast<const float(&)[1]>(ff), acc, acc2);
                 }
+            } else if (STRICT && (sh.fast_car & sh.fast_code)) {   // strict_libm: the exact fast forms of the code phase and of
+                // x / fs, the carrier's cos / sin by sincosf_glibc (f64) — sample by sample, no prefetch use
+                for (uint32_t i = i0 + tid; i < i1; i += T)
+                    correlate_sample<ARMS, true, MODE_T, BOC_T, float, STRICT>(ec, chips, a.ring[(win + i) & a.mask], i, acc);
             } else {   // out-of-family state (e.g. set by the caller): general fmodf, no prefetch use
                 for (uint32_t i = i0 + tid; i < i1; i += T)
-                    correlate_sample<ARMS, false, MODE_T, BOC_T, float>(ec, chips, a.ring[(win + i) & a.mask], i, acc);
+                    correlate_sample<ARMS, false, MODE_T, BOC_T, float, STRICT>(ec, chips, a.ring[(win + i) & a.mask], i, acc);
             }
             if (st_on) stp[1] = stamp_now();
             if (a.stamps && int(blockIdx.x) == a.stamp_block && lane == 0) stp[8 + wave] = stamp_now();        // per-wave compute end
@@ -1198,16 +1313,21 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     // compile-time arms / code-index mode / BOC: straight-line sample code
     const int key = (cfg.n_arms == 5 ? 4 : 0) | (cfg.code_index_mode == GM_CODE_INDEX_FIXED ? 2 : 0) | (cfg.boc11 ? 1 : 0);
     constexpr int T = TRK_PERSIST_THREADS;
+#define GM_TRK_LAUNCH(A, M, B) \
+    if (cfg.strict_libm) hipLaunchKernelGGL((trk_persistent_kernel<A, M, B, T, 1>), grid, dim3(T), lds, st, a); \
+    else hipLaunchKernelGGL((trk_persistent_kernel<A, M, B, T, 0>), grid, dim3(T), lds, st, a); \
+    break
     switch (key) {
-        case 0: hipLaunchKernelGGL((trk_persistent_kernel<3, 0, 0, T>), grid, dim3(T), lds, st, a); break;
-        case 1: hipLaunchKernelGGL((trk_persistent_kernel<3, 0, 1, T>), grid, dim3(T), lds, st, a); break;
-        case 2: hipLaunchKernelGGL((trk_persistent_kernel<3, 1, 0, T>), grid, dim3(T), lds, st, a); break;
-        case 3: hipLaunchKernelGGL((trk_persistent_kernel<3, 1, 1, T>), grid, dim3(T), lds, st, a); break;
-        case 4: hipLaunchKernelGGL((trk_persistent_kernel<5, 0, 0, T>), grid, dim3(T), lds, st, a); break;
-        case 5: hipLaunchKernelGGL((trk_persistent_kernel<5, 0, 1, T>), grid, dim3(T), lds, st, a); break;
-        case 6: hipLaunchKernelGGL((trk_persistent_kernel<5, 1, 0, T>), grid, dim3(T), lds, st, a); break;
-        default: hipLaunchKernelGGL((trk_persistent_kernel<5, 1, 1, T>), grid, dim3(T), lds, st, a); break;
+        case 0: GM_TRK_LAUNCH(3, 0, 0);
+        case 1: GM_TRK_LAUNCH(3, 0, 1);
+        case 2: GM_TRK_LAUNCH(3, 1, 0);
+        case 3: GM_TRK_LAUNCH(3, 1, 1);
+        case 4: GM_TRK_LAUNCH(5, 0, 0);
+        case 5: GM_TRK_LAUNCH(5, 0, 1);
+        case 6: GM_TRK_LAUNCH(5, 1, 0);
+        default: GM_TRK_LAUNCH(5, 1, 1);
     }
+#undef GM_TRK_LAUNCH
 }
 
 // Workgroups of the persistent kernel one CU can hold at once (occupancy API for THIS instantiation and its dynamic LDS,
@@ -1219,23 +1339,51 @@ int trk_persistent_blocks_per_cu(const TrkDevCfg& cfg) {
     constexpr int T = TRK_PERSIST_THREADS;
     int n = 0;
     hipError_t e = hipSuccess;
+#define GM_TRK_OCC(A, M, B) \
+    e = cfg.strict_libm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<A, M, B, T, 1>, T, lds) \
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<A, M, B, T, 0>, T, lds); \
+    break
     switch (key) {
-        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<3, 0, 0, T>, T, lds); break;
-        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<3, 0, 1, T>, T, lds); break;
-        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<3, 1, 0, T>, T, lds); break;
-        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<3, 1, 1, T>, T, lds); break;
-        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<5, 0, 0, T>, T, lds); break;
-        case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<5, 0, 1, T>, T, lds); break;
-        case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<5, 1, 0, T>, T, lds); break;
-        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trk_persistent_kernel<5, 1, 1, T>, T, lds); break;
+        case 0: GM_TRK_OCC(3, 0, 0);
+        case 1: GM_TRK_OCC(3, 0, 1);
+        case 2: GM_TRK_OCC(3, 1, 0);
+        case 3: GM_TRK_OCC(3, 1, 1);
+        case 4: GM_TRK_OCC(5, 0, 0);
+        case 5: GM_TRK_OCC(5, 0, 1);
+        case 6: GM_TRK_OCC(5, 1, 0);
+        default: GM_TRK_OCC(5, 1, 1);
     }
+#undef GM_TRK_OCC
     if (e != hipSuccess || n < 1) n = 1;
     return n < TRK_PERSIST_WG_PER_CU ? n : TRK_PERSIST_WG_PER_CU;
 }
 
+template <int ARMS>
+static void launch_trk_epoch_serial(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_codes, gm_trk_state* d_states,
+                                    const TrkSrc& src, int slices, float* d_partials, uint8_t* d_ready, int mode,
+                                    gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost, uint8_t* d_lost_prn,
+                                    float* d_terms, size_t terms_cap, int* d_error) {
+    const int nch = src.only_channel >= 0 ? 1 : cfg.n_channels;
+    const int ub = 64, ug = src.only_channel >= 0 ? 1 : (cfg.n_channels + ub - 1) / ub;
+    hipLaunchKernelGGL(trk_terms_kernel<ARMS>, dim3(slices, nch), dim3(256), size_t(cfg.code_len), st, cfg, d_codes, d_states, src,
+                       slices, d_terms, (unsigned long long)terms_cap, d_ready, d_error);
+    hipLaunchKernelGGL(trk_serial_sum_kernel<ARMS>, dim3(nch), dim3(256), 0, st,
+                       cfg, d_states, src, d_terms, (unsigned long long)terms_cap, d_ready, d_partials);
+    hipLaunchKernelGGL(trk_update_kernel<ARMS>, dim3(ug), dim3(ub), 0, st, cfg, d_states, d_partials, d_ready,
+                       1, mode, src.only_channel, src.linear, d_outs, d_processed, d_lost, d_lost_prn);
+}
+
 void launch_trk_epoch(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_codes, gm_trk_state* d_states,
                       const TrkSrc& src, int slices, float* d_partials, uint8_t* d_ready, int mode,
-                      gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost, uint8_t* d_lost_prn) {
+                      gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost, uint8_t* d_lost_prn,
+                      float* d_terms, size_t terms_cap, int* d_error) {
+    if (cfg.strict_sum_order) {      // the reference's sequential sums (see trk_terms_kernel)
+        if (cfg.n_arms == 5) launch_trk_epoch_serial<5>(st, cfg, d_codes, d_states, src, slices, d_partials, d_ready, mode, d_outs,
+                                                        d_processed, d_lost, d_lost_prn, d_terms, terms_cap, d_error);
+        else launch_trk_epoch_serial<3>(st, cfg, d_codes, d_states, src, slices, d_partials, d_ready, mode, d_outs, d_processed,
+                                        d_lost, d_lost_prn, d_terms, terms_cap, d_error);
+        return;
+    }
     const int nch = src.only_channel >= 0 ? 1 : cfg.n_channels;
     const dim3 grid(slices, nch);
     const size_t lds = size_t(cfg.code_len);

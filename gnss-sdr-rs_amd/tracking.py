@@ -87,9 +87,11 @@ class TrackingManager:
 
     def __init__(self, fs, n_channels=NUM_OF_CHANNELS, n_arms=3, code_index_mode=CODE_INDEX_FAITHFUL,
                  early_late_space=0.5, very_early_late_space=1.0, boc11=False, codes=None, nominal_code_rate=0.0,
-                 device=None):
+                 device=None, strict_libm=False, strict_sum_order=False):
         _lib.init(device if device is not None else (_lib._initialised or 0))
         cfg = TrkCfg()
+        cfg.strict_libm = int(strict_libm)     # the carrier's cos / sin as glibc's cosf / sinf, bit for bit (gm_trk_cfg.strict_libm)
+        cfg.strict_sum_order = int(strict_sum_order)   # the sums in the reference's sample order (with strict_libm: bit-identical state)
         cfg.fs, cfg.n_channels, cfg.n_arms = fs, n_channels, n_arms
         cfg.early_late_space, cfg.very_early_late_space = early_late_space, very_early_late_space
         cfg.code_index_mode, cfg.boc11 = code_index_mode, int(boc11)

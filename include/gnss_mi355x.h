@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GM_ABI_VERSION 3
+#define GM_ABI_VERSION 4
 
 typedef enum {
     GM_OK = 0,
@@ -338,6 +338,17 @@ typedef struct {
     float pll_bw, pll_zeta, pll_gain, dll_bw, dll_zeta, dll_gain, pll_dt, dll_dt;
     float lock_threshold;      /* LOCK_THRESHOLD = 15 (:16) */
     uint32_t max_lost_epochs;  /* MAX_LOST_EPOCHS = 20 (:17) */
+    int32_t strict_libm;       /* 1: the carrier's cos / sin (`phase.cos()`, `phase.sin()`, :234-235) are glibc 2.35's cosf / sinf
+                                  restated on the device, bit for bit (csrc/gm_libm.h sincosf_glibc: f64 reduction + polynomial,
+                                  one rounding) — every sample's products then equal the reference host's; 0 (default): the
+                                  device's own < 1 ulp forms, which differ from glibc's in the last bit on a quarter of the
+                                  samples.  ABI version 4. */
+    int32_t strict_sum_order;  /* 1: the correlator sums are added sample by sample in f32, the reference's own order
+                                  (`i_p += re * p_chip`, :256-262) — one serial wave per channel instead of the persistent
+                                  kernel's tree (csrc/trk_kernels.hip trk_serial_sum_kernel; ~35x its time per epoch).  With
+                                  strict_libm as well, every correlator sum and every word of the channel state equal the
+                                  reference's bit for bit, free-running.  0 (default): tree sums, within 1e-5 of the
+                                  envelope and closer to the exact sum.  ABI version 4. */
 } gm_trk_cfg;
 
 typedef struct gm_trk gm_trk;

@@ -52,6 +52,8 @@ pub struct GmTrkCfg {               // gm_trk_cfg (zero = reference default)
     pub nominal_code_rate: f32, pub pll_bw: f32, pub pll_zeta: f32, pub pll_gain: f32, pub dll_bw: f32,
     pub dll_zeta: f32, pub dll_gain: f32, pub pll_dt: f32, pub dll_dt: f32, pub lock_threshold: f32,
     pub max_lost_epochs: u32,
+    pub strict_libm: i32,           // 1 = the carrier's cos / sin are glibc's cosf / sinf restated on the device (bit-identical products)
+    pub strict_sum_order: i32,      // 1 = the correlator sums added sample by sample like do_tracking.rs:256-262 (with strict_libm: bit-identical state)
 }
 pub enum GmAcq {} pub enum GmTrk {} pub enum GmRing {} pub enum GmComm {}
 

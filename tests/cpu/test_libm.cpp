@@ -111,6 +111,27 @@ int main() {
         printf("spc_rate_bounds: %llu rates inside their intervals, %llu mismatches (%llu empty intervals)\n", ns, bads, empty);
         bad += bads;
     }
+    // sincosf_glibc against the host's sinf / cosf, bit for bit: every 127th f32 bit pattern (all exponents, both signs, inf / NaN),
+    // a dense sweep of the carrier's operating range (|phase| up to 2.7e5 rad: both reductions), and the neighbourhood of the
+    // range boundaries (2^-12, pi/4, 120)
+    {
+        unsigned long long nsc = 0, badsc = 0;
+        auto check = [&](float x) {
+            float s, c;
+            gm::sincosf_glibc(x, s, c);
+            const float hs = sinf(x), hc = cosf(x);
+            const bool same = (gm::f32_bits(s) == gm::f32_bits(hs) || (s != s && hs != hs)) && (gm::f32_bits(c) == gm::f32_bits(hc) || (c != c && hc != hc));
+            if (!same && badsc++ < 10) printf("sincosf_glibc MISMATCH x=%a ours=(%a, %a) libm=(%a, %a)\n", x, s, c, hs, hc);
+            ++nsc;
+        };
+        for (unsigned long long u = 0; u < 0x100000000ull; u += 127) check(gm::f32_from_bits(uint32_t(u)));
+        for (unsigned i = 0; i <= (1u << 26); ++i) check(float(-270000.0 + 540000.0 * double(i) / double(1u << 26)));
+        const float edges[] = {0x1p-12f, 0x1.921fb6p-1f, 120.0f, 0x1p-126f, 1.0f, 8.0f, 0x1p23f, 0x1p24f, 0x1p31f, 0x1p100f};
+        for (float e : edges)
+            for (int k = -2000; k <= 2000; ++k) { const float v = gm::f32_from_bits(gm::f32_bits(e) + k); check(v); check(-v); }
+        printf("sincosf_glibc: %llu arguments, %llu mismatches\n", nsc, badsc);
+        bad += badsc;
+    }
     // sincos_cw against the f64 functions of the same f32 argument: |x| <= 131072 (the fast path admits 1e5), 2^25 arguments
     double worst = 0.0;
     unsigned long long ns = 0, lastbit = 0;

@@ -23,7 +23,7 @@ def test_header_symbols_all_exported(gm):
     exported = set(re.findall(r" T (gm_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
     assert not [s for s in re.findall(r" [TDB] (\S+)", nm) if not s.startswith("gm_")]   # nothing else leaks
-    assert gm.lib().gm_abi_version() == 3
+    assert gm.lib().gm_abi_version() == 4
 
 
 def test_library_links_no_oracle_and_no_torch(gm):

@@ -296,3 +296,242 @@ def test_phase_beyond_the_fast_range_takes_the_general_forms(gpu, oracle):
                  rel=2e-5, free_rel=2e-4)     # 50 000 terms per sum: the reference's own sequential f32 order is 1.3e-5 away from f64 (cfg5 note)
     print("20 MHz IF", w)
     mgr.close(); ring.close()
+
+
+# ------------------------------------------------------------------------------------------------ gm_trk_cfg.strict_libm
+# The carrier's cos / sin as glibc 2.35's cosf / sinf, restated on the device (csrc/gm_libm.h sincosf_glibc; the CPU suite
+# checks the restatement against this host's libm on 1e8 arguments).  The oracle calls the host's cosf / sinf — what the
+# reference's `phase.cos()` / `phase.sin()` (do_tracking.rs:234-235) resolve to — so with the switch on every sample's
+# products are the SAME f32 values on both sides and what is left of the 1e-5 is the summation order alone.
+STRICT_F64_REL = 2.5e-7    # device tree sum of the identical products against their f64 accumulation (measured 1.2e-7; 5e-7 without the switch)
+STRICT_FREE_REL = FREE_REL  # free-running with identical products: measured 0.9e-5 (FAITHFUL) / 1.35e-5 (FIXED) over 12 epochs, against
+                            # 1.3e-5 without the switch — NO tighter: what feeds the loops is the reference's own sequential f32 summation
+                            # order (7.4e-6 teacher-forced, with or without the switch), which no parallel sum reproduces
+
+
+@pytest.mark.parametrize("fs,f_if,doppler", [(25.0e6, 0.0, 1830.0), (16_367_600.0, 4_130_400.0, -2210.0), (8.0e6, 0.0, 3.0)])
+def test_strict_libm_single_sample_products_equal_the_hosts(gpu, oracle, fs, f_if, doppler):
+    """One-hot sample vectors through early_late_correlation (gm_trk_correlate): with a single sample (1 + 0j) at index i the
+    prompt sums ARE that sample's products, cos(phase_i) * chip and -sin(phase_i) * chip (adding zeros is exact) — so the
+    device's cos / sin of 3 x 200 carrier phases are compared with the host libm's BIT FOR BIT.  Phases: below pi/4 and up
+    to ~20 rad (reduce_fast), and up to 2.6e4 rad at the reference capture's 4.1304 MHz IF (reduce_large); the state the
+    calls advance (carrier_phase, code_phase) must stay word-equal as well."""
+    from gnss_sdr_rs_amd import tracking as T
+    n = int(oracle.num_samples_per_code(1.023e6, fs))
+    mgr = T.TrackingManager(fs, n_channels=2, code_index_mode=1, strict_libm=True)
+    ch, oc = mgr.channels[1], oracle.TrackingChannel(1, fs, code_index_mode=1)
+    for c in (ch, oc):
+        c.start(dict(prn=9, code_phase_samples=0, code_phase_chips=0.0, carrier_freq=f_if + doppler, fs=fs, mag_relative=10.0,
+                     sample_global_index=0, doppler_bin=0))
+    rng = np.random.default_rng(int(fs) % 1000)
+    idx = np.concatenate([[0, 1, 2, n - 1], rng.integers(0, n, 196)])
+    seen_nonzero = 0
+    for i in idx:
+        seg = np.zeros(n, np.complex64)
+        seg[int(i)] = 1.0
+        got = np.array(ch.early_late_correlation(seg), np.float32)
+        exp = np.array(oc.early_late_correlation(seg), np.float32)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (int(i), got, exp)
+        seen_nonzero += int(abs(got[0]) > 0) + int(abs(got[1]) > 0)
+        s = ch.state
+        assert s.carrier_phase == oc.c.carrier_phase and s.code_phase == oc.c.code_phase
+    assert seen_nonzero >= 390
+    # the default (strict_libm = 0) forms differ from the host's in the last bit on a quarter of the arguments: the same probe must see it
+    dflt = T.TrackingManager(fs, n_channels=2, code_index_mode=1)
+    dc, oc2 = dflt.channels[1], oracle.TrackingChannel(1, fs, code_index_mode=1)
+    for c in (dc, oc2):
+        c.start(dict(prn=9, code_phase_samples=0, code_phase_chips=0.0, carrier_freq=f_if + doppler, fs=fs, mag_relative=10.0,
+                     sample_global_index=0, doppler_bin=0))
+    differ = 0
+    for i in idx:
+        seg = np.zeros(n, np.complex64)
+        seg[int(i)] = 1.0
+        got = np.array(dc.early_late_correlation(seg), np.float32)
+        exp = np.array(oc2.early_late_correlation(seg), np.float32)
+        assert np.max(np.abs(got[:2].astype(np.float64) - exp[:2])) <= 1.3e-7         # 2 ulp of values below 1
+        differ += int(not np.array_equal(got[:2].view(np.uint32), exp[:2].view(np.uint32)))
+    print("strict probe", fs, "default forms differ on", differ, "of", len(idx))
+    if f_if > 0 or doppler > 100:
+        assert differ > 0
+    mgr.close(); dflt.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_strict_libm_cfg3_free_running(gpu, oracle, mode):
+    """BASELINE configs[2] (32 channels x 25 Msps) with strict_libm: identical products, so the teacher-forced sums sit
+    within the device tree sum's own error of the f64 accumulation (STRICT_F64_REL: 1.2e-7 measured, 5e-7 without the
+    switch).  The FREE-RUNNING comparison — the reference's plain update() from the same start, 12 epochs of loop feedback —
+    does NOT tighten (0.9e-5 / 1.35e-5 for FAITHFUL / FIXED against 1.3e-5 without the switch): the teacher-forced 7.4e-6 is the
+    reference's sequential f32 summation order against the device's tree, untouched by the switch, and that is what the
+    loops integrate.  So the answer to "does free-running hold 1e-5 once cos / sin are glibc's" is no; the bound stays FREE_REL."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    fs, n, C, E = 25.0e6, 25000, 32, 12
+    t = oracle.ca_code_table()
+    prns = [1 + (i % 31) for i in range(C)]
+    uniq = sorted(set(prns))
+    rows = [p if mode == 0 else p - 1 for p in uniq]
+    sc = synth.tracking_scene(t, fs, 0.0, uniq, E + 2, config_id=3, cn0=47.0, code_rows=rows)
+    x = synth.to_c32(sc["x"])
+    ring, oring = T.MulticastRingBuffer(1 << 19), oracle.MulticastRingBuffer(1 << 19)
+    ring.write_samples(x[:(E + 1) * n])
+    oring.write_samples(x[:(E + 1) * n])
+    mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=mode, strict_libm=True)
+    by_prn = {s["prn"]: s for s in sc["sats"]}
+    starts = [_acq_result(p, by_prn[p]["doppler_hz"] + 20.0 - 1.5 * (i // 31), fs, by_prn[p]["code_start"])
+              for i, p in enumerate(prns)]
+    w = _compare(mgr, ring, oring, starts, lambda i: oracle.TrackingChannel(i, fs, code_index_mode=mode), 3, E, E,
+                 rel=REL, free_rel=STRICT_FREE_REL)
+    print("cfg3 strict mode", mode, w)
+    assert w["f64"] <= STRICT_F64_REL, w
+    mgr.close(); ring.close()
+
+
+def test_strict_libm_large_phase_and_five_arms(gpu, oracle):
+    """strict_libm on the two other sample paths: (a) a 20 MHz IF at 50 Msps (phases to 1.26e5 rad: glibc's reduce_large on
+    the device, inside correlate_sample<FAST = false>), (b) the BOC(1,1) five-arm geometry of BASELINE configs[4] at a
+    reduced channel count.  Teacher-forced against the oracle; the f64 bound is the strict one."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    fs, f_if, n, C, E = 50.0e6, 20.0e6, 50000, 3, 5
+    t = oracle.ca_code_table()
+    sc = synth.tracking_scene(t, fs, f_if, [2, 12, 30], E + 2, config_id=71, cn0=50.0)
+    x = synth.to_c32(sc["x"])
+    ring, oring = T.MulticastRingBuffer(1 << 19), oracle.MulticastRingBuffer(1 << 19)
+    ring.write_samples(x[:(E + 1) * n])
+    oring.write_samples(x[:(E + 1) * n])
+    mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=1, strict_libm=True)
+    starts = [_acq_result(s["prn"], f_if + s["doppler_hz"] + 10.0, fs, s["code_start"]) for s in sc["sats"]]
+    w = _compare(mgr, ring, oring, starts, lambda i: oracle.TrackingChannel(i, fs, code_index_mode=1), 3, E, E,
+                 rel=2e-5, free_rel=2e-5)     # 50 000 terms per sum: the reference's sequential f32 order alone is 1.3e-5 from f64
+    print("20 MHz IF strict", w)
+    assert w["f64"] <= STRICT_F64_REL, w
+    mgr.close(); ring.close()
+    # (b)
+    fs, L, rate, C, E = 50.0e6, 4092, 1.023e6, 6, 4
+    n = 200000
+    rng = np.random.default_rng(56)
+    codes = np.where(rng.integers(0, 2, (C, L)) > 0, 1, -1).astype(np.int8)
+    dopp = rng.uniform(-2000, 2000, C)
+    cstart = rng.integers(0, 5000, C)
+    x = _boc_scene(codes, fs, rate, L, (E + 1) * n, dopp, cstart)
+    ring, oring = T.MulticastRingBuffer(1 << 21), oracle.MulticastRingBuffer(1 << 21)
+    ring.write_samples(x)
+    oring.write_samples(x)
+    mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED, nominal_code_rate=rate, n_arms=5,
+                            early_late_space=0.25, very_early_late_space=0.6, boc11=True, codes=codes, strict_libm=True)
+    starts = [_acq_result(c + 1, float(dopp[c]) + 10.0, fs, int(cstart[c])) for c in range(C)]
+    w = _compare(mgr, ring, oring, starts,
+                 lambda i: oracle.TrackingChannel(i, fs, code_index_mode=1, n_arms=5, el_space=0.25, vel_space=0.6, boc11=True,
+                                                  codes=codes, code_rate=rate), 5, E, E, rel=4e-5, free_rel=4e-5)
+    print("cfg5 geometry strict", w)
+    assert w["f64"] <= STRICT_F64_REL, w
+    mgr.close(); ring.close()
+
+
+# ------------------------------------------------------------------------------- strict_libm + strict_sum_order: bit for bit
+def _assert_bit_identical_free_running(mgr, ring, oring, starts, make_oracle, arms, epochs):
+    """update_all against the oracle's plain update() from the same start (FREE-RUNNING, no teacher forcing): every
+    correlator sum of every epoch and every word of the final channel state must be the same bits."""
+    free = []
+    for i, r in enumerate(starts):
+        mgr.channels[i].start(r)
+        oc = make_oracle(i)
+        oc.start(r)
+        free.append(oc)
+    outs, proc, lost, done = mgr.update_all(ring, epochs)
+    assert done == epochs and not lost.any() and proc.all()
+    nv = 2 * arms
+    for i in range(len(starts)):
+        for ep in range(epochs):
+            rc, exp, _ = free[i].update_ex(oring)
+            assert rc != 0
+            got = np.ascontiguousarray(outs[ep, i, :nv], np.float32)
+            want = np.ascontiguousarray(np.asarray(exp[:nv], np.float32))
+            assert float(np.hypot(want[0], want[1])) > 100.0
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (i, ep, got, want)
+        s, o = mgr.channels[i].state, free[i].c
+        assert s.next_sample_index == o.next_sample_index and s.num_samples_per_code == o.num_samples_per_code
+        assert s.lost_counter == o.lost_counter == 0 and s.prn == o.prn
+        for k in ("carrier_freq", "carrier_phase", "carrier_error", "carrier_nco", "code_phase", "code_error", "code_nco",
+                  "code_rate", "i_prompt", "q_prompt"):
+            assert _ulps(getattr(s, k), getattr(o, k)) == 0, (i, k, getattr(s, k), getattr(o, k))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_strict_modes_cfg3_free_running_bit_identical(gpu, oracle, mode):
+    """BASELINE configs[2] (32 channels x 25 Msps, E/P/L) with gm_trk_cfg.strict_libm + strict_sum_order: glibc's cos / sin
+    and the reference's sequential sums (do_tracking.rs:231-263) on the device.  40 epochs FREE-RUNNING from the acquisition
+    hand-over — PLL / DLL feedback and all — and every sum of every epoch and every state word equals the oracle's bit for
+    bit: the tolerance of this path is zero when the caller asks for it."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    fs, n, C, E = 25.0e6, 25000, 32, 40
+    t = oracle.ca_code_table()
+    prns = [1 + (i % 31) for i in range(C)]
+    uniq = sorted(set(prns))
+    rows = [p if mode == 0 else p - 1 for p in uniq]
+    sc = synth.tracking_scene(t, fs, 0.0, uniq, E + 2, config_id=3, cn0=47.0, code_rows=rows)
+    x = synth.to_c32(sc["x"])
+    ring, oring = T.MulticastRingBuffer(1 << 21), oracle.MulticastRingBuffer(1 << 21)
+    ring.write_samples(x[:(E + 1) * n])
+    oring.write_samples(x[:(E + 1) * n])
+    mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=mode, strict_libm=True, strict_sum_order=True)
+    by_prn = {s["prn"]: s for s in sc["sats"]}
+    starts = [_acq_result(p, by_prn[p]["doppler_hz"] + 20.0 - 1.5 * (i // 31), fs, by_prn[p]["code_start"])
+              for i, p in enumerate(prns)]
+    _assert_bit_identical_free_running(mgr, ring, oring, starts, lambda i: oracle.TrackingChannel(i, fs, code_index_mode=mode), 3, E)
+    mgr.close(); ring.close()
+
+
+def test_strict_modes_other_paths_bit_identical(gpu, oracle):
+    """The same zero-tolerance comparison on the other sample paths: (a) the reference capture's geometry, 16.3676 Msps with
+    a 4.1304 MHz IF (phases to 2.6e4 rad: glibc's reduce_large; n = 16368, not a multiple of the LDS stage), (b) a 20 MHz
+    IF at 50 Msps (the general forms: library fmod, IEEE division), (c) BOC(1,1), five arms, a 4092-chip custom code at
+    50 Msps (n = 200 000: 196 stages per sum), (d) the unit entries early_late_correlation / do_work on caller samples."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    t = oracle.ca_code_table()
+    for fs, f_if, prns, E, cid in ((16_367_600.0, 4_130_400.0, [3, 11, 19, 27], 15, 72), (50.0e6, 20.0e6, [2, 12, 30], 5, 71)):
+        n = int(oracle.num_samples_per_code(1.023e6, fs))
+        sc = synth.tracking_scene(t, fs, f_if, prns, E + 2, config_id=cid, cn0=50.0)
+        x = synth.to_c32(sc["x"])
+        ring, oring = T.MulticastRingBuffer(1 << 19), oracle.MulticastRingBuffer(1 << 19)
+        ring.write_samples(x[:(E + 1) * n])
+        oring.write_samples(x[:(E + 1) * n])
+        mgr = T.TrackingManager(fs, n_channels=len(prns), code_index_mode=1, strict_libm=True, strict_sum_order=True)
+        starts = [_acq_result(s["prn"], f_if + s["doppler_hz"] + 10.0, fs, s["code_start"]) for s in sc["sats"]]
+        _assert_bit_identical_free_running(mgr, ring, oring, starts, lambda i: oracle.TrackingChannel(i, fs, code_index_mode=1), 3, E)
+        # (d) unit entries (a fresh handle: start() keeps the code rate the loops left behind, as the reference's does)
+        mgr.close()
+        mgr = T.TrackingManager(fs, n_channels=2, code_index_mode=1, strict_libm=True, strict_sum_order=True)
+        ch, oc = mgr.channels[0], oracle.TrackingChannel(0, fs, code_index_mode=1)
+        for c in (ch, oc):
+            c.start(_acq_result(sc["sats"][0]["prn"], f_if + sc["sats"][0]["doppler_hz"] + 10.0, fs, 0))
+        seg = x[sc["sats"][0]["code_start"]:sc["sats"][0]["code_start"] + n]
+        got = np.array(ch.early_late_correlation(seg), np.float32)
+        want = np.array(oc.early_late_correlation(seg), np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (got, want)
+        seg2 = x[sc["sats"][0]["code_start"] + n:sc["sats"][0]["code_start"] + 2 * n]
+        got2, msg = ch.do_work(seg2)
+        want2, wmsg = oc.do_work(seg2)
+        assert np.array_equal(np.array(got2, np.float32).view(np.uint32), np.array(want2, np.float32).view(np.uint32)) and msg == wmsg
+        for k in ("carrier_freq", "carrier_phase", "carrier_nco", "code_phase", "code_rate", "code_nco"):
+            assert _ulps(getattr(ch.state, k), getattr(oc.c, k)) == 0, k
+        mgr.close(); ring.close()
+    # (c)
+    fs, L, rate, C, E = 50.0e6, 4092, 1.023e6, 5, 4
+    n = 200000
+    rng = np.random.default_rng(57)
+    codes = np.where(rng.integers(0, 2, (C, L)) > 0, 1, -1).astype(np.int8)
+    dopp = rng.uniform(-2000, 2000, C)
+    cstart = rng.integers(0, 5000, C)
+    x = _boc_scene(codes, fs, rate, L, (E + 1) * n, dopp, cstart)
+    ring, oring = T.MulticastRingBuffer(1 << 21), oracle.MulticastRingBuffer(1 << 21)
+    ring.write_samples(x)
+    oring.write_samples(x)
+    mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED, nominal_code_rate=rate, n_arms=5,
+                            early_late_space=0.25, very_early_late_space=0.6, boc11=True, codes=codes, strict_libm=True,
+                            strict_sum_order=True)
+    starts = [_acq_result(c + 1, float(dopp[c]) + 10.0, fs, int(cstart[c])) for c in range(C)]
+    _assert_bit_identical_free_running(
+        mgr, ring, oring, starts,
+        lambda i: oracle.TrackingChannel(i, fs, code_index_mode=1, n_arms=5, el_space=0.25, vel_space=0.6, boc11=True, codes=codes,
+                                         code_rate=rate), 5, E)
+    mgr.close(); ring.close()

@@ -121,3 +121,37 @@ def test_reference_synthetic_tests_through_the_hip_path(gpu, oracle, name):
         assert s.next_sample_index == forced.c.next_sample_index and s.num_samples_per_code == forced.c.num_samples_per_code
     _reference_asserts(name, recs, sig.size)
     mgr.close(); ring.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pll", "dll"])
+def test_reference_synthetic_tests_strict_modes_equal_the_committed_vectors(gpu, oracle, name):
+    """The same two reference tests with gm_trk_cfg.strict_libm + strict_sum_order (glibc's cos / sin, the reference's
+    sequential sums): FREE-RUNNING — no teacher forcing, no oracle in the loop — every correlator sum, every index and every
+    state word after each of the three update() calls equals the committed restatement output
+    (tests/golden/tracking_synthetic.npz) bit for bit, and the reference's own assertions hold on them."""
+    from gnss_sdr_rs_amd import tracking as T
+    g, fx = _gen(), _fixture()
+    sc = g.scenario(oracle, name)
+    sig, fs = sc["signal"], sc["fs"]
+    ring = T.MulticastRingBuffer(sc["ring"])
+    mgr = T.TrackingManager(fs, n_channels=4, code_index_mode=T.CODE_INDEX_FAITHFUL, strict_libm=True, strict_sum_order=True)
+    ch = mgr.channels[sc["ch_id"]]
+    ch.start(dict(prn=sc["prn"], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=sc["start_freq"], fs=fs,
+                  mag_relative=10.0, sample_global_index=0, doppler_bin=0))
+    recs = []
+    for k, writes in enumerate((1, 2, 1)):
+        for _ in range(writes):
+            ring.write_samples(sig)
+        outs, proc, lost, done = mgr.update_all(ring, 1)
+        assert done == 1 and proc[0, sc["ch_id"]] and proc.sum() == 1 and not lost.any()
+        got = np.ascontiguousarray(outs[0, sc["ch_id"]], np.float32)
+        s = ch.state
+        recs.append(dict(out=got, head=ring.get_head(), next_sample_index=s.next_sample_index,
+                         num_samples_per_code=s.num_samples_per_code, carrier_error=s.carrier_error,
+                         carrier_nco=s.carrier_nco, carrier_freq=s.carrier_freq))
+        assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(fx[name + "_out"][k], np.float32).view(np.uint32)), (k, got, fx[name + "_out"][k])
+        assert [ring.get_head(), s.next_sample_index, s.num_samples_per_code] == fx[name + "_index"][k].tolist()
+        assert (np.array([getattr(s, w) for w in g.STATE_WORDS], np.float32).view(np.uint32) == fx[name + "_state"][k].view(np.uint32)).all(), k
+    _reference_asserts(name, recs, sig.size)
+    mgr.close(); ring.close()
