@@ -1227,6 +1227,7 @@ struct gm_trk {
 static int trk_check_error(gm_trk* t);
 // strict_sum_order: room for `samples` per-sample products per sum and channel
 static int trk_reserve_terms(gm_trk* t, size_t samples) {
+    samples = (samples + 3) & ~size_t(3);       // rows of the streams stay 16-byte aligned
     if (!t->dc.strict_sum_order || samples <= t->terms_cap) return GM_OK;
     HIPC(hipStreamSynchronize(t->stream));
     hipFree(t->d_terms); t->d_terms = nullptr; t->terms_cap = 0;

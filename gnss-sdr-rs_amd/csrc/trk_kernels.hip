@@ -534,32 +534,51 @@ __global__ __launch_bounds__(256) void trk_serial_sum_kernel(TrkDevCfg cfg, cons
     uint64_t n64 = st.num_samples_per_code;
     if (!src.linear) n64 = samples_per_code(cfg.fs, st.code_rate, cfg.code_len_f);
     const uint32_t n = uint32_t(n64);
-    __shared__ float stage[2 * NV * CH];                                   // [2][NV][CH]
-    const float* in = terms + size_t(ch) * NV * cap;
-    auto fetch = [&](uint32_t c, int t0, int nt) {                         // chunk c -> buffer c & 1, by threads t0 .. t0 + nt - 1
-        float* dst = stage + size_t(c & 1u) * NV * CH;
+    __shared__ float4 stage4[2 * NV * CH / 4];                             // [2][NV][CH] floats
+    const float* in = terms + size_t(ch) * NV * cap;                       // cap is a multiple of 4 (trk_reserve_terms): rows 16-byte aligned
+    // chunk c -> buffer c & 1, by the NT threads t0 .. t0 + NT - 1: 16-byte loads, all of a thread's loads in flight before its
+    // first LDS store (the element-by-element form waited for every load by itself and was what bounded the kernel).  Words
+    // beyond the epoch's n inside the last 16 bytes are never summed.
+    auto fetch = [&](uint32_t c, int t0, auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value, PER = (NV * CH / 4 + NT - 1) / NT;
+        float4* dst = stage4 + size_t(c & 1u) * (NV * CH / 4);
         const uint32_t s0 = c * CH, cnt = n - s0 < uint32_t(CH) ? n - s0 : uint32_t(CH);
-        for (int k = 0; k < NV; ++k)
-            for (uint32_t j = uint32_t(tid - t0); j < cnt; j += uint32_t(nt)) dst[k * CH + j] = in[size_t(k) * cap + s0 + j];
+        const uint32_t q4 = (cnt + 3) / 4;                                 // 16-byte groups per stream in this chunk
+        float4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const uint32_t f = uint32_t(tid - t0) + uint32_t(u) * NT, k = f / (CH / 4), j4 = f % (CH / 4);
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < uint32_t(NV * CH / 4) && j4 < q4) v[u] = *reinterpret_cast<const float4*>(in + size_t(k) * cap + s0 + 4 * j4);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const uint32_t f = uint32_t(tid - t0) + uint32_t(u) * NT;
+            if (f < uint32_t(NV * CH / 4)) dst[f] = v[u];
+        }
     };
     const uint32_t chunks = (n + CH - 1) / CH;
-    fetch(0, 0, 256);
+    fetch(0, 0, std::integral_constant<int, 256>());
     __syncthreads();
     float acc = 0.0f;                                                      // let mut i_p = 0.0_f32 (:244-249)
     for (uint32_t c = 0; c < chunks; ++c) {
-        if (tid >= 64) { if (c + 1 < chunks) fetch(c + 1, 64, 192); }      // waves 1-3 stage the next chunk
+        if (tid >= 64) { if (c + 1 < chunks) fetch(c + 1, 64, std::integral_constant<int, 192>()); }   // waves 1-3 stage the next chunk
         else if (tid < NV) {                                               // lane k: sum k, sample by sample
-            const float* srcp = stage + size_t(c & 1u) * NV * CH + tid * CH;
+            const float4* srcp = stage4 + size_t(c & 1u) * (NV * CH / 4) + tid * (CH / 4);
             const uint32_t s0 = c * CH, cnt = n - s0 < uint32_t(CH) ? n - s0 : uint32_t(CH);
-            uint32_t j = 0;
-            for (; j + 16 <= cnt; j += 16) {
-                float t[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) t[q] = srcp[j + q];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc = acc + t[q];             // i_p += re * p_chip, in sample order
+            const uint32_t full = cnt / 16;                                // batches of 16 samples, the next batch's LDS reads
+            float4 a0, a1, a2, a3;                                         // issued before the current batch's 16 dependent adds
+            if (full) { a0 = srcp[0]; a1 = srcp[1]; a2 = srcp[2]; a3 = srcp[3]; }
+            for (uint32_t bt = 0; bt < full; ++bt) {
+                const float4 b0 = a0, b1 = a1, b2 = a2, b3 = a3;
+                if (bt + 1 < full) { a0 = srcp[4 * bt + 4]; a1 = srcp[4 * bt + 5]; a2 = srcp[4 * bt + 6]; a3 = srcp[4 * bt + 7]; }
+                acc = acc + b0.x; acc = acc + b0.y; acc = acc + b0.z; acc = acc + b0.w;      // i_p += re * p_chip, in sample order
+                acc = acc + b1.x; acc = acc + b1.y; acc = acc + b1.z; acc = acc + b1.w;
+                acc = acc + b2.x; acc = acc + b2.y; acc = acc + b2.z; acc = acc + b2.w;
+                acc = acc + b3.x; acc = acc + b3.y; acc = acc + b3.z; acc = acc + b3.w;
             }
-            for (; j < cnt; ++j) acc = acc + srcp[j];
+            const float* tail = reinterpret_cast<const float*>(srcp);
+            for (uint32_t j = full * 16; j < cnt; ++j) acc = acc + tail[j];
         }
         __syncthreads();
     }
