@@ -88,6 +88,10 @@ def main():
 
     from gnss_sdr_rs_amd import _lib, acquisition as A, synth, tracking as T
     _lib.init(local_rank)                      # raises if the HIP library is missing: no fallback
+    # inputs: SURVEY §8 d2's C++ generator (splitmix64-seeded xoshiro256**, Box-Muller; gnss-sdr-rs_amd/synthgen) unless told
+    # otherwise — identical bytes on every rank and every box for a given seed, no numpy version in the loop
+    if "GM_SYNTH_GENERATOR" not in os.environ:
+        synth.DEFAULT_GENERATOR = "xoshiro"
 
     # ------------------------------------------------------------------ acquisition workload (configs[1])
     ca = A.ca_code_table()
@@ -325,6 +329,7 @@ def main():
         "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (DEBUG gloo rehearsal, one GPU shared)" if debug_gloo else ""),
+        "data_generator": synth.DEFAULT_GENERATOR + (" (C++: splitmix64-seeded xoshiro256**, Box-Muller; seed 0x6E5553445200 + config id)" if synth.DEFAULT_GENERATOR == "xoshiro" else ""),
         "config": {"workload": "GPS L1 C/A 32-PRN x +-5 kHz/250 Hz (41 bins) acquisition, 8 Msps complex int8, "
                                "N=8000, 10 x 1 ms non-coherent, per GPU" + ("; all-gather of {max,argmax,sum}[P][D]" if world > 1 else ""),
                    "prns_per_gpu": P, "doppler_bins": D, "fft_size": N, "integrations": M,
@@ -537,7 +542,7 @@ def cpu_model():
     return "unknown"
 
 
-def cfg1_cpu_single_prn(sc, prn):
+def cfg1_cpu_single_prn(sc, prn, reps=3):
     """BASELINE configs[0] as the reference runs it (test_acquisition_with_real_data, do_acquisition.rs:399-466): ONE
     AcquisitionWorker, one thread, 29 Doppler tables, 10 x 16368 samples, early exit — the oracle on this host."""
     from oracle import oracle as O
@@ -546,9 +551,10 @@ def cfg1_cpu_single_prn(sc, prn):
     x = synth.to_c32(sc["x"])
     tables = [O.DopplerShiftTable(sc["f_if"], float(d), sc["fs"], sc["N"]) for d in sc["doppler_hz"]]
     w = O.AcquisitionWorker(prn, sc["N"], sc["fs"], native=True)
-    O.search_all([w], 1, x, tables, 0, sc["M"], n_threads=1, native=True)
+    if reps > 1:
+        O.search_all([w], 1, x, tables, 0, sc["M"], n_threads=1, native=True)
     ts, cells = [], 0
-    for _ in range(3):
+    for _ in range(reps):
         t0 = time.perf_counter()
         res, cells = O.search_all([w], 1, x, tables, 0, sc["M"], n_threads=1, native=True)
         ts.append(time.perf_counter() - t0)
@@ -694,7 +700,16 @@ def cfg1_leg(torch, dev, stream, ca, A, synth, with_cpu=False):
             cpu1 = cfg1_cpu_single_prn(sc, sc["sats"][0]["prn"])
         except Exception as e:
             cpu1 = {"error": repr(e)}
-    return {"single_prn": {"ms_per_dwell": dt1 * 1e3, "cells_per_s": D * N / dt1, "cpu_baseline": cpu1,
+    # a satellite of the scene the GPU did not declare (the weakest ones sit at the reference's threshold of 7): what does the CPU
+    # restatement of the reference decide for it on the same samples?  (The decision is the reference's, not the kernel's.)
+    missed = sorted(set(s["prn"] for s in sc["sats"]) - set(found))
+    missed_cpu = None
+    if with_cpu and missed:
+        try:
+            missed_cpu = {str(p): cfg1_cpu_single_prn(sc, p, reps=1)["found"] for p in missed[:3]}
+        except Exception as e:
+            missed_cpu = {"error": repr(e)}
+    return {"prns_not_declared": missed, "cpu_port_declares_them": missed_cpu, "single_prn": {"ms_per_dwell": dt1 * 1e3, "cells_per_s": D * N / dt1, "cpu_baseline": cpu1,
                            "found_within_3_samples_of_truth": bool(r1 and min((r1["code_phase_samples"] - sc["sats"][0]["code_start"]) % N,
                                                                                 (sc["sats"][0]["code_start"] - r1["code_phase_samples"]) % N) <= 3)},
             "workload": "32 PRN x 29 bins (+-7 kHz / 500 Hz) x 16368 phases, 10 x 1 ms, real int8 (reference test geometry)",

@@ -58,7 +58,22 @@ def build(force=False, verbose=False):
         # exported symbols: exactly the gm_* entry points of include/gnss_mi355x.h
         run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
              "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")])
+    build_synth(force)
     return LIB
+
+
+def build_synth(force=False):
+    """The C++ scene generator of SURVEY §8 d2 (synthgen/synth_xoshiro.cpp, host code, g++): inputs for bench.py and tests.
+    -fno-builtin: g++ otherwise merges cos(th) and sin(th) into one sincos() call, whose results differ from the separate
+    functions' in the last bit now and then (1 of 4001 normals against the Python twin)."""
+    src = os.path.join(HERE, "synthgen", "synth_xoshiro.cpp")
+    lib = os.path.join(LIBDIR, "libgm_synth.so")
+    if force or _stale(lib, [src]):
+        r = subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-fno-builtin", "-o", lib, src],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            raise RuntimeError("g++ failed:\n" + r.stdout)
+    return lib
 
 
 if __name__ == "__main__":

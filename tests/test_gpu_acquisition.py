@@ -191,6 +191,24 @@ def test_cfg2_full_i8(gpu, oracle):
     eng.close()
 
 
+def test_cfg2_scene_of_the_cpp_generator(gpu, oracle):
+    """BASELINE configs[1] on the bytes bench.py times: the scene made by SURVEY §8 d2's C++ generator (xoshiro256**,
+    gnss-sdr-rs_amd/synthgen; digest pinned by tests/test_synth_generator.py).  Same comparison as test_cfg2_full_i8: every
+    worker's Option<AcquisitionResult> against the oracle's, index-exact, and every simulated satellite at its true phase."""
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    t = oracle.ca_code_table()
+    sc = synth.cfg2_scene(t, generator="xoshiro")
+    xi8 = synth.to_i8_iq(sc["x"])
+    eng = A.AcquisitionEngine(sc["fs"], sc["f_if"], sc["N"], doppler_hz=sc["doppler_hz"], n_integrations=sc["M"])
+    tables = _tables(oracle, sc["f_if"], sc["doppler_hz"], sc["fs"], sc["N"])
+    assert _compare_search(eng, oracle, xi8, tables, list(range(1, 33)), sc["N"], sc["fs"], sc["M"]) == len(sc["sats"]) == 8
+    truth = {s["prn"]: s for s in sc["sats"]}
+    for r in eng.search(xi8):
+        if r:
+            assert r["code_phase_samples"] == truth[r["prn"]]["code_start"]
+    eng.close()
+
+
 def test_cfg1_geometry_real_int8(gpu, oracle):
     """BASELINE config 1 geometry (fs 16.3676 MHz, IF 4.1304 MHz, N = 16368, 29 bins, M = 10, real int8)
     on the synthetic stand-in for the missing capture; a subset of PRNs keeps the oracle under a few seconds."""
