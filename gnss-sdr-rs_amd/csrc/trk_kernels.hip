@@ -11,6 +11,9 @@
 //   trk_update_kernel    : one lane per channel sums the slices in a fixed order and runs the
 //       reference's scalar epilogue on-device (phase advances, lock detector, atan PLL / normalised
 //       envelope DLL, loop filters, bookkeeping), so consecutive epochs need no host round trip.
+//   trk_persistent_kernel : the production path — one launch runs up to 4095 passes over all channels (below).
+//   trk_terms_kernel + trk_serial_sum_kernel : gm_trk_cfg.strict_sum_order — every sample's products, then the
+//       reference's own sequential f32 sums by one wave per channel (bit-identical sums; with strict_libm, state).
 //
 // Per-sample arithmetic follows the reference's f32 rounding sequence (compiled with
 // -ffp-contract=off, IEEE division by __fdiv_rn):
@@ -18,8 +21,9 @@
 //   data *= (cos(phase), -sin(phase))          num-complex Mul                          (:234-237)
 //   chip_idx = (code_phase + (i as f32) * (code_rate / fs)) % 1023.0                    (:252)
 //   p/e/l = get_ca_chip(chip_idx {, +0.5, -0.5})                                         (:253-255)
-// cos/sin: the f32 phase (up to ~3e4 rad) is reduced in f64 and evaluated with f64 polynomials,
-// then rounded to f32 (glibc's cosf/sinf, which the reference calls, are likewise < 1 ulp).
+// cos/sin: the f32 phase (up to ~3e4 rad) is reduced in f64 (general path) or by an exact f32 Cody-Waite split (fast path)
+// and evaluated with f32 minimax polynomials: < 1 ulp like glibc's cosf/sinf, which the reference calls, but not the same
+// bits on a quarter of the arguments; gm_trk_cfg.strict_libm switches to gm_libm.h's restatement of glibc's own algorithm.
 // Sums: the reference adds sequentially in f32; here each lane adds its strided samples in order
 // and lanes/waves/slices combine as a fixed tree (deterministic; closer to the exact sum).
 #include "gm_internal.h"

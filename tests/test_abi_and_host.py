@@ -133,7 +133,9 @@ def test_fft_core_cpu_emulation_of_every_plan():
 
 def test_device_atanf_restatement_matches_host_libm_bit_for_bit():
     """tests/cpu/test_libm.cpp: gm::atanf_glibc (csrc/gm_libm.h, what the tracking epilogue runs on the device for
-    f32::atan of do_tracking.rs:280) equals this host's atanf on 8.7e7 arguments, bit for bit."""
+    f32::atan of do_tracking.rs:280) equals this host's atanf on 8.7e7 arguments, bit for bit; gm::sincosf_glibc (what
+    gm_trk_cfg.strict_libm runs for `phase.cos()` / `phase.sin()`, :234-235) equals this host's sinf AND cosf on 1.0e8
+    arguments (every 127th bit pattern, the carrier's operating range, the range boundaries), bit for bit."""
     import subprocess
     import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -142,6 +144,10 @@ def test_device_atanf_restatement_matches_host_libm_bit_for_bit():
                     os.path.join(root, "tests", "cpu", "test_libm.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
+    assert "sincosf_glibc:" in r.stdout and "atanf_glibc:" in r.stdout
+    for line in r.stdout.splitlines():
+        if "mismatches" in line:
+            assert " 0 mismatches" in line, line
 
 
 def test_rust_binding_source_matches_the_abi(gm):
