@@ -535,3 +535,40 @@ def test_strict_modes_other_paths_bit_identical(gpu, oracle):
         lambda i: oracle.TrackingChannel(i, fs, code_index_mode=1, n_arms=5, el_space=0.25, vel_space=0.6, boc11=True, codes=codes,
                                          code_rate=rate), 5, E)
     mgr.close(); ring.close()
+
+
+def test_strict_sum_order_reports_a_code_period_beyond_its_streams(gpu, oracle):
+    """strict_sum_order sizes its per-sample product streams for the nominal code period + 1 %.  A channel whose code rate
+    has been set 10 % low (n = 8889 samples against streams of 8144) must be REPORTED — GM_ERR_OUT_OF_RANGE from the call —
+    not skipped silently; a handle with the right nominal rate runs the same state, equal to the oracle's bit for bit."""
+    from gnss_sdr_rs_amd import tracking as T, synth, _lib
+    fs, E = 8.0e6, 3
+    t = oracle.ca_code_table()
+    sc = synth.tracking_scene(t, fs, 0.0, [7], E + 3, config_id=63, cn0=50.0)
+    x = synth.to_c32(sc["x"])
+    ring, oring = T.MulticastRingBuffer(1 << 16), oracle.MulticastRingBuffer(1 << 16)
+    ring.write_samples(x[:40000]); oring.write_samples(x[:40000])
+    s = sc["sats"][0]
+    r0 = _acq_result(s["prn"], s["doppler_hz"] + 5.0, fs, s["code_start"])
+    slow = 1.023e6 * 0.9
+    mgr = T.TrackingManager(fs, n_channels=1, code_index_mode=1, strict_libm=True, strict_sum_order=True)
+    mgr.channels[0].start(r0)
+    mgr.channels[0].set_state(code_rate=slow)
+    with pytest.raises(_lib.GmError) as ei:
+        mgr.update_all(ring, 1)
+    assert ei.value.status == -5, ei.value            # GM_ERR_OUT_OF_RANGE
+    mgr.close()
+    ok = T.TrackingManager(fs, n_channels=1, code_index_mode=1, strict_libm=True, strict_sum_order=True, nominal_code_rate=slow)
+    ok.channels[0].start(r0)
+    ok.channels[0].set_state(code_rate=slow)
+    oc = oracle.TrackingChannel(0, fs, code_index_mode=1)
+    oc.start(r0)
+    oc.c.code_rate = slow
+    outs, proc, lost, done = ok.update_all(ring, E)
+    assert done == E and proc.all()
+    for ep in range(E):
+        rc, exp, _ = oc.update_ex(oring)
+        assert rc != 0 and oc.c.num_samples_per_code in (8888, 8889, 8890)
+        assert np.array_equal(np.ascontiguousarray(outs[ep, 0, :6], np.float32).view(np.uint32), np.asarray(exp[:6], np.float32).view(np.uint32))
+    assert ok.channels[0].state.next_sample_index == oc.c.next_sample_index
+    ok.close(); ring.close()
