@@ -572,3 +572,29 @@ def test_strict_sum_order_reports_a_code_period_beyond_its_streams(gpu, oracle):
         assert np.array_equal(np.ascontiguousarray(outs[ep, 0, :6], np.float32).view(np.uint32), np.asarray(exp[:6], np.float32).view(np.uint32))
     assert ok.channels[0].state.next_sample_index == oc.c.next_sample_index
     ok.close(); ring.close()
+
+
+def test_strict_modes_cfg5_full_shape_bit_identical(gpu, oracle):
+    """BASELINE configs[4] at its full shape — 36 channels x 50 Msps, 4092-chip code, BOC(1,1), VE/E/P/L/VL, n = 200 000 samples
+    per period (288 MB of per-sample products per pass) — with both strict switches: three code periods free-running, every
+    one of the 36 x 3 x 10 sums and every state word equal to the generalised oracle's bit for bit."""
+    from gnss_sdr_rs_amd import tracking as T
+    fs, L, rate, C, E = 50.0e6, 4092, 1.023e6, 36, 3
+    n = 200000
+    rng = np.random.default_rng(55)
+    codes = np.where(rng.integers(0, 2, (C, L)) > 0, 1, -1).astype(np.int8)
+    dopp = rng.uniform(-2000, 2000, C)
+    cstart = rng.integers(0, 5000, C)
+    x = _boc_scene(codes, fs, rate, L, (E + 1) * n, dopp, cstart)
+    ring, oring = T.MulticastRingBuffer(1 << 20), oracle.MulticastRingBuffer(1 << 20)
+    ring.write_samples(x)
+    oring.write_samples(x)
+    mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED, nominal_code_rate=rate, n_arms=5,
+                            early_late_space=0.25, very_early_late_space=0.6, boc11=True, codes=codes, strict_libm=True,
+                            strict_sum_order=True)
+    starts = [_acq_result(c + 1, float(dopp[c]) + 10.0, fs, int(cstart[c])) for c in range(C)]
+    _assert_bit_identical_free_running(
+        mgr, ring, oring, starts,
+        lambda i: oracle.TrackingChannel(i, fs, code_index_mode=1, n_arms=5, el_space=0.25, vel_space=0.6, boc11=True, codes=codes,
+                                         code_rate=rate), 5, E)
+    mgr.close(); ring.close()
