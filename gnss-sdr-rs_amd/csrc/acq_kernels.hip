@@ -54,7 +54,11 @@ __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restri
     auto in = [&](int it, int r) {
         const int idx = (tid + it * PL::T) + r * NB0;
         const cf s = load_sample(samples, fmt, sbase + idx);
+#ifdef GM_LAB_MIX_NOTAB      // timing ablation only (tools/mix_lab)
+        const cf t = cf_make(0.6f, 0.8f);
+#else
         const cf t = tab[idx];
+#endif
         // multiply_simd_block (doppler_shift.rs:43-58): a*c + (b*d*(-1)), a*d + (b*c*(+1))
         return cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);
     };
@@ -83,10 +87,28 @@ __global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restri
             const int k = (tid + it * PL::T) + r * NBL;
             lds[k + (k >> 5)] = val; }, tid);
         __syncthreads();
+#ifdef GM_LAB_MIX_OLDSTORE   // the element-by-element write-out (A/B timing, tools/mix_lab)
         for (int p = tid; p < PL::N; p += PL::T) {
             const int k = order[p];
             dst[p] = lds[k + (k >> 5)];
         }
+#else
+        // two consecutive positions per lane and round: one 4-byte read of the order table, two LDS reads, ONE 16-byte store —
+        // a wave's store covers 1 KB of contiguous spectrum: stage F 25.4 -> 24.2 us (tools/mix_lab, GM_LAB_MIX_OLDSTORE = the
+        // 8-byte form).  The write phase is a burst of D*M*N*8 bytes (26 MB at configs[1]) from every workgroup at once: without
+        // it the kernel takes 17.6 us, which is the latency of ONE transform by a workgroup alone on its CU (the 410 transforms
+        // are a single round); eight positions per lane (64 contiguous bytes, four partial-line stores) was slower: 27.5 us.
+        static_assert(PL::N % 2 == 0, "N must be even");
+        for (int g = tid; g < PL::N / 2; g += PL::T) {
+            const uint32_t o = reinterpret_cast<const uint32_t*>(order)[g];
+            const int k0 = int(o & 0xffffu), k1 = int(o >> 16);
+            const cf v0 = lds[k0 + (k0 >> 5)], v1 = lds[k1 + (k1 >> 5)];
+#ifdef GM_LAB_MIX_NOSTORE    // timing ablation only (tools/mix_lab): no spectrum leaves the workgroup unless it holds a NaN
+            if (v0.x != v0.x || v1.y != v1.y)
+#endif
+            reinterpret_cast<float4*>(dst)[g] = make_float4(v0.x, v0.y, v1.x, v1.y);
+        }
+#endif
     }
 }
 

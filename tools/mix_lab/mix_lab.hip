@@ -1,0 +1,48 @@
+// tools/mix_lab/mix_lab.hip — timing laboratory for stage F (acq_mix_fft_kernel) at BASELINE configs[1] geometry (41 bins x 10
+// integrations of N = 8000, complex int8): the product kernel source included as is, one plan, optional ablation macros
+// (-DGM_LAB_MIX_NOSTORE: the spectrum write-out is skipped unless a value is NaN; -DGM_LAB_MIX_NOTAB: the Doppler table is not
+// read).  Timing only.  Not product code, not a test.
+#ifndef LAB_PLAN
+#define LAB_PLAN gm::Plan8000
+#endif
+#define GM_FOR_EACH_PLAN(X) X(LAB_PLAN)
+#include "../../gnss-sdr-rs_amd/csrc/acq_kernels.hip"
+#include <cstdio>
+#include <vector>
+#include <random>
+#include <algorithm>
+
+int main(int argc, char** argv) {
+    using namespace gm;
+    const int D = argc > 1 ? atoi(argv[1]) : 41, M = argc > 2 ? atoi(argv[2]) : 10;
+    const PlanOps* pl = &g_plans[0];
+    const int N = pl->n;
+    std::mt19937 rng(1);
+    std::vector<int8_t> hs(size_t(M) * N * 2);
+    for (auto& v : hs) v = int8_t(int(rng() % 255) - 127);
+    std::vector<cf> ht(size_t(D) * N), htw(pl->tw_total + 1);
+    for (size_t i = 0; i < ht.size(); ++i) { const float a = 1e-3f * float(i % 6283); ht[i] = cf_make(cosf(a), sinf(a)); }
+    pl->fill_tw(htw.data(), false);
+    const int no = pl->fill_order(nullptr);
+    std::vector<uint16_t> ho(no > 0 ? no : 1);
+    if (no > 0) pl->fill_order(ho.data());
+    int8_t* ds; cf *dt, *dtw, *dsp; uint16_t* dord;
+    hipMalloc(&ds, hs.size()); hipMalloc(&dt, ht.size() * 8); hipMalloc(&dtw, htw.size() * 8);
+    hipMalloc(&dsp, size_t(D) * M * N * 8); hipMalloc(&dord, ho.size() * 2);
+    hipMemcpy(ds, hs.data(), hs.size(), hipMemcpyHostToDevice);
+    hipMemcpy(dt, ht.data(), ht.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dtw, htw.data(), htw.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dord, ho.data(), ho.size() * 2, hipMemcpyHostToDevice);
+    auto go = [&]() { pl->mix_fft(0, ds, GM_FMT_I8_IQ, dt, dtw, dsp, D, M, nullptr, no > 0 ? dord : nullptr); };
+    for (int i = 0; i < 3; ++i) go();
+    hipDeviceSynchronize();
+    std::vector<float> t;
+    for (int rep = 0; rep < 25; ++rep) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, 0); go(); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); t.push_back(ms * 1e3f);
+    }
+    std::sort(t.begin(), t.end());
+    printf("stage F N=%d D=%d M=%d: median %.1f us, min %.1f us per launch\n", N, D, M, t[t.size() / 2], t[0]);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
