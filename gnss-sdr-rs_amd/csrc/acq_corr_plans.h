@@ -3,6 +3,18 @@
 #pragma once
 namespace gm {
 template <class PL> struct CorrPlanOf;
+// Stage F's forward transform may run on a plan of its own (same N): the stage is ONE round of D*M workgroups, i.e. bound by the
+// latency of a single transform, where a plan of more, smaller passes on more lanes wins — the opposite of what the
+// throughput-bound inverse in acq_corr_kernel wants.
+template <class PL> struct MixPlanOf { using type = PL; };
+#ifndef GM_NO_MIX_PLAN
+// stage F at N = 8000: four passes of radix 5 / 8 / 10 / 20 on 1024 lanes (56 VGPRs, 67.5 KB: two workgroups per CU) — 18.1 us per
+// 410-transform launch against 23.2 for [25, 20, 16] on 512 lanes (tools/mix_lab; [8,10,10,10]: 18.7, [16,25,20] on 512: 20.1)
+template <> struct MixPlanOf<Plan<8000, 512, 25, 20, 16>> { using type = Plan<8000, 1024, 5, 8, 10, 20>; };
+// N = 16368 (one workgroup per CU either way: 290 transforms are two rounds): radix 16 first on 1024 lanes — every lane loads in
+// pass 0 — 45.7 us against 57.4 for [33, 16, 31] on 768 lanes ([16,3,11,31]: 47.8, [11,3,16,31]: 51.6)
+template <> struct MixPlanOf<Plan<16368, 768, 33, 16, 31>> { using type = Plan<16368, 1024, 16, 33, 31>; };
+#endif
 #ifndef GM_NO_HYBRID_PLANS
 using CorrPlan8000 = HybridPlan<8000, 512, 5, 25, 4, 16>;     // 125 * 64: passes of radix 20 / 25 / 16
 template <> struct CorrPlanOf<Plan8000> { using type = CorrPlan8000; };

@@ -24,15 +24,19 @@
 namespace gm {
 
 // ------------------------------------------------------------------------------------ stage F
-template <class PL>
-__global__ __launch_bounds__(PL::T) void acq_mix_fft_kernel(const void* __restrict__ samples, int fmt,
+template <class PLX>
+__global__ __launch_bounds__(MixPlanOf<PLX>::type::T) void acq_mix_fft_kernel(const void* __restrict__ samples, int fmt,
                                                             const cf* __restrict__ tables,
                                                             const cf* __restrict__ tw_fwd,
                                                             cf* __restrict__ spectra, int n_int,
                                                             uint32_t* __restrict__ clear_tickets,
                                                             const uint16_t* __restrict__ order) {
+    // PLX: the size's registered plan (its correlation plan CP fixes the stored order); PL: the plan the FORWARD transform runs
+    // on (MixPlanOf, acq_device.h) — `tw_fwd` is PL's base-twiddle table (PlanOps::fill_tw_mix)
     // (permuted storage orders stage the outputs through LDS, one padding element per 32: see below)
-    using CP = typename CorrPlanOf<PL>::type;
+    using PL = typename MixPlanOf<PLX>::type;
+    using CP = typename CorrPlanOf<PLX>::type;
+    static_assert(PL::N == PLX::N, "the mix plan keeps the size");
     constexpr bool PERMUTED = CorrMode<CP>::PERMUTED;
     constexpr int STAGE = PERMUTED ? PL::N + PL::N / 32 + 1 : 0;
     constexpr int LDS_N = PL::LDS_ELEMS + PL::TW_TOTAL > STAGE ? PL::LDS_ELEMS + PL::TW_TOTAL : STAGE;
@@ -710,9 +714,13 @@ template <class PL> struct Launch {
     }
     using CP = typename CorrPlanOf<PL>::type;      // the plan acq_corr_kernel's inverse runs on (acq_device.h)
     static_assert(CP::T == PL::T && CP::N == PL::N, "the correlation plan keeps the size and the workgroup");
+    using MP = typename MixPlanOf<PL>::type;       // the plan stage F's forward transform runs on (tw_fwd: ITS table, fill_tw_mix)
+    static void fill_tw_mix(cf* tw, bool inverse) {
+        fill_twiddles<MP>(tw, inverse, [](double a) { return ::cos(a); }, [](double a) { return ::sin(a); });
+    }
     static void mix_fft(hipStream_t st, const void* samples, int fmt, const cf* tables, const cf* tw_fwd,
                         cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets, const uint16_t* order) {
-        hipLaunchKernelGGL(acq_mix_fft_kernel<PL>, dim3(n_bins * n_int), dim3(PL::T), 0, st, samples, fmt,
+        hipLaunchKernelGGL(acq_mix_fft_kernel<PL>, dim3(n_bins * n_int), dim3(MP::T), 0, st, samples, fmt,
                            tables, tw_fwd, spectra, n_int, clear_tickets, order);
     }
     static int fill_order(uint16_t* order) { return fill_order_table<CP>(order); }
@@ -823,7 +831,7 @@ template <class PL> struct Launch {
                        CorrLayout<CP>::RELAYOUT ? 1 : 0,
                        &fill_tw, &fill_order, &mix_fft, &corr, &code_fft, &pair_codes, &fft_batch,
                        POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr, FineRows<PL>::RT,
-                       POW2 ? &big_cols : nullptr, POW2 ? &big_rows : nullptr};
+                       POW2 ? &big_cols : nullptr, POW2 ? &big_rows : nullptr, MP::TW_TOTAL, &fill_tw_mix};
     }
 };
 

@@ -207,6 +207,7 @@ struct gm_acq {
     float code_rate = CA_RATE;
     std::vector<float> table_freq;
     std::vector<uint8_t> prn_ids, dev_prn_ids;
+    cf* d_tw_mix = nullptr;       // forward base twiddles of stage F's own plan (PlanOps::fill_tw_mix)
     cf *d_tables = nullptr, *d_tw_fwd = nullptr, *d_tw_inv = nullptr, *d_code_fft = nullptr, *d_spectra = nullptr;
     cf* d_code_fft_paired = nullptr;   // Q == 1: the code spectra in the layout acq_corr_kernel reads (PairLayout)
     uint16_t* d_order = nullptr;       // Q == 1, permuted storage orders: element index stored at each position (PlanOps::fill_order)
@@ -527,6 +528,7 @@ int gm_acq_destroy(gm_acq* a) {
     hipFree(a->fine.d_rowmax); hipFree(a->fine.d_rowarg); hipFree(a->fine.d_sat_worker); hipFree(a->fine.d_sat_cp);
     hipFree(a->fine.d_peak_pow); hipFree(a->fine.d_peak_idx);
     if (a->device >= 0) hipSetDevice(a->device);
+    hipFree(a->d_tw_mix);
     hipFree(a->d_tables); hipFree(a->d_tw_fwd); hipFree(a->d_tw_inv); hipFree(a->d_code_fft); hipFree(a->d_code_fft_paired); hipFree(a->d_order);
     hipFree(a->d_spectra); hipFree(a->d_table_freq); hipFree(a->d_code_samples); hipFree(a->d_samples);
     hipFree(a->d_metrics); hipFree(a->d_worker_list); hipFree(a->d_results); hipFree(a->d_found);
@@ -604,6 +606,8 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     std::vector<cf> twf(size_t(pl->tw_total) + 1), twi(size_t(pl->tw_total) + 1);
     pl->fill_tw(twf.data(), false);
     pl->fill_tw(twi.data(), true);
+    std::vector<cf> twm(size_t(pl->tw_total_mix) + 1);
+    pl->fill_tw_mix(twm.data(), false);
 
 #define HIPA(expr)                                                     \
     do {                                                               \
@@ -616,6 +620,7 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     HIPA(hipMalloc(&a->d_table_freq, D * 4));
     HIPA(hipMalloc(&a->d_tw_fwd, twf.size() * 8));
     HIPA(hipMalloc(&a->d_tw_inv, twi.size() * 8));
+    HIPA(hipMalloc(&a->d_tw_mix, twm.size() * 8));
     HIPA(hipMalloc(&a->d_code_samples, P * N));
     HIPA(hipMalloc(&a->d_code_fft, P * N * 8));
     HIPA(hipMalloc(&a->d_spectra, D * M * N * 8));
@@ -633,6 +638,7 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     HIPA(hipMemcpy(a->d_table_freq, a->table_freq.data(), D * 4, hipMemcpyHostToDevice));
     HIPA(hipMemcpy(a->d_tw_fwd, twf.data(), twf.size() * 8, hipMemcpyHostToDevice));
     HIPA(hipMemcpy(a->d_tw_inv, twi.data(), twi.size() * 8, hipMemcpyHostToDevice));
+    HIPA(hipMemcpy(a->d_tw_mix, twm.data(), twm.size() * 8, hipMemcpyHostToDevice));
     HIPA(hipMemcpy(a->d_code_samples, code_samples.data(), P * N, hipMemcpyHostToDevice));
     if ((rc = acq_reserve_results(a, uint32_t(P)))) return fail(rc);
     HIPA(hipMemcpy(a->d_prn_ids, a->prn_ids.data(), P, hipMemcpyHostToDevice));
@@ -698,7 +704,7 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     hipEvent_t* ev = t ? &a->tm.ev[size_t(a->tm.count % Timing::CAP) * 4] : nullptr;
     if (t) HIPC(hipEventRecord(ev[0], a->stream));
     if (a->Q == 1) {
-        a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_fwd, a->d_spectra, int(a->D), int(a->M), a->d_split_counter, a->d_order);
+        a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_mix, a->d_spectra, int(a->D), int(a->M), a->d_split_counter, a->d_order);
     } else {
         a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_fwd, a->d_comp_tmp, a->D * a->M, a->M, a->d_order);
         a->comp->fwd_post(a->stream, a->d_comp_tmp, a->d_spectra, a->D * a->M, 1, a->d_order);

@@ -61,6 +61,9 @@ struct PlanOps {
     // long power-of-two FFT, four-step (power-of-two plans only, else null): columns x -> B[n2][k1] (twiddled), rows B -> X natural
     void (*big_cols)(hipStream_t, const cf* x, cf* B, const cf* tw, uint32_t n2, int inverse);
     void (*big_rows)(hipStream_t, const cf* B, cf* X, const cf* tw, uint32_t n1, int inverse);
+    // stage F's forward transform may run on a plan of its own (MixPlanOf, acq_device.h): ITS base-twiddle table is what mix_fft takes
+    int tw_total_mix;
+    void (*fill_tw_mix)(cf* tw, bool inverse);
 };
 // mean of the snapshot (finer_doppler :236) and the final per-satellite reduction over the rows
 void launch_fine_mean(hipStream_t, const void* samples, int fmt, uint32_t n, float* d_mean);

@@ -139,6 +139,13 @@ int main() {
 #define RUN(PL) worst = std::fmax(worst, run_plan<PL, false>(#PL)); worst = std::fmax(worst, run_plan<PL, true>(#PL)); \
     if constexpr (PL::COPRIME) { worst = std::fmax(worst, run_plan<PL, false, true>(#PL)); worst = std::fmax(worst, run_plan<PL, true, true>(#PL)); }
     GM_FOR_EACH_PLAN(RUN)
+    {   // stage F's own forward plan at N = 8000 (MixPlanOf, acq_corr_plans.h): four passes on 1024 lanes
+        using MixPlan8000 = gm::MixPlanOf<gm::Plan8000>::type;
+        worst = std::fmax(worst, run_plan<MixPlan8000, false>("MixPlanOf<Plan8000>"));
+        worst = std::fmax(worst, run_plan<MixPlan8000, true>("MixPlanOf<Plan8000>"));
+        using MixPlan16368 = gm::MixPlanOf<gm::Plan16368>::type;
+        worst = std::fmax(worst, run_plan<MixPlan16368, false>("MixPlanOf<Plan16368>"));
+    }
     std::printf("worst %.3e\n", worst);
     return worst < 7e-7 ? 0 : 1;   // f32 FFT rounding of the largest plans; parity tolerances downstream are 1e-5
 }

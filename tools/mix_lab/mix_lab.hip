@@ -20,9 +20,9 @@ int main(int argc, char** argv) {
     std::mt19937 rng(1);
     std::vector<int8_t> hs(size_t(M) * N * 2);
     for (auto& v : hs) v = int8_t(int(rng() % 255) - 127);
-    std::vector<cf> ht(size_t(D) * N), htw(pl->tw_total + 1);
+    std::vector<cf> ht(size_t(D) * N), htw(pl->tw_total_mix + 1);
     for (size_t i = 0; i < ht.size(); ++i) { const float a = 1e-3f * float(i % 6283); ht[i] = cf_make(cosf(a), sinf(a)); }
-    pl->fill_tw(htw.data(), false);
+    pl->fill_tw_mix(htw.data(), false);
     const int no = pl->fill_order(nullptr);
     std::vector<uint16_t> ho(no > 0 ? no : 1);
     if (no > 0) pl->fill_order(ho.data());
