@@ -40,16 +40,19 @@ __device__ __forceinline__ cf unit_root(uint32_t t, uint32_t n, bool inverse) {
 // ------------------------------------------------------------------------------------ forward, step 1
 // grid n_items * Q: item = (d, m) for the signal (tables != null: apply_doppler_shift fused, doppler_shift.rs:43-58, same
 // products) or a code index for the replicas (int8 chips, :134); n1 = blockIdx % Q.  A[item][n1][k2], natural order.
-template <class PL>
-__global__ __launch_bounds__(PL::T) void comp_fwd_sub_kernel(const void* __restrict__ samples, int fmt,
+template <class PLX>
+__global__ __launch_bounds__(MixPlanOf<PLX>::type::T) void comp_fwd_sub_kernel(const void* __restrict__ samples, int fmt,
                                                              const cf* __restrict__ tables,
                                                              const int8_t* __restrict__ code_samples,
                                                              const cf* __restrict__ tw_fwd, cf* __restrict__ A,
                                                              uint32_t Q, uint32_t n_int, const uint16_t* __restrict__ order) {
     // order != null (base sizes whose correlation plan reads a permuted spectrum): the sub-transform leaves in STORAGE order —
     // A[item][n1][p] holds element order[p] — staged through the LDS buffer like stage F (acq_kernels.hip), so that
-    // comp_fwd_post_kernel reads and writes position by position, coalesced
-    constexpr int STAGE = CorrMode<typename CompPlanOf<PL>::type>::PERMUTED ? PL::N + PL::N / 32 + 1 : 0;
+    // comp_fwd_post_kernel reads and writes position by position, coalesced.
+    // PLX: the base size's registered plan; PL: the plan the forward sub-transform runs on (MixPlanOf: like stage F this is one
+    // round of latency-bound workgroups) — `tw_fwd` is PL's table (PlanOps::fill_tw_mix)
+    using PL = typename MixPlanOf<PLX>::type;
+    constexpr int STAGE = CorrMode<typename CompPlanOf<PLX>::type>::PERMUTED ? PL::N + PL::N / 32 + 1 : 0;
     constexpr int LDS_N = PL::LDS_ELEMS + PL::TW_TOTAL > STAGE ? PL::LDS_ELEMS + PL::TW_TOTAL : STAGE;
     __shared__ cf lds[LDS_N];
     cf* tw = lds + PL::LDS_ELEMS;
@@ -293,7 +296,7 @@ template <class PL, uint32_t Q> struct CompLaunch {
     }
     static void fwd_sub(hipStream_t st, const void* samples, int fmt, const cf* tables, const int8_t* code_samples,
                         const cf* tw_fwd, cf* A, uint32_t n_items, uint32_t n_int, const uint16_t* order) {
-        hipLaunchKernelGGL(comp_fwd_sub_kernel<PL>, dim3(n_items * Q), dim3(PL::T), 0, st, samples, fmt, tables, code_samples,
+        hipLaunchKernelGGL(comp_fwd_sub_kernel<PL>, dim3(n_items * Q), dim3(MixPlanOf<PL>::type::T), 0, st, samples, fmt, tables, code_samples,
                            tw_fwd, A, Q, n_int, order);
     }
     static void fwd_post(hipStream_t st, const cf* A, cf* X, uint32_t n_items, int paired, const uint16_t* order) {

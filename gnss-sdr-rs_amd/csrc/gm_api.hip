@@ -663,7 +663,7 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
         std::vector<gm::cf> twn(N);
         comp->fill_twn(twn.data());
         HIPA(hipMemcpy(a->d_comp_twn, twn.data(), N * 8, hipMemcpyHostToDevice));
-        comp->fwd_sub(a->stream, nullptr, GM_FMT_C32, nullptr, a->d_code_samples, a->d_tw_fwd, a->d_comp_tmp, uint32_t(P), 1, nullptr);
+        comp->fwd_sub(a->stream, nullptr, GM_FMT_C32, nullptr, a->d_code_samples, a->d_tw_mix, a->d_comp_tmp, uint32_t(P), 1, nullptr);
         comp->fwd_post(a->stream, a->d_comp_tmp, a->d_code_fft, uint32_t(P), 0, nullptr);
         comp->relayout(a->stream, a->d_code_fft, a->d_code_fft_paired, int(P * a->Q));
         HIPA(hipMalloc(&a->d_code_comb, P * a->Q * N * 8));      // [code][n1][k1][pos]: the whole code-side factor per sub-transform
@@ -706,7 +706,7 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     if (a->Q == 1) {
         a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_mix, a->d_spectra, int(a->D), int(a->M), a->d_split_counter, a->d_order);
     } else {
-        a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_fwd, a->d_comp_tmp, a->D * a->M, a->M, a->d_order);
+        a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_mix, a->d_comp_tmp, a->D * a->M, a->M, a->d_order);
         a->comp->fwd_post(a->stream, a->d_comp_tmp, a->d_spectra, a->D * a->M, 1, a->d_order);
     }
     if (t) HIPC(hipEventRecord(ev[1], a->stream));

@@ -143,6 +143,8 @@ int main() {
         using MixPlan8000 = gm::MixPlanOf<gm::Plan8000>::type;
         worst = std::fmax(worst, run_plan<MixPlan8000, false>("MixPlanOf<Plan8000>"));
         worst = std::fmax(worst, run_plan<MixPlan8000, true>("MixPlanOf<Plan8000>"));
+        using MixPlan16000 = gm::MixPlanOf<gm::Plan16000>::type;
+        worst = std::fmax(worst, run_plan<MixPlan16000, false>("MixPlanOf<Plan16000>"));
         using MixPlan16368 = gm::MixPlanOf<gm::Plan16368>::type;
         worst = std::fmax(worst, run_plan<MixPlan16368, false>("MixPlanOf<Plan16368>"));
     }
