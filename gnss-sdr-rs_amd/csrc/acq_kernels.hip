@@ -902,14 +902,39 @@ __global__ __launch_bounds__(64) void decide_kernel(DecideArgs a) {
     uint32_t bphase = 0;
     int bbin = -1;
     bool pass = false;
+    float carry_v = 0.0f;                                  // (prefix-scan form) the running best at the end of the previous 64 bins
+    int carry_b = -1;
     for (int d0 = 0; d0 < D; d0 += 64) {                   // D <= 64 in practice: one trip
         const int d = d0 + lane;
         if (d0 > 0) { gmax = 0.0f; bsum = 0.0f; bphase = 0; bbin = -1; }
+#ifdef GM_DECIDE_SERIAL_SCAN      // the scan as it was: every lane walks smax[0..d] out of LDS (41 dependent round trips: ~2 us)
         if (d < D && searched) {
             for (int q = 0; q <= d; ++q) {
                 const float lm = smax[q];
                 if (lm > gmax) { gmax = lm; bphase = sarg[q]; bsum = ssum[q]; bbin = q; }
             }
+        }
+#else
+        // running best THROUGH bin d as a wave prefix scan of (value, bin) with the reference's comparison — a later bin replaces
+        // the running best only if strictly larger (:195-202), the start value 0.0 never loses to a non-positive or NaN maximum —
+        // six shuffle steps instead of d + 1 dependent LDS reads
+        {
+            const float own = (d < D) ? smax[d] : 0.0f;
+            gmax = own > 0.0f ? own : 0.0f;
+            bbin = own > 0.0f ? d : -1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float ev = __shfl_up(gmax, off, 64);      // the running best of the lanes before
+                const int eb = __shfl_up(bbin, off, 64);
+                if (lane >= off && !(gmax > ev)) { gmax = ev; bbin = eb; }
+            }
+            if (d0 > 0 && !(gmax > carry_v)) { gmax = carry_v; bbin = carry_b; }     // D > 64: the best through bin d0 - 1
+            carry_v = __shfl(gmax, 63, 64); carry_b = __shfl(bbin, 63, 64);
+            bphase = bbin >= 0 ? sarg[bbin] : 0u;
+            bsum = bbin >= 0 ? ssum[bbin] : 0.0f;
+        }
+#endif
+        if (d < D && searched) {
             if (!a.best_bin_mode || d + 1 == D) {          // strongest-bin mode: test once, after the last bin
                 const float avg = __fdiv_rn(bsum - gmax, float(a.fft_size - 1));   // (sum - max) / (N-1)  (:236)
                 pass = __fdiv_rn(gmax, avg) > a.threshold;                          // max/avg > 7.0       (:237)

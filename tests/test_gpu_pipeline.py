@@ -141,3 +141,44 @@ def test_full_chain_frontend_to_nav_bits(gpu, oracle):
     start = next(k for k in range(data.size - bits.size + 1) if (data[k:k + bits.size] == st["polarity"] * bits).all())
     assert start > 50
     mgr.close(); eng.close(); fe.close(); ring.close()
+
+
+def test_decision_over_more_than_64_doppler_bins(gpu, oracle):
+    """decide_kernel forms the reference's running best (first strict maximum, do_acquisition.rs:195-202) as a wave prefix scan,
+    64 bins per trip with a carry between trips: 151 bins (three trips), satellites whose first passing bin lies in the
+    first, second and third trip, one absent code, both decision modes.  Every Option<AcquisitionResult> must equal the oracle's
+    decision replayed on the DEVICE's own metrics (orc_decide_from_metrics: the sequential scan as the reference writes it)."""
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    t = oracle.ca_code_table()
+    fs, N, M = 2.048e6, 2048, 3
+    dop = np.arange(-3750.0, 3750.1, 50.0, dtype=np.float32)
+    assert dop.size == 151
+    sats = [dict(prn_row=2, cn0_dbhz=52.0, doppler_hz=-3100.0, code_start=100),      # passes inside the first 64 bins
+            dict(prn_row=11, cn0_dbhz=50.0, doppler_hz=600.0, code_start=1500),      # ... in the second trip (bin 87)
+            dict(prn_row=25, cn0_dbhz=50.0, doppler_hz=3700.0, code_start=9)]        # ... in the third (its lobe starts beyond bin 128)
+    x = synth.to_c32(synth.make_scene(t, fs, 0.0, M * N, sats, config_id=64))
+    prns = [3, 12, 26, 30]
+    for mode in (0, 1):
+        eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=prns, n_integrations=M, decision_mode=mode)
+        res = eng.search(x, local_tail=777)
+        mx, am, sm = eng.metrics()
+        trips = set()
+        for i, prn in enumerate(prns):
+            if mode == 0:
+                exp = oracle.decide_from_metrics(mx[i], am[i], sm[i], dop, N, prn, fs, 777)
+            else:      # strongest bin, tested once
+                b = int(np.argmax(mx[i]))
+                avg = (np.float32(sm[i, b]) - np.float32(mx[i, b])) / np.float32(N - 1)
+                exp = dict(doppler_bin=b, code_phase_samples=int(am[i, b])) if np.float32(mx[i, b]) / avg > np.float32(7.0) else None
+            got = res[i]
+            assert (got is None) == (exp is None), (mode, prn, got, exp)
+            if exp:
+                assert got["code_phase_samples"] == exp["code_phase_samples"], (mode, prn)
+                if mode == 0:
+                    assert got["carrier_freq"] == exp["carrier_freq"] and got["mag_relative"] == exp["mag_relative"]
+                    assert got["sample_global_index"] == exp["sample_global_index"]
+                else:
+                    assert got["doppler_bin"] == exp["doppler_bin"]
+                trips.add(got["doppler_bin"] // 64)
+        assert res[3] is None and trips == {0, 1, 2}, (mode, trips)
+        eng.close()
