@@ -471,10 +471,10 @@ __global__ __launch_bounds__(256) void trk_correlate_kernel(TrkDevCfg cfg, const
 // the carrier's cos / sin are glibc's (strict_libm).  With the switch on an epoch is three launches instead of the
 // persistent kernel's loop: trk_terms_kernel — every sample's products (the same correlate_sample as everywhere else, on a
 // zeroed accumulator: x * (+-1) is exact), stored as one contiguous stream per sum; trk_serial_sum_kernel — ONE wave per
-// channel, lane k walks stream k from sample 0 to n - 1 (n dependent f32 adds, ~8 cycles each: ~95 us at n = 25 000, all
+// channel, lane k walks stream k from sample 0 to n - 1 (n dependent f32 adds, ~10 cycles each: ~110 us at n = 25 000, all
 // channels side by side), the streams staged through LDS by the workgroup's other three waves; trk_update_kernel — the
 // scalar epilogue as before.  The sums, and with strict_libm every word of the channel state, then equal the reference's
-// bit for bit, free-running, for as many epochs as one likes (tests/test_gpu_tracking_shapes.py).  ~35x the persistent
+// bit for bit, free-running, for as many epochs as one likes (tests/test_gpu_tracking_shapes.py).  ~40x the persistent
 // kernel's time per epoch at BASELINE configs[2]: a parity switch, not the production path.
 template <int ARMS>
 __global__ __launch_bounds__(256) void trk_terms_kernel(TrkDevCfg cfg, const int8_t* __restrict__ codes,
@@ -570,17 +570,31 @@ __global__ __launch_bounds__(256) void trk_serial_sum_kernel(TrkDevCfg cfg, cons
         else if (tid < NV) {                                               // lane k: sum k, sample by sample
             const float4* srcp = stage4 + size_t(c & 1u) * (NV * CH / 4) + tid * (CH / 4);
             const uint32_t s0 = c * CH, cnt = n - s0 < uint32_t(CH) ? n - s0 : uint32_t(CH);
-            const uint32_t full = cnt / 16;                                // batches of 16 samples, the next batch's LDS reads
-            float4 a0, a1, a2, a3;                                         // issued before the current batch's 16 dependent adds
+            // batches of 16 samples in TWO named register sets: while the 16 dependent adds of one set issue, the other set's
+            // four LDS reads are in flight (written as a copy `b = a` the compiler turned the hand-over into 16 v_mov per
+            // batch and waited for every read right behind its issue: 8.5 ns per add)
+            const uint32_t full = cnt / 16;
+#define GM_ADD16(q0, q1, q2, q3)                                                                     \
+            acc = acc + q0.x; acc = acc + q0.y; acc = acc + q0.z; acc = acc + q0.w;                  \
+            acc = acc + q1.x; acc = acc + q1.y; acc = acc + q1.z; acc = acc + q1.w;                  \
+            acc = acc + q2.x; acc = acc + q2.y; acc = acc + q2.z; acc = acc + q2.w;                  \
+            acc = acc + q3.x; acc = acc + q3.y; acc = acc + q3.z; acc = acc + q3.w      /* i_p += re * p_chip, in sample order */
+            float4 a0, a1, a2, a3, b0, b1, b2, b3;
             if (full) { a0 = srcp[0]; a1 = srcp[1]; a2 = srcp[2]; a3 = srcp[3]; }
-            for (uint32_t bt = 0; bt < full; ++bt) {
-                const float4 b0 = a0, b1 = a1, b2 = a2, b3 = a3;
-                if (bt + 1 < full) { a0 = srcp[4 * bt + 4]; a1 = srcp[4 * bt + 5]; a2 = srcp[4 * bt + 6]; a3 = srcp[4 * bt + 7]; }
-                acc = acc + b0.x; acc = acc + b0.y; acc = acc + b0.z; acc = acc + b0.w;      // i_p += re * p_chip, in sample order
-                acc = acc + b1.x; acc = acc + b1.y; acc = acc + b1.z; acc = acc + b1.w;
-                acc = acc + b2.x; acc = acc + b2.y; acc = acc + b2.z; acc = acc + b2.w;
-                acc = acc + b3.x; acc = acc + b3.y; acc = acc + b3.z; acc = acc + b3.w;
+            uint32_t bt = 0;
+            for (; bt + 2 <= full; bt += 2) {
+                b0 = srcp[4 * bt + 4]; b1 = srcp[4 * bt + 5]; b2 = srcp[4 * bt + 6]; b3 = srcp[4 * bt + 7];
+                __builtin_amdgcn_sched_barrier(0);                      // the reads stay IN FRONT of the other set's adds
+                GM_ADD16(a0, a1, a2, a3);
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t nx = bt + 2 < full ? bt + 2 : bt;       // unconditional (a re-read of batch bt past the end, unused): a
+                a0 = srcp[4 * nx]; a1 = srcp[4 * nx + 1]; a2 = srcp[4 * nx + 2]; a3 = srcp[4 * nx + 3];   // conditional load made the
+                __builtin_amdgcn_sched_barrier(0);                      // compiler merge the two sets with 32 v_mov per round
+                GM_ADD16(b0, b1, b2, b3);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (bt < full) { GM_ADD16(a0, a1, a2, a3); }             // an odd batch is left in the first set
+#undef GM_ADD16
             const float* tail = reinterpret_cast<const float*>(srcp);
             for (uint32_t j = full * 16; j < cnt; ++j) acc = acc + tail[j];
         }

@@ -345,7 +345,7 @@ typedef struct {
                                   samples.  ABI version 4. */
     int32_t strict_sum_order;  /* 1: the correlator sums are added sample by sample in f32, the reference's own order
                                   (`i_p += re * p_chip`, :256-262) — one serial wave per channel instead of the persistent
-                                  kernel's tree (csrc/trk_kernels.hip trk_serial_sum_kernel; ~35x its time per epoch).  With
+                                  kernel's tree (csrc/trk_kernels.hip trk_serial_sum_kernel; ~40x its time per epoch).  With
                                   strict_libm as well, every correlator sum and every word of the channel state equal the
                                   reference's bit for bit, free-running.  0 (default): tree sums, within 1e-5 of the
                                   envelope and closer to the exact sum.  ABI version 4. */
