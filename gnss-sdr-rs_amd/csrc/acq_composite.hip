@@ -349,6 +349,10 @@ static const CompOps g_comp[] = {GM_COMP_ENTRY(Plan16384) GM_COMP_ENTRY(Plan1636
 
 // N = Q * Nb: the largest base plan first (fewest sub-transform passes over the spectra)
 const CompOps* find_comp(uint32_t n) {
+    static const int base_env = getenv("GM_COMP_BASE") ? atoi(getenv("GM_COMP_BASE")) : 0;   // diagnostic: force the base size (A/B of 2 x 16000 against 4 x 8000)
+    if (base_env > 0)
+        for (const CompOps& c : g_comp)
+            if (c.nb == base_env && uint32_t(c.nb) * uint32_t(c.q) == n) return &c;
     for (const CompOps& c : g_comp)
         if (uint32_t(c.nb) * uint32_t(c.q) == n) return &c;
     return nullptr;
