@@ -3,7 +3,6 @@ synchronisation, three device-to-host copies, through the ctypes wrapper): 67 us
 ten (9.8 us per epoch against 3.1 us of device time) — three orders of magnitude inside the 1 ms real-time budget of an epoch."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import numpy as np
 from gnss_sdr_rs_amd import tracking as T, synth, acquisition as A
 fs, n, C = 25.0e6, 25000, 32
 E = 400

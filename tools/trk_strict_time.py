@@ -3,7 +3,6 @@
 printed its four lines and then never exited on this pool — every handle is closed explicitly below since.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from gnss_sdr_rs_amd import tracking as T, synth, acquisition as A
 
