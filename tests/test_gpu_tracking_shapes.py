@@ -598,3 +598,56 @@ def test_strict_modes_cfg5_full_shape_bit_identical(gpu, oracle):
         lambda i: oracle.TrackingChannel(i, fs, code_index_mode=1, n_arms=5, el_space=0.25, vel_space=0.6, boc11=True, codes=codes,
                                          code_rate=rate), 5, E)
     mgr.close(); ring.close()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_loss_of_lock_inside_update_all(gpu, oracle, strict):
+    """strict_libm + strict_sum_order through the loss-of-lock branch of do_work (do_tracking.rs:195-209) INSIDE update_all:
+    three channels on one ring — the satellite that is there, a code that is not in the air and a channel started far off in
+    Doppler and phase — 26 passes free-running over a stream that falls silent after three code periods.  The pass in which
+    each channel gives up (20 unlocked epochs -> reset + SatelliteLost), its `lost` flag, every sum before it, the processed
+    flags after it (a reset channel is skipped) and the final state must equal the oracle's exactly."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    fs, n, E = 8.0e6, 8000, 26
+    t = oracle.ca_code_table()
+    sc = synth.tracking_scene(t, fs, 0.0, [5], E + 3, config_id=65, cn0=50.0)
+    x = synth.to_c32(sc["x"])
+    s = sc["sats"][0]
+    # LOCK_THRESHOLD = 15 (:16) is far below what int8-scale noise alone puts into the prompt sums, so the air goes SILENT after
+    # three code periods: power 0 <= 15 from pass 3 on, 20 unlocked passes, reset + SatelliteLost in pass 22
+    x[s["code_start"] + 3 * n:] = 0
+    ring, oring = T.MulticastRingBuffer(1 << 18), oracle.MulticastRingBuffer(1 << 18)
+    ring.write_samples(x[:(E + 2) * n]); oring.write_samples(x[:(E + 2) * n])
+    starts = [_acq_result(5, s["doppler_hz"] + 8.0, fs, s["code_start"]),
+              _acq_result(17, s["doppler_hz"], fs, s["code_start"]),                 # PRN 17 is not in the scene
+              _acq_result(5, s["doppler_hz"] + 2500.0, fs, s["code_start"] + 37)]   # wrong Doppler, wrong phase
+    # strict = False: the same scenario through the persistent kernel (tree sums: the three live epochs within FREE_REL, everything
+    # from the silence on — zeros, flags, the pass of the reset, the reset state — exactly equal)
+    mgr = T.TrackingManager(fs, n_channels=3, code_index_mode=1, strict_libm=strict, strict_sum_order=strict)
+    ocs = []
+    for i, r in enumerate(starts):
+        mgr.channels[i].start(r)
+        oc = oracle.TrackingChannel(i, fs, code_index_mode=1)
+        oc.start(r)
+        ocs.append(oc)
+    outs, proc, lost, done = mgr.update_all(ring, E)
+    lost_at = {}
+    for i, oc in enumerate(ocs):
+        for ep in range(E):
+            rc, exp, msg = oc.update_ex(oring)
+            assert (rc != 0) == bool(proc[ep, i]), (i, ep, rc)
+            if rc and (strict or ep >= 4):
+                assert np.array_equal(np.ascontiguousarray(outs[ep, i, :6], np.float32).view(np.uint32), np.asarray(exp[:6], np.float32).view(np.uint32)), (i, ep)
+            elif rc:
+                assert float(np.max(np.abs(outs[ep, i, :6] - exp[:6]))) <= FREE_REL * max(float(np.hypot(exp[0], exp[1])), 1.0e4), (i, ep)
+            assert bool(lost[ep, i]) == (msg is not None), (i, ep, msg)
+            if msg is not None:
+                lost_at[i] = ep
+        st = mgr.channels[i].state
+        assert mgr.channels[i].is_active() == oc.is_active() and st.prn == oc.c.prn and st.lost_counter == oc.c.lost_counter
+        assert st.next_sample_index == oc.c.next_sample_index
+        for k in ("carrier_freq", "carrier_phase", "code_phase", "code_rate", "i_prompt", "q_prompt"):
+            assert _ulps(getattr(st, k), getattr(oc.c, k)) == 0, (i, k)         # reset(): all zero on both sides
+    assert lost_at.get(0) == 22 and lost_at.get(1) == 22 and 2 in lost_at, lost_at
+    assert not any(c.is_active() for c in mgr.channels)
+    mgr.close(); ring.close()
