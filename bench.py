@@ -859,13 +859,14 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0,
     mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED)
     mgr.set_stream(stream)
 
-    def restart():
+    def restart(m=None):
+        m = m or mgr
         for i in range(C):
             s = sc["sats"][i % 32]
-            mgr.channels[i].start(dict(prn=s["prn"], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=s["doppler_hz"] + 20.0,
-                                       fs=fs, mag_relative=1.0, sample_global_index=s["code_start"], doppler_bin=0))
-            mgr.channels[i].set_state(code_rate=1.023e6, num_samples_per_code=n, carrier_phase=0.0, code_error=0.0,
-                                      carrier_error=0.0, lost_counter=0)
+            m.channels[i].start(dict(prn=s["prn"], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=s["doppler_hz"] + 20.0,
+                                     fs=fs, mag_relative=1.0, sample_global_index=s["code_start"], doppler_bin=0))
+            m.channels[i].set_state(code_rate=1.023e6, num_samples_per_code=n, carrier_phase=0.0, code_error=0.0,
+                                    carrier_error=0.0, lost_counter=0)
     restart()
     mgr.update_all_dev(ring, epochs)
     mgr.synchronize()
@@ -892,10 +893,10 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0,
         try:
             ms = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED, strict_libm=True)
             ms.set_stream(stream)
-            mgr, se = ms, 120
+            se = 120
             st = []
             for _ in range(3):
-                restart()
+                restart(ms)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 ms.update_all_dev(ring, se)
@@ -907,10 +908,10 @@ def tracking_leg(torch, dev, stream, ca, T, synth, world, dist, cpu_seconds=0.0,
             # ... and with the reference's sequential sums as well: sums and channel state bit-identical, free-running
             ms = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED, strict_libm=True, strict_sum_order=True)
             ms.set_stream(stream)
-            mgr, se2 = ms, 40
+            se2 = 40
             st = []
             for _ in range(3):
-                restart()
+                restart(ms)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 ms.update_all_dev(ring, se2)
