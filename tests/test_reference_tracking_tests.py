@@ -155,3 +155,78 @@ def test_reference_synthetic_tests_strict_modes_equal_the_committed_vectors(gpu,
         assert (np.array([getattr(s, w) for w in g.STATE_WORDS], np.float32).view(np.uint32) == fx[name + "_state"][k].view(np.uint32)).all(), k
     _reference_asserts(name, recs, sig.size)
     mgr.close(); ring.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [False, True])
+def test_reference_real_signal_test_on_the_stand_in_capture(gpu, oracle, strict):
+    """test_tracking_with_real_signal (do_tracking.rs:657-751), line for line, on the synthetic stand-in for the missing capture
+    (real int8, fs 16.3676 MHz, IF 4.1304 MHz, the satellites of config.txt): acquire PRN 6 with one AcquisitionWorker over
+    the -7 ... +7 kHz / 500 Hz tables and 10 x 16368 samples (:688-709), hand the result to TrackingChannel::start (:717-719),
+    then 100 times: the next num_samples_per_code samples from `offset`, num_samples_per_code recomputed from the code rate,
+    do_work(), and the test's one assertion — prompt power > LOCK_THRESHOLD (:741).  FAITHFUL code indexing (the arithmetic as
+    written: the channel correlates against GPS_CA_CODE_32_PRN[prn], i.e. PRN 7's code, and the assertion still holds because
+    15 is far below what int8 samples put into the sums).  Every epoch is also compared with the oracle running the same
+    sequence: teacher-forced within 1e-5 by default, bit for bit (free-running) with the strict switches."""
+    import json
+    from gnss_sdr_rs_amd import acquisition as A, tracking as T, synth
+    FS, IF, NUM_INTEGRATIONS, N = 16_367_600.0, 4_130_400.0, 10, 16368
+    t = oracle.ca_code_table()
+    cap = json.load(open(os.path.join(HERE, "golden", "capture_config.json")))
+    sc = synth.cfg1_scene(t, cap, n_ms=112)
+    raw = synth.to_c32(sc["x"])                       # Complex32::new(b as i8 as f32, 0.0)
+    assert raw.size == 112 * N and (raw.imag == 0).all()
+    tables, o_tables, cur = [], [], -7000.0
+    while cur <= 7000.0:
+        tables.append(A.DopplerShiftTable(IF, cur, FS, N))
+        o_tables.append(oracle.DopplerShiftTable(IF, cur, FS, N))
+        cur += 500.0
+    assert len(tables) == 29 and all(a.doppler_freq_hz == b.doppler_freq_hz for a, b in zip(tables, o_tables))   # pub doppler_freq_hz = IF + Doppler
+    prn = 6
+    got = A.AcquisitionWorker(prn, N, FS).search_satellite(raw, tables, 0, NUM_INTEGRATIONS)
+    exp = oracle.AcquisitionWorker(prn, N, FS).search_satellite(raw, o_tables, 0, NUM_INTEGRATIONS)
+    assert got is not None and exp is not None                                   # .expect("Failed to acquire satellite")
+    for k in ("prn", "code_phase_samples", "carrier_freq", "code_phase_chips", "sample_global_index"):
+        assert got[k] == exp[k], k
+    truth = next(s for s in sc["sats"] if s["prn"] == prn)
+    assert abs(int(got["code_phase_samples"]) - int(truth["code_start"])) <= 3      # 16 samples per chip: the triangle's top is flat within noise
+    mgr = T.TrackingManager(FS, n_channels=1, code_index_mode=T.CODE_INDEX_FAITHFUL, strict_libm=strict, strict_sum_order=strict)
+    ch, oc = mgr.channels[0], oracle.TrackingChannel(0, FS, code_index_mode=oracle.CODE_INDEX_FAITHFUL)
+    ch.start(got)
+    oc.start(exp)
+    offset = int(got["code_phase_samples"])
+    worst = 0.0
+    for ep in range(100):
+        n_old = int(ch.state.num_samples_per_code)
+        assert n_old == int(oc.c.num_samples_per_code)
+        seg = raw[offset:offset + n_old]                                          # vec![0u8; num_samples_per_code] read at `offset`
+        n_new = int(oracle.num_samples_per_code(float(ch.state.code_rate), FS))   # generate_ca_code_samples(..).len()
+        assert n_new == n_old, "the reference would index past its buffer here"
+        ch.set_state(num_samples_per_code=n_new)
+        oc.c.num_samples_per_code = n_new
+        offset += n_new
+        out, msg = ch.do_work(seg)
+        if strict:
+            eout, emsg = oc.do_work(seg)
+            assert np.array_equal(np.asarray(out, np.float32).view(np.uint32), np.asarray(eout, np.float32).view(np.uint32)), ep
+        else:       # teacher-forced: the oracle computes its sums from its own (identical) state, then adopts the device's
+            comp, emsg = oc.do_work(seg)
+            # FAITHFUL mode puts PRN 7's code against PRN 6's signal: the "prompt envelope" is cross-correlation noise that passes
+            # through zero now and then, so the sums are compared on the scale of a sum of n such terms, sqrt(n) * rms(samples),
+            # wherever that is larger than the envelope
+            env = max(float(np.hypot(comp[0], comp[1])), float(np.sqrt(n_new) * np.sqrt(np.mean(np.abs(seg) ** 2))))
+            worst = max(worst, float(np.max(np.abs(np.asarray(out, np.float32) - comp))) / env)
+            assert worst <= REL, (ep, worst)
+            s = ch.state
+            for w in ("carrier_freq", "carrier_phase", "carrier_error", "carrier_nco", "code_phase", "code_error", "code_nco", "code_rate",
+                      "i_prompt", "q_prompt"):
+                setattr(oc.c, w, getattr(s, w))
+        assert msg is None and emsg is None
+        s = ch.state
+        assert s.i_prompt * s.i_prompt + s.q_prompt * s.q_prompt > 15.0            # :741 "Tracking lost: Prompt power below threshold"
+        if strict:
+            for w in ("carrier_freq", "carrier_phase", "carrier_error", "carrier_nco", "code_phase", "code_error", "code_nco", "code_rate"):
+                assert np.float32(getattr(s, w)).view(np.uint32) == np.float32(getattr(oc.c, w)).view(np.uint32), (ep, w)
+    print("real-signal stand-in: 100 epochs,", "bit-identical" if strict else "worst teacher-forced error %.2e" % worst,
+          "carrier - IF at the end: %.1f Hz (truth %.1f)" % (ch.state.carrier_freq - IF, truth["doppler_hz"]))
+    mgr.close()
