@@ -232,6 +232,48 @@ def test_cfg1_geometry_real_int8(gpu, oracle):
     eng.close()
 
 
+def test_reference_real_data_acquisition_test_on_a_stand_in_capture(gpu, oracle):
+    """test_acquisition_with_real_data (do_acquisition.rs:398-466) line for line: 10 x 16368 real int8 samples as Complex32, the
+    -7 ... +7 kHz / 500 Hz tables, then for test_prn in 1..=32 ONE AcquisitionWorker each, search_satellite with the tables passed
+    in, and the test's one assertion — an acquired PRN must be in [3, 6, 9, 11, 14, 18, 19, 22, 28, 32] (:438-454).  The capture
+    is missing; the stand-in holds exactly that list (carriers and code phases of config.txt where it lists the PRN; PRN 22,
+    which config.txt does not list, invented; PRN 2, which config.txt lists and the test does not accept, left out), so the
+    assertion means what it means in the reference: no false alarm on the 22 absent codes.  Every Option<AcquisitionResult>
+    is also compared with the oracle's, indices exact."""
+    from concurrent.futures import ThreadPoolExecutor
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    FS, IF, NUM_INTEGRATIONS, N = 16_367_600.0, 4_130_400.0, 10, 16368
+    t = oracle.ca_code_table()
+    cap = dict(golden("capture_config.json"))
+    true_satellites = [3, 6, 9, 11, 14, 18, 19, 22, 28, 32]
+    assert cap["test_accepts_prns"] == true_satellites
+    rows = [r for r in cap["signals"] if r["prn"] in true_satellites]
+    rows.append(dict(prn=22, carrier_mhz=4.13163, code_phase_samples=5555, note="not in config.txt"))
+    cap["signals"] = sorted(rows, key=lambda r: r["prn"])
+    sc = synth.cfg1_scene(t, cap, n_ms=NUM_INTEGRATIONS, config_id=14)
+    raw = synth.to_c32(sc["x"])                                    # Complex32::new((*x as i8) as f32, 0.0)
+    assert raw.size == NUM_INTEGRATIONS * N and (raw.imag == 0).all()
+    tables, o_tables, cur = [], [], -7000.0
+    while cur <= 7000.0:
+        tables.append(A.DopplerShiftTable(IF, cur, FS, N))
+        o_tables.append(oracle.DopplerShiftTable(IF, cur, FS, N))
+        cur += 500.0
+    with ThreadPoolExecutor(16) as ex:
+        exps = list(ex.map(lambda p: oracle.AcquisitionWorker(p, N, FS).search_satellite(raw, o_tables, 0, NUM_INTEGRATIONS), range(1, 33)))
+    acquired = []
+    for test_prn in range(1, 33):
+        got = A.AcquisitionWorker(test_prn, N, FS).search_satellite(raw, tables, 0, NUM_INTEGRATIONS)
+        exp = exps[test_prn - 1]
+        assert (got is None) == (exp is None), test_prn
+        if got:
+            assert test_prn in true_satellites, f"Acquired PRN {test_prn} which is not in the true satellite list!"     # :454
+            for k in ("prn", "code_phase_samples", "sample_global_index", "carrier_freq", "code_phase_chips"):
+                assert got[k] == exp[k], (test_prn, k)
+            assert got["mag_relative"] == pytest.approx(exp["mag_relative"], rel=REL)
+            acquired.append(test_prn)
+    assert len(acquired) >= 8, acquired           # the 39-44 dB-Hz ones sit at the threshold of 7 over a 10 ms dwell
+
+
 def test_worker_api_like_reference_test(gpu, oracle):
     """Reads like test_acquisition_with_real_data (do_acquisition.rs:399-466): per-PRN workers, tables passed
     with every call."""
