@@ -56,6 +56,15 @@ def test_ca_table_and_resampler_host(gm, oracle):
     from gnss_sdr_rs_amd import GmError
     with pytest.raises(GmError):
         A.generate_ca_code_samples(0, 1.023e6, 8e6)
+    # bk/gps_ca_prn.rs:65-70 `should_panic`: generate_ca_code(40) — no such PRN: the reference panics (index out of bounds),
+    # the boundary reports GM_ERR_OUT_OF_RANGE; and the table ends at row 31 (GPS_CA_CODE_32_PRN[32] is what FAITHFUL
+    # tracking of PRN 32 would index, do_tracking.rs:276)
+    with pytest.raises(GmError) as ei:
+        A.generate_ca_code_samples(40, 1.023e6, 8e6)
+    assert ei.value.status == -5
+    import ctypes as C
+    row = np.zeros(1023, np.int8)
+    assert gm.lib().gm_ca_code_row(32, row.ctypes.data_as(C.c_void_p)) == -5 and gm.lib().gm_ca_code_row(31, row.ctypes.data_as(C.c_void_p)) == 0
 
 
 def test_doppler_table_host_bit_exact_with_oracle(gm, oracle):
