@@ -230,3 +230,36 @@ def test_reference_real_signal_test_on_the_stand_in_capture(gpu, oracle, strict)
     print("real-signal stand-in: 100 epochs,", "bit-identical" if strict else "worst teacher-forced error %.2e" % worst,
           "carrier - IF at the end: %.1f Hz (truth %.1f)" % (ch.state.carrier_freq - IF, truth["doppler_hz"]))
     mgr.close()
+
+
+def test_reference_real_signal_test_through_the_oracle(oracle):
+    """CPU part of the mirror above: the same sequence of test_tracking_with_real_signal (do_tracking.rs:657-751) through the
+    oracle alone — acquisition of PRN 6 on the stand-in capture, start, 100 x do_work — with the reference's assertion."""
+    import json
+    from gnss_sdr_rs_amd import synth
+    FS, IF, NUM_INTEGRATIONS, N = 16_367_600.0, 4_130_400.0, 10, 16368
+    t = oracle.ca_code_table()
+    cap = json.load(open(os.path.join(HERE, "golden", "capture_config.json")))
+    sc = synth.cfg1_scene(t, cap, n_ms=112)
+    raw = synth.to_c32(sc["x"])
+    tables, cur = [], -7000.0
+    while cur <= 7000.0:
+        tables.append(oracle.DopplerShiftTable(IF, cur, FS, N))
+        cur += 500.0
+    res = oracle.AcquisitionWorker(6, N, FS).search_satellite(raw, tables, 0, NUM_INTEGRATIONS)
+    assert res is not None and res["prn"] == 6                                   # .expect("Failed to acquire satellite")
+    truth = next(s for s in sc["sats"] if s["prn"] == 6)
+    assert abs(int(res["code_phase_samples"]) - int(truth["code_start"])) <= 3
+    assert abs(res["carrier_freq"] - IF - truth["doppler_hz"]) <= 500.0
+    oc = oracle.TrackingChannel(0, FS, code_index_mode=oracle.CODE_INDEX_FAITHFUL)
+    oc.start(res)
+    offset = int(res["code_phase_samples"])
+    for _ in range(100):
+        n = int(oc.c.num_samples_per_code)
+        seg = raw[offset:offset + n]
+        oc.c.num_samples_per_code = int(oracle.num_samples_per_code(float(oc.c.code_rate), FS))
+        assert int(oc.c.num_samples_per_code) == n
+        offset += n
+        out, msg = oc.do_work(seg)
+        assert msg is None
+        assert oc.c.i_prompt ** 2 + oc.c.q_prompt ** 2 > 15.0                     # :741
