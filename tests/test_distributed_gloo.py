@@ -74,6 +74,13 @@ def test_shard_prns_blocks():
     ids = list(range(1, 91))
     blocks = [Dm.shard_prns(ids, 8, r) for r in range(8)]
     assert sum(blocks, []) == ids and [len(b) for b in blocks] == [12, 12, 11, 11, 11, 11, 11, 11]
+    # BASELINE configs[4]: 36 tracking channels over 1 / 2 / 4 / 8 ranks (bench.py cfg5_leg: contiguous blocks, no data-path collective)
+    ch = list(range(36))
+    for world, want in ((1, [36]), (2, [18, 18]), (4, [9, 9, 9, 9]), (8, [5, 5, 5, 5, 4, 4, 4, 4])):
+        parts = [Dm.shard_prns(ch, world, r) for r in range(world)]
+        assert sum(parts, []) == ch and [len(b) for b in parts] == want
+    # more ranks than items: trailing ranks hold nothing
+    assert [len(Dm.shard_prns([1, 2, 3], 8, r)) for r in range(8)] == [1, 1, 1, 0, 0, 0, 0, 0]
 
 
 def _grid_families():
