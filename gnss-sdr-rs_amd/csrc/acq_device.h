@@ -46,18 +46,23 @@ template <class PL, bool INV, int S, bool PFA = false> struct MiddlePasses {
 // the previous transform's last LDS reads and after the twiddle-table load).
 // PFA (PL::COPRIME plans only): the prime-factor form across the passes — inputs in Pfa<PL>::in_slot order, outputs at
 // Pfa<PL>::out_index, `tw` unused.
-template <class PL, bool INV, bool PFA = false, class In, class Out>
-__device__ __forceinline__ void lds_transform(In&& in, Out&& out, cf* lds, const cf* tw, int tid) {
+// `hook(k)` is called at fixed points of the transform (k = 0: behind pass 0's LDS writes, 1: behind the middle passes, 2: between
+// the halves of the last butterfly) — acq_corr_kernel requests a part of the next transform's inputs from one of them.
+template <class PL, bool INV, bool PFA = false, class In, class Out, class Hook = NoStamp>
+__device__ __forceinline__ void lds_transform(In&& in, Out&& out, cf* lds, const cf* tw, int tid, Hook&& hook = Hook()) {
     {
         cf v0[PL::IT0][PL::R0];
         Fft<PL, INV, PFA>::pass0_stage1(v0, in, tid);
         GM_XFORM_SYNC();
         Fft<PL, INV, PFA>::pass0_stage2(v0, lds, tid);
     }
+    hook(0);
     GM_XFORM_SYNC();
     MiddlePasses<PL, INV, 1, PFA>::run(lds, tw, tid);
+    hook(1);
     cf vl[PL::ITL][PL::RL];
     Fft<PL, INV, PFA>::last_stage1(vl, lds, tw, tid);
+    hook(2);
     Fft<PL, INV, PFA>::last_stage2(vl, out, tid);
 }
 
@@ -173,12 +178,15 @@ template <class PL> struct PairLoad {
     static constexpr bool ODD = (PL::R0 & 1) != 0;
     u32x4 q[NPAIR > 0 ? NPAIR : 1];
     cf last;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int b, int base_elems) {
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int b, int base_elems) { load_range<0, NPAIR, true>(rs, b, base_elems); }
+    // pairs [P0, P1) (and the odd element when TAIL): acq_corr_kernel requests the first pairs of the NEXT transform ahead
+    template <int P0, int P1, bool TAIL>
+    __device__ __forceinline__ void load_range(__amdgpu_buffer_rsrc_t rs, int b, int base_elems) {
         const int oob = 0x7ffffff0;                         // b >= NB0: out of the descriptor's range -> no request, zeros
         const int v16 = b < NB0 ? b * 16 : oob, v8 = b < NB0 ? b * 8 : oob;
 #pragma unroll
-        for (int rp = 0; rp < NPAIR; ++rp) q[rp] = __builtin_amdgcn_raw_buffer_load_b128(rs, v16, (base_elems + rp * 2 * NB0) * 8, 0);
-        if constexpr (ODD) last = buf_load_cf(rs, v8, (base_elems + 2 * NPAIR * NB0) * 8);
+        for (int rp = P0; rp < P1; ++rp) q[rp] = __builtin_amdgcn_raw_buffer_load_b128(rs, v16, (base_elems + rp * 2 * NB0) * 8, 0);
+        if constexpr (ODD && TAIL) last = buf_load_cf(rs, v8, (base_elems + 2 * NPAIR * NB0) * 8);
     }
     __device__ __forceinline__ cf get(int r) const {   // r is a compile-time constant after unrolling
         if (ODD && r == PL::R0 - 1) return last;

@@ -256,16 +256,32 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
     constexpr bool CAN_SPLIT = !STAMPS;
     constexpr int RL4 = (PL::RL + 3) / 4;                                         // 16-byte groups of a lane's power values (the last one padded)
     auto acc_or_zero = [&](int it, int r) { return r < PL::RL ? acc[it][r < PL::RL ? r : 0] : 0.0f; };
+    // PREFETCH (GM_CORR_PREFETCH_PAIRS > 0, hybrid plans): the first pairs of transform m + 1's spectrum are requested from
+    // inside transform m (behind its middle pass: the point with registers to spare) and travel while its last pass runs; past
+    // the last integration the request goes beyond the descriptor's range (no memory access).  The transform must stay a
+    // FUNCTION taking a hook: the same statements written inline made hipcc spill 76 registers.
+#ifndef GM_CORR_PREFETCH_PAIRS
+#define GM_CORR_PREFETCH_PAIRS 4
+#endif
+    constexpr int NPF = (HYB && CODE_PAIRED && !STAMPS && !KEEP_CODE) ? (GM_CORR_PREFETCH_PAIRS < PLd::NPAIR ? GM_CORR_PREFETCH_PAIRS : PLd::NPAIR) : 0;
+    PLd xq[PL::IT0];
+    auto load_x_ahead = [&](int m_) {
+#ifndef GM_LAB_NOLOAD
+#pragma unroll
+        for (int it = 0; it < PL::IT0; ++it) xq[it].template load_range<0, NPF, false>(xrs, tid + it * PL::T, m_ * PL::N);
+#endif
+    };
+    if constexpr (NPF > 0) load_x_ahead(m_begin);
     for (int m = m_begin; m < m_end; ++m) {
-        // all pass-0 loads of this transform are issued here, pairs as 16-byte loads (PairLayout)
-        PLd xq[PL::IT0], cq[(KEEP_CODE || !CODE_PAIRED) ? 1 : PL::IT0];
+        // all (remaining) pass-0 loads of this transform are issued here, pairs as 16-byte loads (PairLayout)
+        PLd cq[(KEEP_CODE || !CODE_PAIRED) ? 1 : PL::IT0];
 #pragma unroll
         for (int it = 0; it < PL::IT0; ++it) {
             // no branch around the loads (values that live across control flow made hipcc spill 68 VGPRs): lanes without a
             // pass-0 butterfly get an offset beyond the descriptor's range, which the buffer unit drops without a memory request
             const int b = tid + it * PL::T;
 #ifndef GM_LAB_NOLOAD
-            if constexpr (CODE_PAIRED) xq[it].load(xrs, b, m * PL::N);
+            if constexpr (CODE_PAIRED) xq[it].template load_range<NPF, PLd::NPAIR, true>(xrs, b, m * PL::N);
             if constexpr (!KEEP_CODE && CODE_PAIRED) cq[it].load(crs, b, 0);
 #endif
         }
@@ -296,7 +312,15 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
 #else
         auto out = [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y); };
 #endif
-        if constexpr (!STAMPS) {
+        if constexpr (NPF > 0) {
+            lds_transform<PL, true, PFA>(in, out, lds, tw, tid, [&](int k) {
+                if (k == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_x_ahead(m + 1 < m_end ? m + 1 : n_int);       // n_int: one past the descriptor's range
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        } else if constexpr (!STAMPS) {
             lds_transform<PL, true, PFA>(in, out, lds, tw, tid);
         } else {   // diagnostic variant: the same phases with stamps next to the barriers
             auto st = [&](int k) { corr_stamp(stbase, m, wv, k); };
