@@ -205,6 +205,10 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
     using PL = typename CorrPlanOf<PLX>::type;
     constexpr bool PFA = CorrMode<PL>::PFA, HYB = CorrMode<PL>::HYBRID;
     __shared__ cf lds[PL::LDS_ELEMS + ((PFA || HYB) ? 0 : PL::TW_TOTAL)];
+#ifdef GM_LAB_LDS_PAD      // timing experiment only (tools/corr_lab): extra LDS per workgroup, e.g. 40000 bytes -> ONE workgroup per CU
+    __shared__ int lds_pad[GM_LAB_LDS_PAD / 4];
+    if (threadIdx.x == 0 && n_int < 0) lds_pad[blockIdx.x & 63] = n_bins;      // (kept alive; never executed)
+#endif
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
 #ifdef GM_LAB_PRIO
