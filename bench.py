@@ -48,6 +48,90 @@ def gold_codes(delays):
     return np.stack([np.where(g1 ^ np.roll(g2, d), 1, -1).astype(np.int8) for d in delays])
 
 
+def rank_commands(n_gpus, argv, port, base_env=None, python=None, script=None):
+    """The N child processes `python3 bench.py --gpus N ...` starts when no launcher set WORLD_SIZE: one per GPU, the
+    environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT; rendezvous on 127.0.0.1 — the container hostname may not resolve).  Returns [(argv, env)], rank order.
+    The reference's counterpart is the rayon fan-out over its workers (do_acquisition.rs:302-313)."""
+    env0 = dict(os.environ if base_env is None else base_env)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    cmds = []
+    for r in range(n_gpus):
+        env = dict(env0)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_gpus), "LOCAL_WORLD_SIZE": str(n_gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "GM_BENCH_LAUNCHED_BY_PARENT": "1"})
+        cmds.append(([python or sys.executable, script or os.path.abspath(__file__)] + list(argv), env))
+    return cmds
+
+
+def visible_gpus():
+    """Devices this process could hand to its ranks.  torch.cuda.device_count() does not initialise the GPU on this image
+    (it reads the driver's topology), so the launcher stays a process that never touched the card."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(n_gpus, argv, timeout_s, script=None, have=None, grace_s=30.0):
+    """Start the N ranks, relay rank 0's stdout (its JSON line is this process's last stdout line), send the other ranks'
+    stdout to stderr, and return the worst exit code.  A rank that dies ends the others after a grace period (they would
+    wait in a collective for ever); so does the deadline.  No os.exec*: children are plain subprocesses."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    debug_gloo = os.environ.get("GM_BENCH_DEBUG_GLOO") == "1"
+    have = visible_gpus() if have is None else have
+    if (have < 1) or (have < n_gpus and not debug_gloo):
+        print("bench.py: --gpus %d asked for, %d GPU(s) visible%s" % (n_gpus, have, "" if have else " (none at all)") +
+              "; set GM_BENCH_DEBUG_GLOO=1 to rehearse the N-rank code path on one GPU (never a reported number)",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r, (cmd, env) in enumerate(rank_commands(n_gpus, argv, port, script=script)):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr,
+                           text=True, start_new_session=True))
+
+    def relay(f):
+        for line in f:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    t.start()
+
+    def end_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)       # the exact process groups started above, never a pattern
+                except (ProcessLookupError, PermissionError):
+                    pass
+    deadline = time.monotonic() + timeout_s
+    first_failure, why = None, None
+    while any(p.poll() is None for p in procs):
+        now = time.monotonic()
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and first_failure is None:
+            first_failure = now
+        if first_failure is not None and now - first_failure > grace_s:
+            why = "a rank exited with code %d; ending the others" % bad[0].returncode
+        elif now > deadline:
+            why = "the ranks did not finish within %.0f s (--launch-timeout); ending them" % timeout_s
+        if why:
+            print("bench.py launcher: " + why, file=sys.stderr, flush=True)
+            end_all(signal.SIGTERM)
+            time.sleep(5.0)
+            end_all(signal.SIGKILL)
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    t.join(timeout=10.0)
+    worst = max((abs(c) for c in codes), default=0)
+    return worst if not why else (worst or 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,7 +143,14 @@ def main():
     ap.add_argument("--three-dwells", action="store_true",
                     help="also time three dwells in flight on three streams (informative; off by default because the "
                          "co-executing launches would pollute the per-kernel averages of a rocprofv3 --stats run)")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("GM_BENCH_LAUNCH_TIMEOUT", "1500")),
+                    help="--gpus N > 1 started without a launcher: seconds the parent waits for its N ranks before it ends them")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python3 bench.py --gpus N`), not under torch.distributed.run: this process becomes the launcher
+        # and never touches the GPU (no torch.cuda call that initialises it, no gm_* call, no exec)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
 
     import torch
     import torch.distributed as dist
@@ -113,14 +204,17 @@ def main():
     eng.set_stream(stream)
     d_samples = torch.from_numpy(xi8).to(dev)                       # IF snapshot resident in HBM
     d_metrics = torch.zeros(3 * P * D, dtype=torch.int32, device=dev)
-    # The exchange carrier.  At N > 1 the default is the C ABI's own RCCL communicator (gm_comm_*: what a Rust host calls,
-    # all-gather + regroup inside the library, overlapped with the next dwell on the communicator's stream); before the
-    # timed region one dwell is exchanged through BOTH carriers and the native result must equal torch.distributed's bit
-    # for bit on every rank, else (or on any error) the run falls back to torch.distributed and says so in config.exchange.
-    # GM_BENCH_TORCH_COMM=1 forces the torch carrier, GM_BENCH_NATIVE_COMM=1 exercises the native one at N = 1.
+    # The exchange carrier.  torch.distributed (backend nccl = RCCL) is the default at N > 1.  GM_BENCH_NATIVE_COMM=1 opts in
+    # to the C ABI's own RCCL communicator (gm_comm_*: what a Rust host calls — all-gather + regroup inside the library,
+    # overlapped with the next dwell on the communicator's stream); it also exercises that carrier at N = 1.  Before the timed
+    # region one dwell then goes through BOTH carriers — the native one through the SAME asynchronous entries the timed loop
+    # uses (gm_acq_allgather_metrics_async + gm_comm_wait + the device decision) — and the native result must equal
+    # torch.distributed's bit for bit and give the scene's detections on every rank, else (or on any error) the run falls back
+    # to torch.distributed and says so in config.exchange_fallback_reason.  gm_comm stays opt-in until one multi-GPU run of it
+    # is on record (no multi-GPU box has run either carrier yet).
     from gnss_sdr_rs_amd import distributed as Dm
     native_comm, carrier_note = None, None
-    want_native = (world > 1 and os.environ.get("GM_BENCH_TORCH_COMM") != "1") or os.environ.get("GM_BENCH_NATIVE_COMM") == "1"
+    want_native = os.environ.get("GM_BENCH_NATIVE_COMM") == "1"
     if want_native and not debug_gloo:
         try:
             native_comm = Dm.NativeComm.from_torch_dist() if world > 1 else Dm.NativeComm(1, 0, Dm.NativeComm.unique_id())
@@ -137,13 +231,20 @@ def main():
         if native_comm:
             try:
                 eng.search_dev(d_samples.data_ptr(), A.FMT_I8_IQ, d_metrics.data_ptr())
-                native_comm.allgather_metrics(eng, gat2[1].data_ptr(), d_metrics.data_ptr())       # -> [3][world*P][D]
+                native_comm.allgather_metrics_async(eng, gat2[1].data_ptr(), d_metrics.data_ptr())   # -> [3][world*P][D]
+                native_comm.wait(stream)
+                eng.decide_dev(gat2[1].data_ptr(), n_prn=world * P, prn_ids=ids_all)
                 ref = torch.empty_like(d_gather)
                 dist.all_gather_into_tensor(ref, d_metrics)
                 torch.cuda.synchronize()
                 ok = int(torch.equal(ref.view(world, 3, P * D).permute(1, 0, 2).contiguous().view(-1), gat2[1]))
                 if not ok:
                     carrier_note = "gm_comm all-gather differed from torch.distributed's"
+                else:
+                    tr = eng.fetch_results(world * P)
+                    want = {s_["prn"]: s_["code_start"] for s_ in sc["sats"]}
+                    if {r_["prn"]: r_["code_phase_samples"] for r_ in tr[:P] if r_} != want or any(r_ is not None for r_ in tr[P:]):
+                        ok, carrier_note = 0, "the decision on gm_comm's gathered grid did not give the scene's detections"
             except Exception as e:
                 ok, carrier_note = 0, "gm_comm trial failed: %r" % (e,)
         else:

@@ -1,0 +1,91 @@
+"""`python3 bench.py --gpus N` without a launcher starts its N ranks itself.  CPU tests of the
+launcher: the environment / argument construction, the refusal when fewer GPUs are visible than asked for, the relay of
+rank 0's stdout, the worst exit code, and the end of the surviving ranks when one dies.  The ranks here are a stand-in
+script that never imports torch: the launcher must work without touching a GPU."""
+import importlib.util
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_rank_commands_env_and_argv():
+    b = _bench()
+    cmds = b.rank_commands(4, ["--gpus", "4", "--steps", "7"], 29517, base_env={"PATH": "/bin", "RANK": "99"}, python="py", script="bench.py")
+    assert len(cmds) == 4
+    for r, (argv, env) in enumerate(cmds):
+        assert argv == ["py", "bench.py", "--gpus", "4", "--steps", "7"]
+        assert env["RANK"] == str(r) and env["LOCAL_RANK"] == str(r)
+        assert env["WORLD_SIZE"] == "4" and env["LOCAL_WORLD_SIZE"] == "4"
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29517"
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert env["PATH"] == "/bin"
+    # an inherited setting of the IPC mode is kept
+    cmds = b.rank_commands(1, [], 1, base_env={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert cmds[0][1]["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+
+
+def test_refuses_when_fewer_gpus_than_asked(capsys, monkeypatch):
+    b = _bench()
+    monkeypatch.delenv("GM_BENCH_DEBUG_GLOO", raising=False)
+    assert b.launch_ranks(8, ["--gpus", "8"], 5.0, have=1) == 2
+    assert "8 asked for, 1 GPU(s) visible" in capsys.readouterr().err
+    assert b.launch_ranks(2, ["--gpus", "2"], 5.0, have=0) == 2
+
+
+def _script(tmp_path, body):
+    p = tmp_path / "rank.py"
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
+def test_relays_rank0_and_returns_worst_code(tmp_path):
+    script = _script(tmp_path, """
+        import json, os, sys
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+        print("noise from rank %d" % r)
+        if r == 0:
+            print(json.dumps({"n_gpus": w, "argv": sys.argv[1:]}))
+        sys.exit(3 if (r == 1 and "--fail" in sys.argv) else 0)
+    """)
+    drv = "import sys; sys.path.insert(0, %r); import importlib.util as u; s = u.spec_from_file_location('b', %r); b = u.module_from_spec(s); s.loader.exec_module(b); sys.exit(b.launch_ranks(3, sys.argv[1:], 60.0, script=%r, have=3, grace_s=1.0))" % (ROOT, os.path.join(ROOT, "bench.py"), script)
+    r = subprocess.run([sys.executable, "-c", drv, "--gpus", "3", "--steps", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == '{"n_gpus": 3, "argv": ["--gpus", "3", "--steps", "2"]}'
+    assert "noise from rank 0" in r.stdout and "noise from rank 1" not in r.stdout and "noise from rank 2" in r.stderr
+    r = subprocess.run([sys.executable, "-c", drv, "--gpus", "3", "--fail"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 3
+
+
+def test_a_dead_rank_ends_the_waiting_ones(tmp_path):
+    script = _script(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit(7)
+        time.sleep(600)       # a rank waiting in a collective for a peer that is gone
+    """)
+    drv = "import sys; sys.path.insert(0, %r); import importlib.util as u; s = u.spec_from_file_location('b', %r); b = u.module_from_spec(s); s.loader.exec_module(b); sys.exit(b.launch_ranks(2, [], 300.0, script=%r, have=2, grace_s=1.0))" % (ROOT, os.path.join(ROOT, "bench.py"), script)
+    r = subprocess.run([sys.executable, "-c", drv], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0 and "ending the others" in r.stderr
+
+
+def test_plain_invocation_without_gpus_exits_nonzero_with_a_message():
+    """`python3 bench.py --gpus 2` on a box with no GPU: a message and a non-zero exit, not a silent one-GPU measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GM_BENCH_DEBUG_GLOO")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return      # a real multi-GPU host: the launcher would run the bench; not this test's business
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr and r.stdout.strip() == ""
