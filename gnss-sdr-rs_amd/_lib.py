@@ -30,7 +30,7 @@ class AcqCfg(C.Structure):
                 ("n_bins", C.c_uint32), ("doppler_hz", C.c_void_p), ("tables", C.c_void_p),
                 ("table_freq", C.c_void_p), ("n_prn", C.c_uint32), ("prn_ids", C.c_void_p), ("codes", C.c_void_p),
                 ("code_len", C.c_uint32), ("code_rate", C.c_float), ("threshold", C.c_float),
-                ("decision_mode", C.c_int32), ("strict_sum_order", C.c_int32)]
+                ("decision_mode", C.c_int32), ("strict_sum_order", C.c_int32), ("reference_products", C.c_int32)]
 
 
 class TrkState(C.Structure):

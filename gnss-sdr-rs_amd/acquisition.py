@@ -79,7 +79,7 @@ class AcquisitionEngine:
     all AcquisitionWorkers of one stage in one handle."""
 
     def __init__(self, fs, f_if, fft_size, doppler_hz=None, prn_ids=None, n_integrations=LONG_SAMPLES_LENGTH,
-                 tables=None, codes=None, code_rate=1.023e6, threshold=7.0, decision_mode=0, strict_sum_order=False,
+                 tables=None, codes=None, code_rate=1.023e6, threshold=7.0, decision_mode=0, strict_sum_order=False, reference_products=False,
                  device=None):
         _lib.init(device if device is not None else (_lib._initialised or 0))
         self.fs, self.f_if, self.fft_size, self.M = float(fs), float(f_if), int(fft_size), int(n_integrations)
@@ -106,6 +106,7 @@ class AcquisitionEngine:
         cfg.threshold = threshold
         cfg.decision_mode = decision_mode
         cfg.strict_sum_order = int(bool(strict_sum_order))
+        cfg.reference_products = int(bool(reference_products))
         self.P = int(cfg.n_prn)
         h = C.c_void_p()
         check(lib().gm_acq_create(C.byref(cfg), C.byref(h)), "gm_acq_create")

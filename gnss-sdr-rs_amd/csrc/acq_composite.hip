@@ -22,7 +22,6 @@
 // algorithmic bytes).  Here every spectrum element is re-read Q times from L2 (once per n1), which costs pass-0 load
 // slots but no HBM traffic: the working set is the spectra (D*M*N*8 B) and the code spectra (P*N*8 B).
 #include "acq_device.h"
-#include <cstdlib>
 #include <vector>
 
 namespace gm {
@@ -305,7 +304,7 @@ template <class PL, uint32_t Q> struct CompLaunch {
     static void corr(hipStream_t st, const cf* spectra, const cf* code_paired, const cf* twn, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int) {
         if (n_workers <= 0) return;
-        static const int cb_env = getenv("GM_COMP_CB") ? atoi(getenv("GM_COMP_CB")) : -1;   // diagnostic: workers per block (0: plain order)
+        static const int cb_env = diag_int("GM_COMP_CB", -1);   // diagnostic: workers per block (0: plain order)
         const int items = n_workers * n_bins, share = (items + 7) / 8;
         // measured at 36 codes x 41 bins x N = 2 x 16000: plain order 0.351 ms, blocks of 4 / 8 / 12 workers 0.313 / 0.314 / 0.314,
         // blocks of 2 or 6 no gain (6 x ~5 bins is exactly the resident set: every workgroup of a round then starts a new table)
@@ -336,6 +335,7 @@ template <class PL, uint32_t Q> struct CompLaunch {
 }  // namespace gm
 // 16368's generic plan runs here with its twiddles (AsPlain: the prime-factor form is the fused kernel's)
 namespace gm { template <> struct CompPlanOf<Plan16368> { using type = AsPlain<Plan16368>; }; }
+namespace gm { template <> struct CompPlanOf<Plan8184> { using type = AsPlain<Plan8184>; }; }
 #ifndef GM_COMP_HYBRID_16000      // (A/B switch)
 namespace gm { template <> struct CompPlanOf<Plan16000> { using type = Plan16000; }; }
 #endif
@@ -344,12 +344,12 @@ namespace gm {
 #define GM_COMP_ENTRY(PL)                                                                            \
     CompLaunch<PL, 2>::ops(), CompLaunch<PL, 3>::ops(), CompLaunch<PL, 4>::ops(), CompLaunch<PL, 5>::ops(), \
         CompLaunch<PL, 6>::ops(), CompLaunch<PL, 8>::ops(),
-static const CompOps g_comp[] = {GM_COMP_ENTRY(Plan16384) GM_COMP_ENTRY(Plan16368) GM_COMP_ENTRY(Plan16000) GM_COMP_ENTRY(Plan8000) GM_COMP_ENTRY(Plan8192)
+static const CompOps g_comp[] = {GM_COMP_ENTRY(Plan16384) GM_COMP_ENTRY(Plan16368) GM_COMP_ENTRY(Plan16000) GM_COMP_ENTRY(Plan8000) GM_COMP_ENTRY(Plan8192) GM_COMP_ENTRY(Plan8184)
                                      GM_COMP_ENTRY(Plan6000) GM_COMP_ENTRY(Plan5000) GM_COMP_ENTRY(Plan4000)};
 
 // N = Q * Nb: the largest base plan first (fewest sub-transform passes over the spectra)
 const CompOps* find_comp(uint32_t n) {
-    static const int base_env = getenv("GM_COMP_BASE") ? atoi(getenv("GM_COMP_BASE")) : 0;   // diagnostic: force the base size (A/B of 2 x 16000 against 4 x 8000)
+    static const int base_env = diag_int("GM_COMP_BASE", 0);   // diagnostic: force the base size (A/B of 2 x 16000 against 4 x 8000)
     if (base_env > 0)
         for (const CompOps& c : g_comp)
             if (c.nb == base_env && uint32_t(c.nb) * uint32_t(c.q) == n) return &c;

@@ -9,11 +9,6 @@ namespace gm {
 
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
 
-// the workgroup barriers of a transform (tools/corr_lab defines it away for a timing ablation: the result is then garbage)
-#ifndef GM_XFORM_SYNC
-#define GM_XFORM_SYNC() __syncthreads()
-#endif
-
 // hybrid plans run their middle pass in place per wave group (fft_core.h): a one-wave group orders its own LDS reads before its
 // writes by program order alone
 template <class PL> constexpr bool mid_pass_needs_barrier() {
@@ -28,13 +23,13 @@ template <class PL, bool INV, int S, bool PFA = false> struct MiddlePasses {
             cf v[PL::IT(S)][PL::R[S]];
             Fft<PL, INV, PFA>::template mid_stage1<S>(v, lds, tw, tid);
             st(4);
-            if constexpr (mid_pass_needs_barrier<PL>()) GM_XFORM_SYNC();   // every lane has read its inputs: the image may be overwritten
+            if constexpr (mid_pass_needs_barrier<PL>()) __syncthreads();   // every lane has read its inputs: the image may be overwritten
             else __builtin_amdgcn_sched_barrier(0);   // no hardware barrier, but the two halves stay apart in the schedule (the
                                                       // butterfly's second half pulled over the first cost 65 spilled registers)
             st(5);
             Fft<PL, INV, PFA>::template mid_stage2<S>(v, lds, tid);
             st(6);
-            GM_XFORM_SYNC();
+            __syncthreads();
             st(7);
             MiddlePasses<PL, INV, S + 1, PFA>::run(lds, tw, tid);
         }
@@ -53,11 +48,11 @@ __device__ __forceinline__ void lds_transform(In&& in, Out&& out, cf* lds, const
     {
         cf v0[PL::IT0][PL::R0];
         Fft<PL, INV, PFA>::pass0_stage1(v0, in, tid);
-        GM_XFORM_SYNC();
+        __syncthreads();
         Fft<PL, INV, PFA>::pass0_stage2(v0, lds, tid);
     }
     hook(0);
-    GM_XFORM_SYNC();
+    __syncthreads();
     MiddlePasses<PL, INV, 1, PFA>::run(lds, tw, tid);
     hook(1);
     cf vl[PL::ITL][PL::RL];

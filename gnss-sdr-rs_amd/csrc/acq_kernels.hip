@@ -19,7 +19,6 @@
 // Compiled with -ffp-contract=off: the "faithful" products below must round like rustc's
 // (no FMA); the FFT butterflies use explicit __builtin_fmaf.
 #include "acq_device.h"
-#include <cstdlib>
 
 namespace gm {
 
@@ -58,11 +57,7 @@ __global__ __launch_bounds__(MixPlanOf<PLX>::type::T) void acq_mix_fft_kernel(co
     auto in = [&](int it, int r) {
         const int idx = (tid + it * PL::T) + r * NB0;
         const cf s = load_sample(samples, fmt, sbase + idx);
-#ifdef GM_LAB_MIX_NOTAB      // timing ablation only (tools/mix_lab)
-        const cf t = cf_make(0.6f, 0.8f);
-#else
         const cf t = tab[idx];
-#endif
         // multiply_simd_block (doppler_shift.rs:43-58): a*c + (b*d*(-1)), a*d + (b*c*(+1))
         return cf_make(s.x * t.x - s.y * t.y, s.x * t.y + s.y * t.x);
     };
@@ -91,15 +86,9 @@ __global__ __launch_bounds__(MixPlanOf<PLX>::type::T) void acq_mix_fft_kernel(co
             const int k = (tid + it * PL::T) + r * NBL;
             lds[k + (k >> 5)] = val; }, tid);
         __syncthreads();
-#ifdef GM_LAB_MIX_OLDSTORE   // the element-by-element write-out (A/B timing, tools/mix_lab)
-        for (int p = tid; p < PL::N; p += PL::T) {
-            const int k = order[p];
-            dst[p] = lds[k + (k >> 5)];
-        }
-#else
         // two consecutive positions per lane and round: one 4-byte read of the order table, two LDS reads, ONE 16-byte store —
-        // a wave's store covers 1 KB of contiguous spectrum: stage F 25.4 -> 24.2 us (tools/mix_lab, GM_LAB_MIX_OLDSTORE = the
-        // 8-byte form).  The write phase is a burst of D*M*N*8 bytes (26 MB at configs[1]) from every workgroup at once: without
+        // a wave's store covers 1 KB of contiguous spectrum: stage F 25.4 -> 24.2 us against the element-by-element 8-byte
+        // form (round 3, tools/mix_lab).  The write phase is a burst of D*M*N*8 bytes (26 MB at configs[1]) from every workgroup at once: without
         // it the kernel takes 17.6 us, which is the latency of ONE transform by a workgroup alone on its CU (the 410 transforms
         // are a single round); eight positions per lane (64 contiguous bytes, four partial-line stores) was slower: 27.5 us.
         static_assert(PL::N % 2 == 0, "N must be even");
@@ -107,12 +96,8 @@ __global__ __launch_bounds__(MixPlanOf<PLX>::type::T) void acq_mix_fft_kernel(co
             const uint32_t o = reinterpret_cast<const uint32_t*>(order)[g];
             const int k0 = int(o & 0xffffu), k1 = int(o >> 16);
             const cf v0 = lds[k0 + (k0 >> 5)], v1 = lds[k1 + (k1 >> 5)];
-#ifdef GM_LAB_MIX_NOSTORE    // timing ablation only (tools/mix_lab): no spectrum leaves the workgroup unless it holds a NaN
-            if (v0.x != v0.x || v1.y != v1.y)
-#endif
             reinterpret_cast<float4*>(dst)[g] = make_float4(v0.x, v0.y, v1.x, v1.y);
         }
-#endif
     }
 }
 
@@ -135,7 +120,9 @@ void set_corr_stamps(long long* d_ptr) {
 }
 
 // ------------------------------------------------------------------------------------ stage C
-template <class PLX, bool KEEP_CODE, bool STAMPS>
+// REF_MUL (gm_acq_cfg.reference_products): x conj(code) and |.|^2 formed exactly as num-complex does (separate multiplies and
+// adds, :184-192) instead of with two fused multiply-adds each.
+template <class PLX, bool KEEP_CODE, bool STAMPS, bool REF_MUL>
 __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WAVES_PER_EU) void acq_corr_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ tw_inv,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
@@ -205,15 +192,8 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
     using PL = typename CorrPlanOf<PLX>::type;
     constexpr bool PFA = CorrMode<PL>::PFA, HYB = CorrMode<PL>::HYBRID;
     __shared__ cf lds[PL::LDS_ELEMS + ((PFA || HYB) ? 0 : PL::TW_TOTAL)];
-#ifdef GM_LAB_LDS_PAD      // timing experiment only (tools/corr_lab): extra LDS per workgroup, e.g. 40000 bytes -> ONE workgroup per CU
-    __shared__ int lds_pad[GM_LAB_LDS_PAD / 4];
-    if (threadIdx.x == 0 && n_int < 0) lds_pad[blockIdx.x & 63] = n_bins;      // (kept alive; never executed)
-#endif
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
-#ifdef GM_LAB_PRIO
-    if (tid >= 256) __builtin_amdgcn_s_setprio(1);
-#endif
     if constexpr (!PFA && !HYB) load_twiddles<PL>(tw, tw_inv, tid);
     constexpr int NB0 = PL::NB(0), NBL = PL::NB(PL::NP - 1);
     // does lane (tid, it) own outputs of the last pass, and which element is its output r
@@ -270,10 +250,8 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
     constexpr int NPF = (HYB && CODE_PAIRED && !STAMPS && !KEEP_CODE) ? (GM_CORR_PREFETCH_PAIRS < PLd::NPAIR ? GM_CORR_PREFETCH_PAIRS : PLd::NPAIR) : 0;
     PLd xq[PL::IT0];
     auto load_x_ahead = [&](int m_) {
-#ifndef GM_LAB_NOLOAD
 #pragma unroll
         for (int it = 0; it < PL::IT0; ++it) xq[it].template load_range<0, NPF, false>(xrs, tid + it * PL::T, m_ * PL::N);
-#endif
     };
     if constexpr (NPF > 0) load_x_ahead(m_begin);
     for (int m = m_begin; m < m_end; ++m) {
@@ -284,15 +262,10 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
             // no branch around the loads (values that live across control flow made hipcc spill 68 VGPRs): lanes without a
             // pass-0 butterfly get an offset beyond the descriptor's range, which the buffer unit drops without a memory request
             const int b = tid + it * PL::T;
-#ifndef GM_LAB_NOLOAD
             if constexpr (CODE_PAIRED) xq[it].template load_range<NPF, PLd::NPAIR, true>(xrs, b, m * PL::N);
             if constexpr (!KEEP_CODE && CODE_PAIRED) cq[it].load(crs, b, 0);
-#endif
         }
         auto in = [&](int it, int r) {
-#ifdef GM_LAB_NOLOAD      // timing ablation only (tools/corr_lab): inputs made up in registers, no pass-0 loads
-            { const float f = float(tid + m); return cf_make(f * 1e-3f + float(r), f * 2e-3f - float(it)); }
-#endif
             const cf a = CODE_PAIRED ? xq[it].get(r) : buf_load_cf(xrs, (tid + it * PL::T) * 8, (m * PL::N + r * NB0) * 8);
             cf c;
             if constexpr (KEEP_CODE) c = cc[it][r];
@@ -300,22 +273,19 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
             else { const cf g = buf_load_cf(crs, (tid + it * PL::T) * 8, r * NB0 * 8); c = cf_make(g.x, -g.y); }
             // result_buf[i] *= conj(code[i])  (:184-186).  num-complex multiplies without FMA; here two of the four products are
             // fused (one rounding less each).  The value feeds the inverse FFT, whose own rounding differs from rustfft's by more
-            // than that, and nothing observable sits in between: 4 instead of 6 instructions per element (GM_CORR_NO_FMA: the
-            // unfused forms, for A/B timing)
-#ifndef GM_CORR_NO_FMA
-            return cf_make(__builtin_fmaf(a.x, c.x, -(a.y * c.y)), __builtin_fmaf(a.x, c.y, a.y * c.x));
-#else
-            return cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
-#endif
+            // than that, and nothing observable sits in between: 4 instead of 6 instructions per element.  REF_MUL: num-complex's
+            // own form, re = a.re*b.re - a.im*b.im, im = a.re*b.im + a.im*b.re, every product and sum rounded on its own
+            if constexpr (REF_MUL) return cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
+            else return cf_make(__builtin_fmaf(a.x, c.x, -(a.y * c.y)), __builtin_fmaf(a.x, c.y, a.y * c.x));
         };
         // acc += norm_sqr() (:190-192): the power with one fused multiply-add, then a plain add — the running sum must stay
         // `acc + p` with p complete, so that the planes of a cut item (each 0 + p) merge to the very same words (two fused
         // multiply-adds into acc would save one more instruction and break that)
-#ifndef GM_CORR_NO_FMA
-        auto out = [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + __builtin_fmaf(v.y, v.y, v.x * v.x); };
-#else
-        auto out = [&](int it, int r, cf v) { acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y); };
-#endif
+        // REF_MUL: norm_sqr() = re*re + im*im with both products rounded
+        auto out = [&](int it, int r, cf v) {
+            if constexpr (REF_MUL) acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y);
+            else acc[it][r] = acc[it][r] + __builtin_fmaf(v.y, v.y, v.x * v.x);
+        };
         if constexpr (NPF > 0) {
             lds_transform<PL, true, PFA>(in, out, lds, tw, tid, [&](int k) {
                 if (k == 1) {
@@ -352,7 +322,9 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
             // `buffer_store_dwordx4 v[..], v, s[..], sN offen` (scalar offset REGISTER) directly followed by a VALU write of its
             // data registers stored the NEW values of a few lanes now and then on gfx950 — the plane sums came out 0.01-0.5 %
             // low (tools/split_probe.py) — and hipcc's hazard recogniser inserts its wait state only for the forms without a
-            // scalar offset register.  With soffset = 0 it does.
+            // scalar offset register.  With soffset = 0 it does.  The guard no longer rests on that: every store below is
+            // followed by an explicit `s_nop 1` (two wait states before ANY later instruction, so also before a VALU write of
+            // the registers the store is still reading), and nothing zeroes or reloads `acc` before the s_waitcnt vmcnt(0).
             constexpr int SLAB = PL::ITL * RL4 * 4 * PL::T;                       // floats per power plane, register order
             // the item's planes: [n_int][SLAB] floats at its own place in the scratch
             const size_t item_plane0 = (size_t(xcd) * split_items + (slot - split_from)) * size_t(n_int);
@@ -366,6 +338,7 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
                     v.x = __float_as_uint(acc_or_zero(it, 4 * r4 + 0)); v.y = __float_as_uint(acc_or_zero(it, 4 * r4 + 1));
                     v.z = __float_as_uint(acc_or_zero(it, 4 * r4 + 2)); v.w = __float_as_uint(acc_or_zero(it, 4 * r4 + 3));
                     __builtin_amdgcn_raw_buffer_store_b128(v, srs, voff + (it * RL4 + r4) * PL::T * 16, 0, 16);   // sc1: write-through
+                    asm volatile("s_nop 1" ::: "memory");      // store-data hazard guard (see above): not left to the compiler's recogniser
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left
             __syncthreads();                                         // ... and every wave's
@@ -755,12 +728,13 @@ template <class PL> struct Launch {
     static constexpr int SPLIT_SLAB = CP::ITL * ((CP::RL + 3) / 4) * 4 * CP::T;   // floats per power plane of the tail split
     static void corr(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
-                     int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum, int tickets_cleared) {
+                     int n_int, float* split_scratch, int split_planes, uint32_t* split_counter, int strict_sum, int tickets_cleared,
+                     int ref_mul) {
         if (n_workers <= 0) return;
         // Tile map: whole Doppler bins per XCD (best L2 locality) unless that costs an XCD an extra round of
         // workgroups (2 x 32 resident per XCD) compared with equal shares of the item list.  Measured on configs[1]
         // geometry: P = 12: 125 -> 88 us, P = 24: 195 -> 165 us with equal shares; P = 32: whole bins 3 % faster.
-        static const int forced = getenv("GM_CORR_MAP") ? atoi(getenv("GM_CORR_MAP")) : -1;   // diagnostic override
+        static const int forced = diag_int("GM_CORR_MAP", -1);   // diagnostic override (GM_DIAGNOSTICS=1 only)
         const int per_xcd_bins = ((n_bins + 7) / 8) * n_workers, per_xcd_even = (n_bins * n_workers + 7) / 8;
         const int slots = 32 * CP::WG_PER_CU;
         const int q = n_bins / 8, left = (n_bins - 8 * q) * n_workers;
@@ -769,7 +743,7 @@ template <class PL> struct Launch {
         if (map_mode == 1 && per_xcd_mixed < per_xcd_bins) map_mode = 2;   // same locality, balanced leftovers
         if (forced >= 0) map_mode = forced;
         // GM_CORR_CB = cb (diagnostic, and the default for one-workgroup-per-CU plans below): tiled walk of the equal shares
-        static const int cb_env = getenv("GM_CORR_CB") ? atoi(getenv("GM_CORR_CB")) : -1;
+        static const int cb_env = diag_int("GM_CORR_CB", -1);
         int cb = cb_env >= 0 ? cb_env : 0;
         int share = map_mode == 0 ? per_xcd_even : (map_mode == 1 ? per_xcd_bins : per_xcd_mixed);
         if (cb > 0) {
@@ -785,8 +759,8 @@ template <class PL> struct Launch {
         // them that every resident slot ends on a short workgroup (items * n_int ~ slots).  Measured at configs[1]:
         // 0.229 -> 0.206 ms per launch; the part count and the item count barely matter between (2, 4) and (10, 8).
         // GM_CORR_SPLIT = 0 / 1 (no cut) and GM_CORR_SPLIT_ITEMS override for diagnostics.
-        static const int split_env = getenv("GM_CORR_SPLIT") ? atoi(getenv("GM_CORR_SPLIT")) : -1;
-        static const int items_env = getenv("GM_CORR_SPLIT_ITEMS") ? atoi(getenv("GM_CORR_SPLIT_ITEMS")) : -1;
+        static const int split_env = diag_int("GM_CORR_SPLIT", -1);
+        static const int items_env = diag_int("GM_CORR_SPLIT_ITEMS", -1);
         int split_from = share, split_k = 1, split_items = 0;
         // (strict_sum_order also keeps the reference's sequential accumulation over the integrations: no split)
         if (SPLIT_SLAB && split_scratch && split_counter && split_env != 0 && !g_corr_stamps_armed && !strict_sum &&
@@ -795,7 +769,7 @@ template <class PL> struct Launch {
             // search) leaves most of the chip idle: then EVERY item is cut, which multiplies the parallelism by k
             const bool all = share <= slots;
             // one integration per part (see the kernel): k = n_int, when the scratch holds the planes
-            if (n_int >= 2 && n_int <= GM_CORR_SPLIT_MAX_K && (!all || share * n_int <= GM_CORR_SPLIT_MAX_SLABS / 8)) split_k = n_int;
+            if (n_int >= 2 && n_int <= GM_CORR_SPLIT_MAX_K && (!all || share * n_int <= split_planes / 8)) split_k = n_int;
             // one workgroup per CU (N = 16368 ...): the cut tail does not pay on a grid of several rounds (same box, back to back:
             // 0.440 against 0.432 ms per 32-PRN launch with and without; comparisons ACROSS gpurun boxes are worthless for a
             // 2 % question — the chips differ by more); it stays for grids that fit the chip at once, where it multiplies the parallelism
@@ -805,7 +779,7 @@ template <class PL> struct Launch {
                 split_items = items_env > 0 ? items_env : (all ? share : (slots + split_k - 1) / split_k);
                 if (split_items > share) split_items = share;
                 if (split_items > GM_CORR_SPLIT_MAX_ITEMS / 8) split_items = GM_CORR_SPLIT_MAX_ITEMS / 8;
-                if (split_items * n_int > GM_CORR_SPLIT_MAX_SLABS / 8) split_items = GM_CORR_SPLIT_MAX_SLABS / 8 / n_int;   // one plane per integration
+                if (split_items * n_int > split_planes / 8) split_items = split_planes / 8 / n_int;   // one plane per integration; the scratch holds split_planes of them
                 if (split_items <= 0) { split_items = 0; split_k = 1; }
                 split_from = share - split_items;
             }
@@ -816,11 +790,15 @@ template <class PL> struct Launch {
         // at the start of its allocation (cdna_hip_programming.md G16 "Re-initialise every call")
         if (split_k > 1 && !tickets_cleared) (void)hipMemsetAsync(split_counter, 0, size_t(GM_CORR_SPLIT_MAX_ITEMS) * sizeof(uint32_t), st);
         if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
-            hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, true>), dim3(grid), dim3(PL::T), 0, st,
+            hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, true, false>), dim3(grid), dim3(PL::T), 0, st,
+                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
+                               split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
+        else if (ref_mul)          // gm_acq_cfg.reference_products: the reference's own rounding of x conj(code) and |.|^2
+            hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, false, true>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
                                split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
         else
-            hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, false>), dim3(grid), dim3(PL::T), 0, st,
+            hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, false, false>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
                                split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
     }

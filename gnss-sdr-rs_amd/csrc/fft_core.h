@@ -509,12 +509,6 @@ template <class PL, bool INV, bool PFA = false> struct Fft {
         for (int it = 0; it < PL::IT(S); ++it) {
             const int b = bfly_of<S>(tid, it);
             if (unsigned(b) < unsigned(NB)) {
-#ifdef GM_LAB_NOTW      // timing ablation only (tools/corr_lab): no twiddles at all -> wrong results
-                Bfly<R, INV>::stage1([&](int r) { return lds[rd<S>(b + r * NB)]; }, v[it]);
-#elif defined(GM_LAB_TWTAB)   // timing ablation only: one table read + one complex multiply per input (the cost shape of small-table twiddles)
-                const cf* tb = tw + PL::TWOFF(S) + (b % (P < 25 ? P : 25));
-                Bfly<R, INV>::stage1([&](int r) { return r == 0 ? lds[rd<S>(b)] : cf_mul(lds[rd<S>(b + r * NB)], tb[r % 5 * 25 + r]); }, v[it]);
-#else
                 if constexpr (PFA) {
                     Bfly<R, INV>::stage1([&](int r) { return lds[rd<S>(b + r * NB)]; }, v[it]);
                 } else {
@@ -522,7 +516,6 @@ template <class PL, bool INV, bool PFA = false> struct Fft {
                     w.init(tw[PL::TWOFF(S) + (b % P)]);
                     Bfly<R, INV>::stage1([&](int r) { return w.apply(lds[rd<S>(b + r * NB)], r); }, v[it]);
                 }
-#endif
             }
         }
     }

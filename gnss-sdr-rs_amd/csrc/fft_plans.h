@@ -17,6 +17,12 @@ using Plan8000 = Plan<8000, 512, 25, 20, 16>;
 // radix-16 pass in the middle (two butterflies per thread), the radix-31 pass last: its 31 outputs go straight into the
 // power sums without an LDS scatter (order [33,31,16]: 0.52 ms per 32-PRN dwell; [33,16,31]: 0.47 before the prime-factor form)
 using Plan16368 = Plan<16368, 768, 33, 16, 31>;
+// 8184 = 24 * 11 * 31 (pairwise coprime): half of 16368 — the base of the 2 x 8184 composite form of the reference's own geometry
+// (two workgroups per CU: 65.5 KB each)
+#ifndef GM_PLAN_8184
+#define GM_PLAN_8184 Plan<8184, 384, 24, 11, 31>
+#endif
+using Plan8184 = GM_PLAN_8184;
 using Plan4096 = Plan<4096, 256, 16, 16, 16>;
 using Plan2048 = Plan<2048, 256, 8, 16, 16>;
 using Plan1024 = Plan<1024, 128, 8, 8, 16>;
@@ -42,7 +48,7 @@ template <> struct PlanRot<Plan8000> { static constexpr int rot(int s) { return 
 
 #ifndef GM_FOR_EACH_PLAN   // tools/corr_lab restricts the list to one plan for fast experimental builds
 #define GM_FOR_EACH_PLAN(X) \
-    X(gm::Plan8000) X(gm::Plan16368) X(gm::Plan4096) X(gm::Plan2048) X(gm::Plan1024) \
+    X(gm::Plan8000) X(gm::Plan16368) X(gm::Plan8184) X(gm::Plan4096) X(gm::Plan2048) X(gm::Plan1024) \
     X(gm::Plan4000) X(gm::Plan10000) X(gm::Plan12000) X(gm::Plan16000) \
     X(gm::Plan2000) X(gm::Plan5000) X(gm::Plan6000) X(gm::Plan8192) X(gm::Plan15000) X(gm::Plan16384) \
     X(gm::Plan512) X(gm::Plan256)

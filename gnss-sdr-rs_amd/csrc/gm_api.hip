@@ -19,6 +19,24 @@
 
 using gm::cf;
 
+// The diagnostic gate (gm_internal.h).  The process environment is walked ONCE, and only for the literal GM_DIAGNOSTICS=1;
+// the GM_* overrides are looked up (in the same block) only when it is there.
+extern char** environ;
+namespace gm {
+static const char* env_lookup(const char* name) {
+    const size_t n = strlen(name);
+    for (char** e = environ; e && *e; ++e)
+        if (!strncmp(*e, name, n) && (*e)[n] == '=') return *e + n + 1;
+    return nullptr;
+}
+int diag_int(const char* name, int dflt) {
+    static const bool on = [] { const char* v = env_lookup("GM_DIAGNOSTICS"); return v && !strcmp(v, "1"); }();
+    if (!on) return dflt;
+    const char* v = env_lookup(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+}  // namespace gm
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -227,6 +245,7 @@ struct gm_acq {
     Timing tm;
     // composite transform size N = Q * plan->n (acq_composite.hip); Q == 1: the fused single-LDS-buffer kernels
     float* d_split_scratch = nullptr;      // partial power planes of the correlation grid's tail split
+    int split_planes = 0;                  // ... how many of them the scratch holds (sized from the handle's geometry at create)
     uint32_t* d_split_counter = nullptr;   // arrival tickets, one per split item, zero between launches
     uint32_t Q = 1, Nb = 0;
     const gm::CompOps* comp = nullptr;     // Q > 1: the (Q, base plan) kernels
@@ -269,13 +288,20 @@ static int acq_reserve_results(gm_acq* a, uint32_t n) {
     // results + found flags live in ONE host-pinned, device-visible block: decide_kernel writes its P x 41 bytes straight into
     // host memory and gm_acq_fetch_results is a stream synchronisation and a memcpy — the two device-to-host copies it used to
     // issue cost the host-buffer entry (gm_acq_search) ~25 us per dwell
-    if (a->d_results) { HIPC(hipStreamSynchronize(a->stream)); hipHostFree(a->d_results); hipFree(a->d_prn_ids); }
-    a->dev_prn_ids.clear();
+    // (the new blocks are allocated BEFORE the old ones go: a failed allocation leaves the handle as it was)
     void* blk = nullptr;
+    uint8_t* ids = nullptr;
     HIPC(hipHostMalloc(&blk, (sizeof(gm_acq_result) + 1) * size_t(n), hipHostMallocDefault));
+    if (hipError_t e = hipMalloc(&ids, n); e != hipSuccess) { hipHostFree(blk); return hip_fail(e, "hipMalloc(prn ids)"); }
+    if (a->d_results) {
+        if (hipError_t e = hipStreamSynchronize(a->stream); e != hipSuccess) { hipHostFree(blk); hipFree(ids); return hip_fail(e, "hipStreamSynchronize"); }
+        hipHostFree(a->d_results);
+        hipFree(a->d_prn_ids);
+    }
+    a->dev_prn_ids.clear();
     a->d_results = static_cast<gm_acq_result*>(blk);
     a->d_found = reinterpret_cast<uint8_t*>(a->d_results + n);
-    HIPC(hipMalloc(&a->d_prn_ids, n));
+    a->d_prn_ids = ids;
     a->results_cap = n;
     return GM_OK;
 }
@@ -555,6 +581,10 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     const gm::PlanOps* pl = gm::find_plan(int(cfg->fft_size));
     const gm::CompOps* comp = nullptr;
     uint32_t comp_q = 1;
+    if (pl && !cfg->strict_sum_order && !cfg->reference_products && gm::diag_int("GM_COMP_BASE", 0) > 0) {      // diagnostic: a size with a fused plan through the composite path
+        const gm::CompOps* c = gm::find_comp(cfg->fft_size);
+        if (c && c->nb == gm::diag_int("GM_COMP_BASE", 0)) pl = nullptr;
+    }
     if (!pl) {   // N = Q * Nb with Nb one of the composite base plans (largest first): acq_composite.hip
         comp = gm::find_comp(cfg->fft_size);
         if (comp) { pl = gm::find_plan(comp->nb); comp_q = uint32_t(comp->q); }
@@ -562,6 +592,8 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     if (!pl) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this fft_size, nor Q x {16000, 8000, 8192, 6000, 5000, 4000} with Q in {2,3,4,5,6,8}");
     if (cfg->strict_sum_order && comp_q > 1)
         return set_err(GM_ERR_INVALID_ARG, "strict_sum_order needs an fft_size with an in-LDS plan (gm_fft_supported_sizes)");
+    if (cfg->reference_products && comp_q > 1)
+        return set_err(GM_ERR_INVALID_ARG, "reference_products needs an fft_size with an in-LDS plan (gm_fft_supported_sizes)");
     if (int rc = ensure_device(g_device)) return rc;
 
     gm_acq* a = new gm_acq();
@@ -632,12 +664,20 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     a->samples_cap = M * N * 8;
     HIPA(hipMalloc(&a->d_samples, a->samples_cap));
     HIPA(hipMalloc(&a->d_metrics, 3 * P * D * 4));
-    HIPA(hipMemset(a->d_metrics, 0, 3 * P * D * 4));
+    HIPA(hipMemsetAsync(a->d_metrics, 0, 3 * P * D * 4, a->stream));
     HIPA(hipMalloc(&a->d_worker_list, P * 4));
     if (a->Q == 1 && pl->split_slab && M >= 2) {
-        HIPA(hipMalloc(&a->d_split_scratch, size_t(gm::GM_CORR_SPLIT_MAX_SLABS) * pl->split_slab * sizeof(float)));
+        // planes the tail split can ever use for THIS handle: every item cut (small grids: P*D items x M planes), or per XCD one
+        // resident round of parts (64 slots; an item's M planes each) — never more than GM_CORR_SPLIT_MAX_SLABS
+        // (a one-PRN AcquisitionWorker handle at N = 16368 takes 290 planes = 19 MB instead of 2560 = 251 MB)
+        size_t planes = size_t(8) * ((P * D + 7) / 8) * M;      // (the launcher deals items to the XCDs in equal shares of ceil(P*D / 8))
+        const size_t tail = size_t(8) * (64 + M);
+        if (planes < tail) planes = tail;
+        if (planes > size_t(gm::GM_CORR_SPLIT_MAX_SLABS)) planes = size_t(gm::GM_CORR_SPLIT_MAX_SLABS);
+        a->split_planes = int(planes);
+        HIPA(hipMalloc(&a->d_split_scratch, planes * pl->split_slab * sizeof(float)));
         HIPA(hipMalloc(&a->d_split_counter, gm::GM_CORR_SPLIT_MAX_ITEMS * sizeof(uint32_t)));
-        HIPA(hipMemset(a->d_split_counter, 0, gm::GM_CORR_SPLIT_MAX_ITEMS * sizeof(uint32_t)));
+        HIPA(hipMemsetAsync(a->d_split_counter, 0, gm::GM_CORR_SPLIT_MAX_ITEMS * sizeof(uint32_t), a->stream));
     }
     HIPA(hipMemcpy(a->d_tables, tables.data(), D * N * 8, hipMemcpyHostToDevice));
     HIPA(hipMemcpy(a->d_table_freq, a->table_freq.data(), D * 4, hipMemcpyHostToDevice));
@@ -718,7 +758,8 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     if (a->Q == 1) {
         a->plan->corr(a->stream, a->d_spectra, a->plan->code_paired ? a->d_code_fft_paired : a->d_code_fft, a->d_tw_inv, reinterpret_cast<float*>(met), met + PD,
                       reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M),
-                      a->d_split_scratch, a->d_split_counter, a->cfg.strict_sum_order ? 1 : 0, a->d_split_counter ? 1 : 0);
+                      a->d_split_scratch, a->split_planes, a->d_split_counter, a->cfg.strict_sum_order ? 1 : 0, a->d_split_counter ? 1 : 0,
+                      a->cfg.reference_products ? 1 : 0);
     } else if (a->n_workers) {
         a->comp->corr(a->stream, a->d_spectra, a->d_code_comb, a->d_comp_twn, a->d_tw_inv, reinterpret_cast<float*>(met),
                       met + PD, reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M));
@@ -1352,7 +1393,7 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
     HIPT(hipMemcpy(t->d_states, init.data(), sizeof(gm_trk_state) * t->C, hipMemcpyHostToDevice));
     HIPT(hipMalloc(&t->d_partials, sizeof(float) * t->C * size_t(t->slices) * 10));
     HIPT(hipMalloc(&t->d_ready, t->C));
-    HIPT(hipMemset(t->d_ready, 0, t->C));
+    HIPT(hipMemsetAsync(t->d_ready, 0, t->C, t->stream));      // (the handle's stream is non-blocking: a NULL-stream memset would not be ordered with it)
     HIPT(hipEventCreate(&t->ev0));
     HIPT(hipEventCreate(&t->ev1));
     {   // workgroups per channel for the persistent kernel: all n_channels*G must be co-resident (one per CU)
@@ -1372,20 +1413,21 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
             while (g > 1 && g * nv > 256) --g;
             if (g > 16 && g < 32) g = 16;
         }
-        if (const char* e = getenv("GM_TRK_G")) {   // diagnostic override (must keep n_channels * G resident)
-            const int f = atoi(e);
+        {   // diagnostic override (GM_DIAGNOSTICS=1 only; must keep n_channels * G resident)
+            const int f = gm::diag_int("GM_TRK_G", 0);
             if (f >= 1 && f <= 32 && size_t(f) * slots <= size_t(cus) * per_cu && f * nv <= 256) g = f;
         }
         t->G = g;
         const size_t xb = (size_t(2) * t->C * g * nv + size_t(t->C) * g) * sizeof(unsigned long long);   // partials + XCC_ID granules
         HIPT(hipMalloc(&t->d_xchg, xb));
-        HIPT(hipMemset(t->d_xchg, 0, xb));
+        HIPT(hipMemsetAsync(t->d_xchg, 0, xb, t->stream));
         HIPT(hipHostMalloc(reinterpret_cast<void**>(&t->d_error), sizeof(int), hipHostMallocDefault));   // read on the host after a stream sync: no copy
         *t->d_error = 0;
         HIPT(hipMalloc(&t->d_error_dev, sizeof(int)));
-        HIPT(hipMemset(t->d_error_dev, 0, sizeof(int)));
+        HIPT(hipMemsetAsync(t->d_error_dev, 0, sizeof(int), t->stream));
     }
     if (int rc = trk_reserve_epochs(t, 1)) return fail(rc);
+    HIPT(hipStreamSynchronize(t->stream));      // the clears above have landed before any caller-supplied stream (gm_trk_set_stream) can run a kernel
 #undef HIPT
     *out = t;
     return GM_OK;
@@ -1533,6 +1575,12 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
         // instead of the persistent kernel; the data gate of every pass reads the head as of this call, like the persistent form
         const float nn = roundf(t->dc.fs / (t->dc.nominal_code_rate / t->dc.code_len_f));
         if (int rc = trk_reserve_terms(t, (nn > 0 ? size_t(nn * 1.01f) : 0) + 64)) return rc;
+        // the strict launches (256 threads, 40-48 KB of LDS each) must not take CU slots away from another handle's persistent
+        // grid on this device either: same chain — wait for the previous launch of the device, record behind the last one
+        PersistChain& schain = g_persist_chain[t->device & 15];
+        std::lock_guard<std::mutex> schain_lock(schain.mu);
+        if (!schain.ev) HIPC(hipEventCreateWithFlags(&schain.ev, hipEventDisableTiming));
+        if (schain.armed) HIPC(hipStreamWaitEvent(t->stream, schain.ev, 0));
         if (t->timing) HIPC(hipEventRecord(t->ev0, t->stream));
         gm::TrkSrc src;
         src.base = ring->d_buf; src.mask = ring->mask; src.head = ring->head.load(std::memory_order_acquire); src.linear = 0; src.only_channel = -1;
@@ -1542,6 +1590,8 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
                                  t->d_outs + o, t->d_proc + o, t->d_lost + o, t->d_lostprn + o, t->d_terms, t->terms_cap, t->d_error);
         }
         if (t->timing) { HIPC(hipEventRecord(t->ev1, t->stream)); t->timed_launches = epochs; }
+        HIPC(hipEventRecord(schain.ev, t->stream));
+        schain.armed = true;
         HIPC(hipGetLastError());
         return GM_OK;
     }
@@ -1986,7 +2036,8 @@ struct gm_comm {
     // two events, so the next dwell's kernels on the handle's stream do not wait for it
     hipStream_t xs = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    bool pending = false;
+    hipEvent_t ev_sync = nullptr;  // behind the last SYNCHRONOUS exchange's regroup (it reads d_stage on the caller's stream)
+    bool pending = false, async_used = false, sync_used = false;
 };
 
 extern "C" {
@@ -2021,6 +2072,7 @@ int gm_comm_destroy(gm_comm* c) {
     if (c->xs) { hipStreamSynchronize(c->xs); hipStreamDestroy(c->xs); }
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_out) hipEventDestroy(c->ev_out);
+    if (c->ev_sync) hipEventDestroy(c->ev_sync);
     if (c->comm) rccl().CommDestroy(c->comm);
     hipFree(c->d_stage);
     delete c;
@@ -2039,7 +2091,14 @@ int gm_acq_allgather_metrics(gm_acq* a, gm_comm* c, const void* d_local, void* d
     if (!a || !c || !d_all) return set_err(GM_ERR_INVALID_ARG, "null handle/comm/output");
     if (a->device != c->device) return set_err(GM_ERR_INVALID_ARG, "handle and communicator live on different devices");
     if (int rc = ensure_device(a->device)) return rc;
-    return comm_gather_regroup(a, c, d_local, d_all, a->stream);
+    // d_stage is ONE buffer: an asynchronous exchange still running on the communicator's stream must have read it out before
+    // this one overwrites it (whether or not gm_comm_wait has been called for it yet, and on whichever stream)
+    if (c->async_used) HIPC(hipStreamWaitEvent(a->stream, c->ev_out, 0));
+    if (int rc = comm_gather_regroup(a, c, d_local, d_all, a->stream)) return rc;
+    if (!c->ev_sync) HIPC(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
+    HIPC(hipEventRecord(c->ev_sync, a->stream));
+    c->sync_used = true;
+    return GM_OK;
 }
 
 static int comm_gather_regroup(gm_acq* a, gm_comm* c, const void* d_local, void* d_all, hipStream_t st) {
@@ -2070,9 +2129,11 @@ int gm_acq_allgather_metrics_async(gm_acq* a, gm_comm* c, const void* d_local, v
     }
     HIPC(hipEventRecord(c->ev_in, a->stream));          // everything enqueued so far on the handle's stream (the search)
     HIPC(hipStreamWaitEvent(c->xs, c->ev_in, 0));
+    if (c->sync_used) HIPC(hipStreamWaitEvent(c->xs, c->ev_sync, 0));     // ... and a synchronous exchange of ANOTHER handle through this communicator
     if (int rc = comm_gather_regroup(a, c, d_local, d_all, c->xs)) return rc;
     HIPC(hipEventRecord(c->ev_out, c->xs));
     c->pending = true;
+    c->async_used = true;
     return GM_OK;
 }
 

@@ -46,7 +46,8 @@ struct PlanOps {
     // {max, first argmax, sum} per (worker, bin)  (do_acquisition.rs:184-202, 229-235)
     void (*corr)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                  uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
-                 int n_int, float* split_scratch, uint32_t* split_counter, int strict_sum, int tickets_cleared);   // tickets_cleared: mix_fft(.., split_counter) ran just before on this stream
+                 int n_int, float* split_scratch, int split_planes, uint32_t* split_counter, int strict_sum, int tickets_cleared,
+                 int ref_mul);   // ref_mul: gm_acq_cfg.reference_products;   // split_planes: power planes the scratch holds (<= GM_CORR_SPLIT_MAX_SLABS); tickets_cleared: mix_fft(.., split_counter) ran just before on this stream
     // AcquisitionWorker::new's replica spectrum (do_acquisition.rs:132-138)
     void (*code_fft)(hipStream_t, const int8_t* code_samples, const cf* tw_fwd, cf* code_fft, int n_codes);
     // the same spectra re-stored in the paired layout stage C reads (PairLayout in acq_kernels.hip); stage F writes its
@@ -75,6 +76,10 @@ void launch_fine_final(hipStream_t, const float* rowmax, const uint32_t* rowarg,
 constexpr int GM_CORR_SPLIT_MAX_K = 16;
 constexpr int GM_CORR_SPLIT_MAX_SLABS = 8 * 320;
 constexpr int GM_CORR_SPLIT_MAX_ITEMS = 8 * 80;
+// Diagnostic overrides (item maps, tail split, workgroups per channel ...: tools/README.md).  The library reads NO environment
+// variable unless the process was started with GM_DIAGNOSTICS=1: a receiver that links this library must not change kernels
+// because its environment happens to carry a GM_* name.  diag_int returns `dflt` when diagnostics are off or `name` is unset.
+int diag_int(const char* name, int dflt);
 const PlanOps* find_plan(int n);
 int list_plans(uint32_t* sizes, int cap);
 

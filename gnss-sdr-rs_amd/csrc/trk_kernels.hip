@@ -28,7 +28,6 @@
 // and lanes/waves/slices combine as a fixed tree (deterministic; closer to the exact sum).
 #include "gm_internal.h"
 #include "gm_libm.h"
-#include <cstdlib>
 
 namespace gm {
 
@@ -1334,11 +1333,8 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     a.stamps = d_stamps;
     a.cfg = cfg; a.codes = d_codes; a.states = d_states; a.ring = ring; a.mask = mask; a.head = head;
     a.G = G; a.epochs = epochs; a.tag_base = tag_base;
-    { const char* z = getenv("GM_TRK_STAMP_WG"); a.stamp_block = z ? atoi(z) : 0; }
-    {
-        const char* e = getenv("GM_TRK_FORCE_SC1");
-        a.force_write_through = (e && atoi(e) != 0) ? 1 : 0;
-    }
+    a.stamp_block = diag_int("GM_TRK_STAMP_WG", 0);
+    a.force_write_through = diag_int("GM_TRK_FORCE_SC1", 0) != 0 ? 1 : 0;
     {   // slice length from the nominal code period (+1 % margin), whole wavefronts
         const float nn = roundf(cfg.fs / (cfg.nominal_code_rate / cfg.code_len_f));
         const uint64_t n_nom = nn > 0 ? uint64_t(nn * 1.01f) + 64 : 64;

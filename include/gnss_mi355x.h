@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GM_ABI_VERSION 4
+#define GM_ABI_VERSION 5
 
 typedef enum {
     GM_OK = 0,
@@ -131,6 +131,12 @@ typedef struct {
                                   eight running f32 sums over chunks_exact(8), then reduce_sum from -0.0 — and the
                                   integrations accumulated strictly in sequence (no grid-tail split); costs ~4 us per
                                   (worker, bin) workgroup.  In-LDS sizes only (fft_size one of gm_fft_supported_sizes()). */
+    int32_t reference_products; /* 0: `result_buf[i] *= conj(code_fft[i])` (:184-186) and `norm_sqr()` (:190-192) use two fused
+                                  multiply-adds each (one rounding fewer per component; 4 instead of 6 instructions per
+                                  element).  1: formed as num-complex forms them — every product and every sum rounded on its
+                                  own (re = a.re*b.re - a.im*b.im, im = a.re*b.im + a.im*b.re; re*re + im*im) — so that the only
+                                  arithmetic on the path that differs from the reference's is the FFT itself (rustfft's plan
+                                  cannot be restated here).  ~3 % slower.  In-LDS sizes only.  (ABI 5) */
 } gm_acq_cfg;
 typedef enum { GM_DECIDE_REFERENCE = 0, GM_DECIDE_BEST_BIN = 1 } gm_decision_mode;
 

@@ -1,14 +1,26 @@
-// mi355x.rs — raw bindings of include/gnss_mi355x.h for kewei/gnss-sdr-rs: the `extern "C"` block and
-// the #[repr(C)] mirrors.  The wrappers that carry the reference's own names and signatures live next to it:
-//   doppler_shift.rs   DopplerShiftTable::new, apply_doppler_shift                       (src/acquisition/doppler_shift.rs:5-40)
-//   do_acquisition.rs  AcquisitionWorker::{new, search_satellite}, AcquisitionEngine     (src/acquisition/do_acquisition.rs:130-226, 268-313)
-//   do_tracking.rs     TrackingChannel::{new, start, is_active, update, early_late_correlation, get_ca_chip,
-//                      run_loop_filters, reset}, TrackingManager::{new, process_channels} (src/tracking/do_tracking.rs:88-382)
-//   fft.rs             FFT<f32>, RealFFT<f32>                                            (src/fft.rs:5-56)
+// mi355x.rs — DESTINATION: src/mi355x.rs of kewei/gnss-sdr-rs (a NEW module; `pub mod mi355x;` is added to src/lib.rs after
+// `pub mod constants;`, lib.rs:14).  Raw bindings of include/gnss_mi355x.h: the `extern "C"` block and the
+// #[repr(C)] mirrors.  The wrappers that carry the reference's own names and signatures are its SUBMODULES — new sibling
+// modules of the reference's own, which stay in the crate untouched (nothing is edited in place, nothing is replaced):
+//   src/mi355x/doppler_shift.rs   DopplerShiftTable::new, apply_doppler_shift                 (cf. src/acquisition/doppler_shift.rs:5-40)
+//   src/mi355x/do_acquisition.rs  AcquisitionWorker::{new, search_satellite}, AcquisitionEngine, run
+//                                                                                              (cf. src/acquisition/do_acquisition.rs:130-226, 241-327)
+//   src/mi355x/do_tracking.rs     TrackingChannel (22 pub fields, every method), TrackingManager::{new, process_channels}, run
+//                                                                                              (cf. src/tracking/do_tracking.rs:88-415)
+//   src/mi355x/fft.rs             FFT<f32>, RealFFT<f32>                                       (cf. src/fft.rs:5-56)
+// They import the items that do NOT change (AcquisitionResult, AcqError, ChannelState, AcquisitionManager, LoopFilter,
+// TrackingMessage, TrackingError, MulticastRingBuffer, the reference's DopplerShiftTable) from the reference's modules.
+// main.rs switches two `use` lines (rust/patches/main_rs.diff); the thread wiring at main.rs:204-227 is unchanged.
 // Shipped as source: the build image has no Rust toolchain, so these files were NOT compiled here; the same ABI is
 // exercised end to end by gnss-sdr-rs_amd/host/gnss_sdr.hpp + tests/cpp/test_host_api.cpp (C++) and by the ctypes mirror
-// used in tests/ (Python); tests/test_abi_and_host.py checks struct layouts, extern names and wrapper signatures.
+// used in tests/ (Python); tests/test_abi_and_host.py checks struct layouts, extern names, wrapper signatures and that every
+// `use crate::...` path of these files names an item that exists in the reference's module tree or in these files.
 #![allow(non_camel_case_types, dead_code)]
+
+pub mod doppler_shift;
+pub mod do_acquisition;
+pub mod do_tracking;
+pub mod fft;
 
 // ------------------------------------------------------------------ raw bindings
 use num_complex::Complex32;
@@ -33,6 +45,7 @@ pub struct GmAcqCfg {               // gm_acq_cfg
     pub threshold: f32,
     pub decision_mode: i32,          // 0 = the reference's early exit (GM_DECIDE_REFERENCE), 1 = strongest bin
     pub strict_sum_order: i32,       // 1 = is_good_satellite's sum in the reference's 8-lane order (do_acquisition.rs:229-235)
+    pub reference_products: i32,     // 1 = x conj(code) and norm_sqr() rounded as num-complex rounds them (no fused multiply-add; :184-192)
 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct GmTrkState {             // gm_trk_state  <->  the evolving fields of TrackingChannel (do_tracking.rs:88-116)

@@ -1,6 +1,7 @@
-// do_tracking.rs — the items of src/tracking/do_tracking.rs that sit on the hot path, on the MI355X library.
-// Unchanged in the crate and therefore not repeated here: LoopFilter (:52-71), TrackingMessage (:47-50), TrackingError
-// (:31-45), the constants (:16-29), run() (:384-415: its loop calls process_channels exactly as before).
+// do_tracking.rs — DESTINATION: src/mi355x/do_tracking.rs (module crate::mi355x::do_tracking, a new sibling of
+// crate::tracking::do_tracking, which stays in the crate untouched).  The items of src/tracking/do_tracking.rs that sit on the
+// hot path, on the MI355X library.  Imported from the reference's module because they do not change: LoopFilter (:52-71),
+// TrackingMessage (:47-50), TrackingError (:31-45).  The reference's private constants (:16-29) are restated below.
 //
 //   * TrackingChannel keeps its 22 pub fields and every method signature (:88-327).  Each channel owns a ONE-channel
 //     handle; the evolving fields are written to the handle before a call and read back after it, so code that pokes the
@@ -12,9 +13,13 @@
 //     LOOP_MS = 10 per call (as many as the ring holds samples for).  Under run()'s loop (:391-414) the two are the same
 //     sequence of updates; a caller that interleaves its own work between calls sees channels advance by up to 10 code
 //     periods per call.  `gm_trk_update_all(.., 1, ..)` is the one-epoch form (PROCESS_EPOCHS below).
+//   * Fields poked between calls are honoured on the batched path too: process_channels writes every active channel's pub
+//     fields into the manager's handle before the launch (gm_trk_set_state) and reads them back after it.
+//   * run — the tracking stage's thread body with the reference's signature and control flow (:384-415): main.rs:216-227 calls
+//     it through `use gnss_sdr_rs::mi355x::do_tracking;` instead of `...::tracking::do_tracking;`.
 use crate::acquisition::do_acquisition::{AcquisitionResult, ChannelState};
 use crate::mi355x::*;
-use crate::tracking::do_tracking::{LoopFilter, TrackingMessage};
+use crate::tracking::do_tracking::{LoopFilter, TrackingError, TrackingMessage};
 use crate::utilities::multicast_ring_buffer::MulticastRingBuffer;
 use crossbeam_channel::{Receiver, Sender};   // the crate's channels (do_tracking.rs:8, main.rs:183-184)
 use num_complex::Complex32;
@@ -87,12 +92,15 @@ impl TrackingChannel {
                pll_filter: LoopFilter { tau1: p1, tau2: p2 }, dll_filter: LoopFilter { tau1: d1, tau2: d2 }, h }
     }
 
-    fn push(&self) {       // fields -> handle
-        let s = GmTrkState { prn: self.prn, active: self.is_active() as u8, reserved: [0; 2], lost_counter: self.lost_counter,
+    fn raw_state(&self) -> GmTrkState {      // the pub fields as the library's state record
+        GmTrkState { prn: self.prn, active: self.is_active() as u8, reserved: [0; 2], lost_counter: self.lost_counter,
             next_sample_index: self.next_sample_index as u64, num_samples_per_code: self.num_samples_per_code as u64,
             carrier_freq: self.carrier_freq, carrier_phase: self.carrier_phase, carrier_error: self.carrier_error,
             carrier_nco: self.carrier_nco, code_phase: self.code_phase, code_error: self.code_error, code_nco: self.code_nco,
-            code_rate: self.code_rate, i_prompt: self.i_prompt, q_prompt: self.q_prompt };
+            code_rate: self.code_rate, i_prompt: self.i_prompt, q_prompt: self.q_prompt }
+    }
+    fn push(&self) {       // fields -> handle
+        let s = self.raw_state();
         let st = unsafe { gm_trk_set_state(self.h, 0, &s) };
         assert_eq!(st, 0, "gm_trk_set_state: {}", last_error());
     }
@@ -233,6 +241,16 @@ impl TrackingManager {
             assert_eq!(st, 0, "gm_ring_write_samples: {}", last_error());
             self.mirrored += n;
         }
+        // the pub fields are the truth between calls (the reference's tests poke them): every active channel's fields go into
+        // the batched handle before the launch.  After a call they equal the device state (read back below), so this changes
+        // nothing unless the caller wrote a field.
+        for (i, ch) in self.channels.iter().enumerate() {
+            if ch.is_active() {
+                let s = ch.raw_state();
+                let st = unsafe { gm_trk_set_state(self.h, i as u32, &s) };
+                assert_eq!(st, 0, "gm_trk_set_state: {}", last_error());
+            }
+        }
         // channels.par_iter_mut().filter(is_active).for_each(update) (:364-371), up to PROCESS_EPOCHS code periods per call
         let n = self.channels.len();
         let mut lost = vec![0u8; PROCESS_EPOCHS * n];
@@ -261,4 +279,32 @@ impl TrackingManager {
 }
 impl Drop for TrackingManager {
     fn drop(&mut self) { unsafe { gm_trk_destroy(self.h); if !self.ring.is_null() { gm_ring_destroy(self.ring); } } }
+}
+
+/// The tracking stage (do_tracking.rs:384-415): same signature and control flow — wait on the ring's condvar until the
+/// earliest active channel has its next code period, then process_channels while data is there.
+pub fn run(
+    multi_ring_buf: Arc<MulticastRingBuffer>,
+    acq_to_trk: Receiver<AcquisitionResult>,
+    trk_to_acq: Sender<TrackingMessage>,
+    fs: f32,
+) -> Result<(), TrackingError> {
+    let mut manager = TrackingManager::new(acq_to_trk, trk_to_acq, fs);
+    loop {
+        let mut curr_head = multi_ring_buf.get_head();
+        let mut required_idx = manager.next_tracking_index();
+        if (curr_head.wrapping_sub(required_idx) as isize) < 0 {
+            let mut head_guard = multi_ring_buf.notifier.lock()?;
+            while (multi_ring_buf.get_head().wrapping_sub(manager.next_tracking_index()) as isize) < 0 {
+                head_guard = multi_ring_buf.condvar.wait(head_guard)?;
+            }
+            curr_head = multi_ring_buf.get_head();
+            drop(head_guard);
+        }
+        while (curr_head.wrapping_sub(required_idx) as isize) >= 0 {
+            manager.process_channels(multi_ring_buf.clone());
+            required_idx = manager.next_tracking_index();
+            curr_head = multi_ring_buf.get_head();
+        }
+    }
 }

@@ -1,4 +1,5 @@
-// doppler_shift.rs — src/acquisition/doppler_shift.rs on the MI355X library: same items, same signatures.
+// doppler_shift.rs — DESTINATION: src/mi355x/doppler_shift.rs (module crate::mi355x::doppler_shift; src/acquisition/doppler_shift.rs
+// stays as it is, and AcquisitionWorker below keeps taking ITS DopplerShiftTable).  Same items, same signatures, on the library:
 // `DopplerShiftTable::new` (:10-22) and `apply_doppler_shift` (:25-40) keep their meaning bit for bit: the table is built
 // on the host with the platform cosf/sinf exactly like the reference (gm_doppler_table_new), the product uses the
 // reference's rounding sequence (a*c - b*d, a*d + b*c, no FMA) and touches only the first 4*floor(n/4) outputs.

@@ -1,7 +1,9 @@
-// fft.rs — src/fft.rs (crate-root FFT<T> / RealFFT<T>, :5-56) on the MI355X library.  The reference is generic over
-// rustfft's FftNum; its only instantiations in the crate are f32, which is what the library computes in: the wrappers are
-// generic over a one-impl trait so that `FFT::<f32>::new(len)` keeps compiling unchanged.  Lengths: the in-LDS plans and
-// their four-step composites (gm_fft_supported_sizes); another length panics in `new` like an unsupported rustfft feature.
+// fft.rs — DESTINATION: src/mi355x/fft.rs (module crate::mi355x::fft; the crate-root src/fft.rs stays as it is).
+// FFT<T> / RealFFT<T> (src/fft.rs:5-56) on the MI355X library.  The reference is generic over rustfft's FftNum; its only
+// instantiations in the crate are f32, which is what the library computes in: the wrappers are generic over a one-impl trait
+// so that `FFT::<f32>::new(len)` keeps compiling unchanged.  Lengths: ANY length up to 2^23 — the in-LDS plans
+// (gm_fft_supported_sizes), their four-step composites, and Bluestein's algorithm for everything else (a length the library
+// refuses, e.g. 0 or beyond 2^23, panics in `execute` like an unsupported rustfft feature would).
 use crate::mi355x::*;
 use num_complex::Complex;
 

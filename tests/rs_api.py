@@ -58,3 +58,21 @@ def signatures(text):
             owner = ""
         out.setdefault(owner, {})[m.group(1)] = sig
     return out
+
+
+def mod_decls(text):
+    """names declared by `mod x;` / `pub mod x;` (declarations with a body `mod x { .. }` are inline modules: not files)"""
+    return re.findall(r"^\s*(?:pub(?:\([^)]*\))?\s+)?mod\s+(\w+)\s*;", text, re.M)
+
+
+def pub_items(text):
+    """names of the top-level pub items of a module's text: struct / enum / fn / const / static / trait / type / mod, and what its
+    `pub use` lines re-export.  Top level = the keyword `pub` starts its line (items inside impl / mod blocks are indented)."""
+    names = set(re.findall(r"^pub\s+(?:unsafe\s+)?(?:struct|enum|fn|const|static|trait|type|mod)\s+(?:mut\s+)?(\w+)", text, re.M))
+    for m in re.finditer(r"^pub\s+use\s+([^;]+);", text, re.M):
+        path = re.sub(r"\s+", "", m.group(1))
+        g = re.match(r"(.*)::\{(.*)\}$", path)
+        for n in (g.group(2).split(",") if g else [path]):
+            if n:
+                names.add(n.split("::")[-1])
+    return sorted(names)

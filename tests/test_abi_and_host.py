@@ -23,12 +23,25 @@ def test_header_symbols_all_exported(gm):
     exported = set(re.findall(r" T (gm_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
     assert not [s for s in re.findall(r" [TDB] (\S+)", nm) if not s.startswith("gm_")]   # nothing else leaks
-    assert gm.lib().gm_abi_version() == 4
+    assert gm.lib().gm_abi_version() == 5
 
 
 def test_library_links_no_oracle_and_no_torch(gm):
     out = subprocess.run(["ldd", gm.library_path()], stdout=subprocess.PIPE, text=True).stdout
     assert "liboracle" not in out and "torch" not in out and "libamdhip64" in out
+
+
+def test_library_reads_no_environment_variable_by_name(gm):
+    """a receiver that links the library must not get other kernels because its environment
+    carries a GM_* name.  The library imports neither getenv nor secure_getenv; its diagnostic overrides sit behind ONE gate
+    (gm::diag_int, gm_api.hip: a walk of `environ` for the literal GM_DIAGNOSTICS=1), and no kernel source calls getenv."""
+    out = subprocess.run(["nm", "-D", "--undefined-only", gm.library_path()], stdout=subprocess.PIPE, text=True).stdout
+    assert "getenv" not in out, [l for l in out.splitlines() if "getenv" in l]
+    csrc = os.path.join(ROOT, "gnss-sdr-rs_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, f)).read()
+        assert "getenv(" not in text, f
+        assert "GM_LAB_" not in text, f           # item 7b: no timing-ablation branches inside the shipped kernels
 
 
 def test_compute_entry_fails_loudly_without_device(gm):
@@ -167,7 +180,8 @@ def test_rust_binding_source_matches_the_abi(gm):
     doppler_shift.rs:5-40, do_tracking.rs:88-382, fft.rs:5-56)."""
     from gnss_sdr_rs_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    rs = {n: open(os.path.join(root, "rust", "src", n)).read()
+    # the layout under rust/src IS the destination layout in the crate: src/mi355x.rs + src/mi355x/{...}.rs (INTEGRATION.md §0)
+    rs = {n: open(os.path.join(root, "rust", "src", "mi355x.rs" if n == "mi355x.rs" else os.path.join("mi355x", n))).read()
           for n in ("mi355x.rs", "doppler_shift.rs", "do_acquisition.rs", "do_tracking.rs", "fft.rs")}
     src = rs["mi355x.rs"]
     hdr = open(os.path.join(root, "include", "gnss_mi355x.h")).read()
@@ -249,9 +263,52 @@ def test_rust_binding_source_matches_the_abi(gm):
         "carrier_freq", "carrier_phase", "carrier_error", "carrier_nco", "code_phase", "code_error", "code_nco", "code_rate",
         "cos_p", "sin_p", "i_prompt", "q_prompt", "pll_filter", "dll_filter"]
     assert rust_fields(rs["do_tracking.rs"], "TrackingManager") == ["channels", "acq_to_trk", "trk_to_acq"]
-    # and INTEGRATION.md carries the same bindings
+    # the stage drivers keep the reference's signatures too (do_acquisition.rs:241-247, do_tracking.rs:384-389)
+    for name in ("do_acquisition.rs", "do_tracking.rs"):
+        assert signatures(strip_comments(rs[name]))[""]["run"] == ref[name]["pub_fn"][""]["run"], name
+
+    # ---- where the files go, and that every path they name resolves ----
+    # module tree of the crate as the reference has it (names only, tests/golden/make_api_signatures.py) + the shipped modules
+    from rs_api import mod_decls, pub_items
+    tree = {k: (set(v) if v is not None else None) for k, v in ref["_module_tree"].items()}
+    shipped = {"crate::mi355x": set(pub_items(strip_comments(rs["mi355x.rs"])))}
+    assert mod_decls(strip_comments(rs["mi355x.rs"])) == ["doppler_shift", "do_acquisition", "do_tracking", "fft"]
+    for sub in mod_decls(strip_comments(rs["mi355x.rs"])):
+        assert os.path.exists(os.path.join(root, "rust", "src", "mi355x", sub + ".rs")), sub
+        shipped["crate::mi355x::" + sub] = set(pub_items(strip_comments(rs[sub + ".rs"])))
+    assert "mi355x" not in ref["_lib_rs_mods"] and "crate::mi355x" not in tree          # a NEW module: nothing is replaced
+    n_paths = 0
+    for name, text in rs.items():
+        for sym, path in imports(strip_comments(text)).items():
+            if not path.startswith("crate"):
+                continue
+            n_paths += 1
+            where = shipped if path.startswith("crate::mi355x") else tree
+            assert path in where and where[path] is not None, (name, path, "no such module")
+            if sym != "*":
+                assert sym in where[path], (name, path, sym, "no such pub item in that module")
+    assert n_paths >= 14, n_paths
+    # none of the wrappers imports from a module it claims to replace: they are siblings, and say so
+    for name in ("doppler_shift.rs", "do_acquisition.rs", "do_tracking.rs", "fft.rs"):
+        assert "DESTINATION: src/mi355x/%s" % name in rs[name], name
+    assert "DESTINATION: src/mi355x.rs" in rs["mi355x.rs"]
+    # the three patches: lib.rs gains `pub mod mi355x;` behind its last module; main.rs switches exactly the two stage modules,
+    # and the lines it removes are the reference's own imports
+    lib_diff = open(os.path.join(root, "rust", "patches", "lib_rs.diff")).read()
+    assert "+pub mod mi355x;" in lib_diff and " pub mod %s;" % ref["_lib_rs_mods"][-1] in lib_diff
+    main_diff = open(os.path.join(root, "rust", "patches", "main_rs.diff")).read()
+    removed = [l[1:].strip() for l in main_diff.splitlines() if l.startswith("-") and not l.startswith("---")]
+    added = [l[1:].strip() for l in main_diff.splitlines() if l.startswith("+") and not l.startswith("+++")]
+    assert removed == ["use gnss_sdr_rs::acquisition::do_acquisition;", "use gnss_sdr_rs::tracking::do_tracking;"]
+    assert added == ["use gnss_sdr_rs::mi355x::do_acquisition;", "use gnss_sdr_rs::mi355x::do_tracking;"]
+    mi = ref["_main_rs_imports"]
+    assert mi["do_acquisition"] == "gnss_sdr_rs::acquisition" and mi["do_tracking"] == "gnss_sdr_rs::tracking"
+    assert mi["AcquisitionResult"] == "gnss_sdr_rs::acquisition::do_acquisition" and mi["TrackingMessage"] == "gnss_sdr_rs::tracking::do_tracking"
+    # and INTEGRATION.md says the same
     integ = open(os.path.join(root, "INTEGRATION.md")).read()
-    assert "pub strict_sum_order: i32" in integ and "pub fn search_satellite(" in integ and "pub fn process_channels(" in integ
+    for needle in ("src/mi355x.rs", "src/mi355x/do_acquisition.rs", "src/mi355x/do_tracking.rs", "src/mi355x/doppler_shift.rs",
+                   "src/mi355x/fft.rs", "pub mod mi355x;", "use gnss_sdr_rs::mi355x::do_acquisition;", "use gnss_sdr_rs::mi355x::do_tracking;"):
+        assert needle in integ, needle
 
 
 def test_beidou_b1i_codes_known_properties(gm):

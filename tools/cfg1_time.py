@@ -20,3 +20,5 @@ for _ in range(30):
     eng.search_dev(x.data_ptr(), A.FMT_I8_REAL); eng.decide_dev()
 torch.cuda.synchronize()
 print("split env", os.environ.get("GM_CORR_SPLIT"), eng.timing_summary())
+res = eng.fetch_results()
+print("found", [(r["prn"], r["code_phase_samples"], r["doppler_bin"], round(r["mag_relative"], 1)) for r in res if r])

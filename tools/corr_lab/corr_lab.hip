@@ -7,10 +7,19 @@
 #define LAB_PLAN gm::Plan8000
 #endif
 #define GM_FOR_EACH_PLAN(X) X(LAB_PLAN)
+#ifdef LAB_WAVES_PER_EU      // the same plan under a register cap (e.g. 4 waves per SIMD = 128 VGPRs: what two 512-lane workgroups per CU would leave each lane)
+#include "../../gnss-sdr-rs_amd/csrc/fft_core.h"
+struct LabCapped : LAB_BASE_PLAN { static constexpr int WAVES_PER_EU = LAB_WAVES_PER_EU; };
+#endif
+#ifndef LAB_REF_MUL
+#define LAB_REF_MUL 0      // 1: gm_acq_cfg.reference_products (num-complex rounding of the products)
+#endif
 #ifndef LAB_SRC
 #define LAB_SRC "../../gnss-sdr-rs_amd/csrc/acq_kernels.hip"
 #endif
 #include LAB_SRC
+// the laboratory reads its overrides straight from the environment (the product library's gate is gm_api.hip's diag_int)
+namespace gm { int diag_int(const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; } }
 #include <cstdio>
 #include <vector>
 #include <random>
@@ -37,7 +46,7 @@ int main(int argc, char** argv) {
     hipMemcpy(dtw, htw.data(), htw.size() * 8, hipMemcpyHostToDevice);
     std::vector<uint32_t> hwl(P); for (int i = 0; i < P; ++i) hwl[i] = i;
     hipMemcpy(wl, hwl.data(), P * 4, hipMemcpyHostToDevice);
-    auto go = [&]() { pl->corr(0, dx, dc, dtw, met, reinterpret_cast<uint32_t*>(met) + P * D, met + 2 * P * D, wl, P, D, M, scratch, counter, 0, 0); };
+    auto go = [&]() { pl->corr(0, dx, dc, dtw, met, reinterpret_cast<uint32_t*>(met) + P * D, met + 2 * P * D, wl, P, D, M, scratch, GM_CORR_SPLIT_MAX_SLABS, counter, 0, 0, LAB_REF_MUL); };
     for (int i = 0; i < 3; ++i) go();
     hipDeviceSynchronize();
     std::vector<float> t;
