@@ -169,15 +169,21 @@ def test_thirty_two_one_prn_workers_at_the_reference_geometry(gpu, oracle):
     """The reference's own set-up (do_acquisition.rs:268-271): 32 AcquisitionWorkers, one PRN each, N = 16368.  Each handle's
     split scratch is sized from its geometry (290 planes, not 2560): the 32 handles take ~0.6 GB of scratch instead of 8 GB,
     and the searches (every item cut into its 10 integrations) still find what one 32-PRN handle finds."""
-    import torch
+    import ctypes as C
     from gnss_sdr_rs_amd import acquisition as A, synth
     cap = json.load(open(os.path.join(ROOT, "tests", "golden", "capture_config.json")))
     sc = synth.cfg1_scene(oracle.ca_code_table(), cap)
     x = synth.to_i8_real(sc["x"])
-    free0 = torch.cuda.mem_get_info()[0]
+    hip = C.CDLL("libamdhip64.so.7")          # the runtime the product library already loaded (no PyTorch in this test)
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+    free0 = free_bytes()
     workers = [A.AcquisitionEngine(sc["fs"], sc["f_if"], sc["N"], doppler_hz=sc["doppler_hz"], n_integrations=sc["M"], prn_ids=[p])
                for p in range(1, 33)]
-    used = free0 - torch.cuda.mem_get_info()[0]
+    used = free0 - free_bytes()
     assert used < 4.0e9, used        # spectra 38 MB + tables 3.8 MB + scratch 19 MB + ... per handle
     found = {}
     for p, w in zip(range(1, 33), workers):
@@ -190,3 +196,4 @@ def test_thirty_two_one_prn_workers_at_the_reference_geometry(gpu, oracle):
     eng.close()
     assert found == {r["prn"]: (r["code_phase_samples"], r["doppler_bin"]) for r in res if r}
     assert len(found) >= 8
+
