@@ -494,6 +494,13 @@ def main():
         except Exception as e:
             out["fine_doppler"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ configs[1] with ONE integration ("also report M = 1")
+    if rank == 0 and world == 1:
+        try:
+            out["cfg2_single_integration"] = m1_leg(torch, dev, stream, sc, A, synth, xi8)
+        except Exception as e:
+            out["cfg2_single_integration"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ three dwells in flight (informative, never `value`)
     if rank == 0 and world == 1 and args.three_dwells:
         try:
@@ -557,6 +564,13 @@ def main():
         except Exception as e:
             out["frontend"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ the whole receiver chain, informative
+    if rank == 0 and world == 1 and os.environ.get("GM_BENCH_NO_RECEIVER") != "1":
+        try:
+            out["receiver"] = receiver_leg(ca, A, T, synth, not args.no_cpu_baseline)
+        except Exception as e:
+            out["receiver"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc, args.cpu_seconds)
@@ -567,6 +581,42 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def m1_leg(torch, dev, stream, sc, A, synth, xi8):
+    """BASELINE configs[1] with M = 1: the same 32 PRN x 41 bins x 8000 phases on the FIRST millisecond of the bench scene, one
+    coherent integration and no non-coherent sum (SURVEY §8's "also report M = 1"; the reference's LONG_SAMPLES_LENGTH is 10).
+    1312 single-transform workgroups: the launch is 2.56 rounds of ONE transform each, so it is bound by launch + one transform's
+    latency per round, not by issue.  Informative, never `value`."""
+    P, D, N = 32, int(sc["doppler_hz"].size), sc["N"]
+    eng = A.AcquisitionEngine(sc["fs"], sc["f_if"], N, doppler_hz=sc["doppler_hz"], n_integrations=1)
+    eng.set_stream(stream)
+    d_x = torch.from_numpy(np.ascontiguousarray(xi8[:N])).to(dev)
+    d_met = torch.zeros(3 * P * D, dtype=torch.int32, device=dev)
+    for _ in range(5):
+        eng.search_dev(d_x.data_ptr(), A.FMT_I8_IQ, d_met.data_ptr()); eng.decide_dev(d_met.data_ptr())
+    torch.cuda.synchronize()
+    eng.enable_timing(5)
+    K = 100
+    t0 = time.perf_counter()
+    for _ in range(K):
+        eng.search_dev(d_x.data_ptr(), A.FMT_I8_IQ, d_met.data_ptr()); eng.decide_dev(d_met.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    ts = eng.timing_summary()
+    res = eng.fetch_results(P)
+    mx, am, _ = eng.metrics()
+    # one integration of 8000 cells: max / mean of a noise-only plane is ~ln(8000) = 9 > 7, so the reference's detector declares EVERY
+    # PRN at its first Doppler bin (the oracle does the same) — M = 1 is a throughput figure, not a usable detector.  The check is on
+    # the planes: the strongest bin of each strong satellite peaks at its true code phase.
+    strong = {s_["prn"]: s_["code_start"] for s_ in sc["sats"] if s_["cn0_dbhz"] >= 47.0}
+    ok = all(int(am[p_ - 1][int(np.argmax(mx[p_ - 1]))]) == c_ for p_, c_ in strong.items())
+    eng.close()
+    return {"workload": "32 PRN x 41 bins x 8000 phases, ONE 1 ms integration (M = 1), 8 Msps complex int8", "integrations": 1,
+            "ms_per_dwell": dt * 1e3, "cells_per_s": P * D * N / dt, "cell_integrations_per_s": P * D * N / dt,
+            "corr_kernel_ms": ts["avg_corr_ms"], "mix_fft_kernel_ms": ts["avg_mix_fft_ms"],
+            "strong_satellites_peak_at_true_phase": bool(ok), "prns_declared_by_the_reference_detector": sum(1 for r in res if r),
+            "note": "max/mean > 7 passes on noise with one integration of 8000 cells (ln 8000 = 9): every PRN is declared, as by the reference"}
 
 
 def cfg4_leg(torch, dev, A, synth):
@@ -895,6 +945,187 @@ def cfg5_leg(torch, stream, T, world=1, rank=0, dist=None, dev=None, debug_gloo=
             "channels_per_rank": [len(Dm.shard_prns(list(range(C)), world, r)) for r in range(world)],
             "ch_msps": C * fs / 1e6 * (sig_s / dt), "ms_per_code_period": dt / periods * 1e3, "channels_locked": locked,
             "algorithmic_GBs": C * n * 8 * periods / dt / 1e9}
+
+
+def receiver_leg(ca, A, T, synth, with_cpu, cpu_seconds=8.0, n_ms=3200, prefix_only_ms=None):
+    """SURVEY §8 f1 as ONE chain, the receiver main.rs:182-227 wires: a feeder (the SDR's sample blocks) -> the digital front-end
+    writing the device ring (rf_thread's block step, rf/rf_thread.rs:43-48: gm_frontend_write_ring) -> do_acquisition::run's
+    snapshot + search on the ring (:297-313, the AcquisitionManager's pacing counted in SIGNAL time) + fine Doppler ->
+    TrackingChannel::start -> TrackingManager::process_channels on the same ring (15 channels, the reference's constants, FIXED
+    code index) -> bit sync / nav bits / preamble on every channel's prompt I.  3.2 s of int8 IQ at the reference capture's
+    16.3676 Msps / 4.1304 MHz IF (N = 16368), eight satellites with 50 bit/s data; n_ms = 3200 by default (frame sync needs ~3 s).  One host thread drives it block by block
+    (16 ms blocks); reported: sustained Msps and x real time over the whole chain, when the first satellite was handed to
+    tracking / bit-synchronised / frame-synchronised (signal time and wall clock), and the wall clock per stage.  Informative,
+    never `value`.  The same chain is parity-tested in tests/test_gpu_pipeline.py::test_full_chain_frontend_to_nav_bits."""
+    from gnss_sdr_rs_amd import decoding as Dm, frontend as F
+    fs, f_if, N, M = 16_367_600.0, 4_130_400.0, 16368, 10
+    if prefix_only_ms:
+        n_ms = prefix_only_ms
+    rng = np.random.default_rng(11)
+    sats = []
+    for i, (prn, cn0) in enumerate([(2, 50.0), (5, 48.0), (9, 47.0), (13, 46.0), (17, 46.0), (22, 45.0), (26, 44.0), (30, 44.0)]):
+        data = rng.integers(0, 2, 200) * 2 - 1
+        for at in range(10 + i, 190, 30):
+            data[at:at + 8] = Dm.GPS_CA_PREAMBLE
+        sats.append(dict(prn=prn, prn_row=prn - 1, cn0_dbhz=cn0, doppler_hz=float(rng.uniform(-5500, 5500)), code_start=int(rng.integers(0, N)),
+                         phase=0.3 * i, data_bits=data, bit_edge_ms=int(rng.integers(0, 20))))
+    t_gen = time.perf_counter()
+    # the front-end's mix (nco_lut.rs:8-15) brings a spectrally INVERTED IF stream to baseband at +Doppler: that is what is fed
+    x = np.conj(synth.make_scene(ca, fs, f_if, n_ms * N, sats, config_id=12))
+    x += (5.0 - 3.0j)                                               # a DC offset for the front-end to remove
+    xi8 = synth.to_i8_iq(np.clip(x.real, -127, 127) + 1j * np.clip(x.imag, -127, 127))
+    del x
+    t_gen = time.perf_counter() - t_gen
+    BLK = 1 << 18                                                   # 16 ms per block
+    dop = np.arange(-7000.0, 7000.1, 500.0, dtype=np.float32)       # do_acquisition.rs:248-255
+    ring = T.MulticastRingBuffer(1 << 23)                           # 0.5 s of samples (the reference: 2^20)
+    fe = F.DigitalFrontend(f_if, fs, fs)
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, n_integrations=M, decision_mode=A.DECIDE_BEST_BIN)
+    mgr = T.TrackingManager(fs, n_channels=15, code_index_mode=T.CODE_INDEX_FIXED)
+    amgr = A.AcquisitionManager()
+    navs = [Dm.NavSyncStatus(Dm.NAV_FIXED) for _ in range(15)]
+    nav_old, nav_cnt, nav_st = [0.0] * 15, [0] * 15, [None] * 15
+    chan_prn, active = {}, set()
+    # warm the kernels (first launches load code objects): a scratch search + tracking pass on a scratch ring, outside the timed region
+    wring = T.MulticastRingBuffer(1 << 18)
+    wfe = F.DigitalFrontend(f_if, fs, fs)
+    wfe.write_ring(wring, xi8[:12 * N]); wring.flush()
+    eng.search_ring(wring)
+    wm = T.TrackingManager(fs, n_channels=15, code_index_mode=T.CODE_INDEX_FIXED)
+    wm.channels[0].start(dict(prn=1, code_phase_samples=0, code_phase_chips=0.0, carrier_freq=0.0, fs=fs, mag_relative=1.0, sample_global_index=0, doppler_bin=0))
+    wm.update_all(wring, 2); wm.close(); wfe.close(); wring.close()
+
+    # start-up, not throughput: the first write of a ring creates its pinned staging slots, its copy stream and its publisher
+    # thread (~0.12 s, once per ring).  The first 64 samples of the stream (4 us of signal) go in before the clock starts.
+    PRE = 64
+    fe.write_ring(ring, xi8[:PRE]); ring.flush()
+    stage = dict(frontend=0.0, acquisition=0.0, fine_doppler=0.0, tracking=0.0, nav_bits=0.0)
+    events = {}
+    next_acq_ms, dwells, epochs_run, fe_blocks = 10.0, 0, 0, []
+    t_start = time.perf_counter()
+    for off in range(PRE, n_ms * N, BLK):
+        t0 = time.perf_counter()
+        fe.write_ring(ring, xi8[off:off + BLK]); ring.flush()
+        head = ring.get_head()
+        t1 = time.perf_counter(); stage["frontend"] += t1 - t0
+        fe_blocks.append(t1 - t0)
+        sig_ms = head / fs * 1e3
+        # ---- do_acquisition::run's loop body, paced in signal time (:287-295: interval from the manager, then a snapshot ending at head)
+        if sig_ms >= next_acq_ms:
+            amgr.update_mode(len(active))
+            interval_ms, mask = amgr.get_pacing_and_list(active)
+            res, local_tail = eng.search_ring(ring, prn_mask=mask)
+            t2 = time.perf_counter(); stage["acquisition"] += t2 - t1
+            dwells += 1
+            if res:
+                hits = [r if (r and r["prn"] not in active) else None for r in res]
+                if any(hits):
+                    fine = eng.finer_doppler(hits)
+                    for r, f_ in zip(hits, fine):
+                        if r and f_:
+                            ch = next((c for c in range(15) if not mgr.channels[c].is_active() and c not in chan_prn), None)
+                            if ch is None:
+                                continue
+                            mgr.channels[ch].start(dict(r, carrier_freq=f_["freq_hz"]))     # TrackingChannel::start (:148-153)
+                            chan_prn[ch] = r["prn"]; active.add(r["prn"])
+                            events.setdefault("first_handover", (sig_ms, time.perf_counter() - t_start))
+                stage["fine_doppler"] += time.perf_counter() - t2
+            next_acq_ms = sig_ms + interval_ms
+            t1 = time.perf_counter()
+        # ---- TrackingManager::process_channels until the ring's head (do_tracking.rs:407-413)
+        if chan_prn:
+            outs, proc, lost, done = mgr.update_all(ring, BLK // N + 2)
+            t3 = time.perf_counter(); stage["tracking"] += t3 - t1
+            epochs_run += int(proc.sum())
+            for ch in chan_prn:                                        # nav_decoding's per-epoch step on the prompt I (decoding.rs:102-145)
+                for e in np.nonzero(proc[:, ch])[0]:
+                    ipv = float(outs[e, ch, 0])
+                    st = navs[ch].update(nav_old[ch], ipv, nav_cnt[ch])
+                    nav_old[ch], nav_cnt[ch], nav_st[ch] = ipv, nav_cnt[ch] + 1, st
+                    if st["flag_bit_sync"]:
+                        events.setdefault("first_bit_sync", (sig_ms, time.perf_counter() - t_start))
+                    if st["flag_frame_sync"]:
+                        events.setdefault("first_frame_sync", (sig_ms, time.perf_counter() - t_start))
+            stage["nav_bits"] += time.perf_counter() - t3
+            for ch in list(chan_prn):
+                if lost[:, ch].any():
+                    active.discard(chan_prn.pop(ch))
+    wall = time.perf_counter() - t_start
+    sig_s = n_ms * 1e-3
+    truth = {s_["prn"]: s_ for s_ in sats}
+    locked = 0
+    for ch, prn in chan_prn.items():
+        st = mgr.channels[ch].state
+        if st.active and prn in truth and abs(st.carrier_freq - truth[prn]["doppler_hz"]) < 25.0:
+            locked += 1
+    out = {"workload": "feeder -> digital front-end -> device ring -> acquisition (32 PRN x 29 bins x 16368, 10 ms) + fine Doppler -> 15-channel "
+                       "tracking -> bit sync / nav bits; %.1f s of int8 IQ at 16.3676 Msps, IF 4.1304 MHz, 8 satellites, 16 ms blocks, one host thread" % sig_s,
+           "signal_seconds": sig_s, "wall_seconds": wall, "x_real_time": sig_s / wall, "sustained_msps": n_ms * N / wall / 1e6,
+           "dwells": dwells, "channel_epochs": epochs_run, "satellites_in_scene": len(sats), "channels_started": len(chan_prn),
+           "channels_on_true_doppler": locked,
+           "channels_bit_synchronised": sum(1 for ch in chan_prn if nav_st[ch] and nav_st[ch]["flag_bit_sync"]),
+           "channels_frame_synchronised": sum(1 for ch in chan_prn if nav_st[ch] and nav_st[ch]["flag_frame_sync"]),
+           "events_signal_ms_and_wall_s": {k: {"signal_ms": v[0], "wall_s": v[1]} for k, v in events.items()},
+           "wall_seconds_per_stage": stage, "frontend_block_seconds": {"first": fe_blocks[0], "median": float(np.median(fe_blocks)), "max_after_first": float(max(fe_blocks[1:]))},
+           "scene_generation_seconds": t_gen,
+           "bound": "the host: %d front-end + %d tracking + %d acquisition calls, each a launch and a synchronisation, and one nav-bit step per "
+                    "channel-epoch through ctypes; the GPU is idle most of the time (DESIGN 5)" % (-(-n_ms * N // BLK), -(-n_ms * N // BLK), dwells)}
+    for o in navs:
+        o.close()
+    mgr.close(); eng.close(); fe.close(); ring.close()
+    if with_cpu:
+        try:
+            out["cpu_oracle_chain"] = receiver_cpu_chain(ca, xi8, fs, f_if, N, M, dop, sats, cpu_seconds)
+        except Exception as e:
+            out["cpu_oracle_chain"] = {"error": repr(e)}
+    return out
+
+
+def receiver_cpu_chain(ca, xi8, fs, f_if, N, M, dop, sats, budget_s):
+    """The oracle's restatement of the same chain on this host, stage by stage on bounded samples of the same stream: the
+    front-end (one thread: its recurrences are sequential), one 32-PRN acquisition dwell (min(32, nproc) threads, early exit as
+    in the reference), eight tracking channels (one thread each), nav-bit steps.  seconds of CPU wall clock per second of signal
+    = front-end + dwells per second x dwell + tracking + nav; x real time = its inverse (stages run one after the other here; the
+    reference runs them as threads, so max(...) is its optimistic bound and is reported too)."""
+    from oracle import oracle as O
+    O.build(native=True)
+    nthreads = min(32, os.cpu_count() or 1)
+    n_fe = min(xi8.shape[0], 1 << 22)
+    ofe = O.DigitalFrontend(f_if, fs, fs, native=True)
+    xf = xi8[:n_fe].astype(np.float32).reshape(-1)
+    t0 = time.perf_counter()
+    ofe.process_block(xf)
+    fe_s = (time.perf_counter() - t0) / (n_fe / fs)
+    base = xf.view(np.complex64)[:60 * N].copy()                      # 60 ms of front-end output for the other stages
+    tables = [O.DopplerShiftTable(0.0, float(d), fs, N) for d in dop]
+    workers = [O.AcquisitionWorker(p, N, fs, native=True) for p in range(1, 33)]
+    t0 = time.perf_counter()
+    res, cells = O.search_all(workers, 0xFFFFFFFF, base[:M * N], tables, 0, M, n_threads=nthreads, native=True)
+    acq_s = time.perf_counter() - t0
+    ring = O.MulticastRingBuffer(1 << 20)
+    ring.write_samples(base)
+    chans = []
+    for i, s_ in enumerate(sats):
+        ch = O.TrackingChannel(i, fs, code_index_mode=O.CODE_INDEX_FIXED)
+        ch.start(dict(prn=s_["prn"], code_phase_samples=0, code_phase_chips=0.0, carrier_freq=s_["doppler_hz"], fs=fs, mag_relative=1.0,
+                      sample_global_index=s_["code_start"]))
+        chans.append(ch)
+    O.process_channels(chans, ring, 2, n_threads=min(nthreads, len(chans)), native=True)
+    t0 = time.perf_counter()
+    got = O.process_channels(chans, ring, 50, n_threads=min(nthreads, len(chans)), native=True)
+    trk_s = (time.perf_counter() - t0) / max(got, 1) * len(chans) * 1000.0 / 1.0       # per channel-epoch x 8 channels x 1000 epochs per second
+    nav = O.NavSyncStatus(fixed=True)
+    t0 = time.perf_counter()
+    for e in range(2000):
+        nav.update(1.0, -1.0 if (e // 20) & 1 else 1.0, e)
+    nav_s = (time.perf_counter() - t0) / 2000 * len(sats) * 1000.0
+    dwells_per_s = 0.5                                                # steady state: one dwell per 2 s (do_acquisition.rs:57-61)
+    total = fe_s + dwells_per_s * acq_s + trk_s + nav_s
+    return {"kind": "port", "cores": nthreads, "cpu": cpu_model(),
+            "seconds_per_signal_second": {"frontend_1_thread": fe_s, "acquisition_dwell_s": acq_s, "tracking_8_channels": trk_s, "nav_bits": nav_s,
+                                          "total_sequential": total},
+            "x_real_time_sequential": 1.0 / total, "x_real_time_if_stages_overlap_perfectly": 1.0 / max(fe_s, dwells_per_s * acq_s, trk_s, nav_s),
+            "sample": "front-end: %.2f s of the stream; acquisition: one 32-PRN dwell (%d threads); tracking: 50 epochs x 8 channels" % (n_fe / fs, nthreads)}
 
 
 def frontend_leg(torch, dev, with_cpu):
