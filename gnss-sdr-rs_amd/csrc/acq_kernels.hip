@@ -483,6 +483,11 @@ __global__ __launch_bounds__(CorrPlanOf<PLX>::type::T, CorrPlanOf<PLX>::type::WA
     }
 }
 
+}  // namespace gm
+// stage C of N = 16368 (prime-factor plan ending in radix 31): the wave-specialised kernel with the radix-31 pass on the matrix pipe
+#include "acq_corr_ws31.h"
+namespace gm {
+
 // ------------------------------------------------------------------------------------ replica spectrum
 template <class PL>
 __global__ __launch_bounds__(PL::T) void acq_code_fft_kernel(const int8_t* __restrict__ code_samples,
@@ -725,7 +730,13 @@ template <class PL> struct Launch {
                            tables, tw_fwd, spectra, n_int, clear_tickets, order);
     }
     static int fill_order(uint16_t* order) { return fill_order_table<CP>(order); }
-    static constexpr int SPLIT_SLAB = CP::ITL * ((CP::RL + 3) / 4) * 4 * CP::T;   // floats per power plane of the tail split
+    static constexpr bool WS31 = Ws31<CP>::USE && CorrMode<CP>::PFA;      // stage C runs acq_corr_ws31_kernel (acq_corr_ws31.h)
+    static constexpr int slab() {
+        constexpr int generic = CP::ITL * ((CP::RL + 3) / 4) * 4 * CP::T;
+        if constexpr (WS31) return ws31_split_slab<CP>() > generic ? ws31_split_slab<CP>() : generic;
+        else return generic;
+    }
+    static constexpr int SPLIT_SLAB = slab();                             // floats per power plane of the tail split
     static void corr(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
                      int n_int, float* split_scratch, int split_planes, uint32_t* split_counter, int strict_sum, int tickets_cleared,
@@ -789,6 +800,17 @@ template <class PL> struct Launch {
         // must not leave a count behind that makes a later dwell merge early): the whole ticket block, a multiple of 16 bytes
         // at the start of its allocation (cdna_hip_programming.md G16 "Re-initialise every call")
         if (split_k > 1 && !tickets_cleared) (void)hipMemsetAsync(split_counter, 0, size_t(GM_CORR_SPLIT_MAX_ITEMS) * sizeof(uint32_t), st);
+        if constexpr (WS31) {
+            if (!g_corr_stamps_armed) {
+                if (ref_mul)
+                    hipLaunchKernelGGL((acq_corr_ws31_kernel<CP, true>), dim3(grid), dim3(1024), 0, st, spectra, code_fft, mmax, margmax, msum,
+                                       worker_list, n_workers, n_bins, n_int, map_mode, split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
+                else
+                    hipLaunchKernelGGL((acq_corr_ws31_kernel<CP, false>), dim3(grid), dim3(1024), 0, st, spectra, code_fft, mmax, margmax, msum,
+                                       worker_list, n_workers, n_bins, n_int, map_mode, split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
+                return;
+            }
+        }
         if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
             hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, true, false>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
