@@ -3,6 +3,21 @@
 #pragma once
 namespace gm {
 template <class PL> struct CorrPlanOf;
+// Pass-0 input ROWS of the stored spectra / code spectra (PairLayout, acq_device.h).  Lane b of pass 0 consumes rows r = 0 .. R0 - 1
+// (element b + r * NB0); FORCE pairs the rows two by two (16-byte loads) also for a first radix above 25, and row() / nat() store them
+// in another order than the natural one.  N = 16368: the radix-33 Good-Thomas butterfly consumes its inputs in the order
+// (11 n1 + 3 N2) mod 33, n1 = 0 .. 2 inside N2 = 0 .. 10 (fft_core.h Bfly<33>::s1); stored in THAT order, every 16-byte load of
+// acq_corr_ws31_kernel feeds the next two inputs of the butterfly and nothing waits in registers for its partner.
+template <class PL> struct PairRows {
+    static constexpr bool FORCE = false;
+    static constexpr int row(int r) { return r; }      // natural row -> stored row
+    static constexpr int nat(int s) { return s; }      // stored row -> natural row
+};
+template <> struct PairRows<Plan<16368, 768, 33, 16, 31>> {
+    static constexpr bool FORCE = true;
+    static constexpr int row(int r) { return 3 * ((4 * (r % 11)) % 11) + (2 * (r % 3)) % 3; }     // r = (11 n1 + 3 N2) mod 33 -> 3 N2 + n1
+    static constexpr int nat(int s) { return (11 * (s % 3) + 3 * (s / 3)) % 33; }
+};
 // Stage F's forward transform may run on a plan of its own (same N): the stage is ONE round of D*M workgroups, i.e. bound by the
 // latency of a single transform, where a plan of more, smaller passes on more lanes wins — the opposite of what the
 // throughput-bound inverse in acq_corr_kernel wants.

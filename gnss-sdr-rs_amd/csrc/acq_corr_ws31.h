@@ -42,14 +42,16 @@ namespace gm {
 template <int N_> struct Ws31PlanOf { using type = Plan<N_, 1024, 33, 16, 31>; };
 
 // the matrix-pipe radix-31 pass: NWM waves starting at wave W0 share the NB / 16 batches — wave w takes batches (w - W0) + NWM it,
-// it < ITL = NBATCH / NWM — and the one batch left over (33 = 8 x 4 + 1) goes to wave W0 - 1 as its batch it = 0 (a fifth batch on a
-// matrix wave would be a fifth set of 8 power sums: 40 + the pass's ~80 registers spill under the 128-register cap, and a scratch
-// reload in the matrix loop queues behind the pass-0 waves' loads)
+// it < ITF = NBATCH / NWM, power sums in registers — and the one batch left over (33 = 8 x 4 + 1) is wave W0's batch it = ITF, whose
+// eight power sums per lane live in LDS (2 KB of the 25 KB the image leaves free) while the integrations run: a fifth set of
+// registers (40 power sums + the pass's ~80) spills under the 128-register cap, and a scratch reload inside the matrix loop queues
+// behind the pass-0 waves' 528 loads (measured: 3 300 cycles per batch instead of 1 200); on a pass-0 wave instead, the batch delays
+// that wave's loads and the whole workgroup waits for it at B1 (2 400 - 4 000 cycles per transform).
 template <class PL, int W0, int NWM> struct Mfma31 {
     static constexpr int NB = PL::NB(PL::NP - 1), NBATCH = NB / 16;
-    static constexpr int ITL = NBATCH / NWM, RL = 8, EXTRA = NBATCH - NWM * ITL;
+    static constexpr int ITF = NBATCH / NWM, EXTRA = NBATCH - NWM * ITF, ITL = ITF + EXTRA, RL = 8;
     static_assert(PL::R[PL::NP - 1] == 31 && NB % 16 == 0 && PL::COPRIME, "prime-factor plan ending in radix 31");
-    static_assert(EXTRA == 0 || (EXTRA == 1 && W0 >= 1), "at most one batch left over, taken by the wave in front of the matrix waves");
+    static_assert(EXTRA == 0 || EXTRA == 1, "at most one batch left over");
     struct Tab { float c[31], s[31]; };
     static constexpr Tab make() {
         Tab t{};
@@ -69,13 +71,10 @@ template <class PL, int W0, int NWM> struct Mfma31 {
         }
         return m;
     }
-    static __device__ __forceinline__ int batch_of(int tid, int it) {
-        const int w = (tid >> 6) - W0;
-        return w >= 0 ? w + NWM * it : NWM * ITL;               // (wave W0 - 1, it = 0: the batch left over)
-    }
+    static __device__ __forceinline__ int batch_of(int tid, int it) { return (tid >> 6) - W0 + NWM * it; }
     static __device__ __forceinline__ bool batch_active(int tid, int it) {
         const int w = (tid >> 6) - W0;
-        return (w >= 0 && w < NWM) || (EXTRA == 1 && w == -1 && it == 0);
+        return w >= 0 && w < NWM && w + NWM * it < NBATCH;
     }
     static __device__ __forceinline__ bool slot_ok(int tid, int r8) { return !(((tid >> 4) & 3) == 0 && r8 == 1); }   // q = 0 has no partner output
     static __device__ __forceinline__ int bfly(int tid, int it) { return 16 * batch_of(tid, it) + (tid & 15); }
@@ -91,7 +90,7 @@ template <class PL, int W0, int NWM> struct Mfma31 {
     // the image is declared one row longer and the value is discarded.
     struct Bases { const cf *pa, *pb; };
     static __device__ __forceinline__ Bases bases(const cf* lds, int tid) {
-        const int kg = (tid >> 4) & 3, col = 16 * batch_of(tid, 0) + (tid & 15);
+        const int kg = (tid >> 4) & 3, col = 16 * ((tid >> 6) - W0) + (tid & 15);
         return Bases{lds + col + kg * NB, lds + col + (19 - kg) * NB};
     }
     template <class Out>
@@ -237,7 +236,12 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
     const __amdgpu_buffer_rsrc_t crs = make_rsrc(code_fft + size_t(p) * PL::N, PL::N * 8u);
     const int m_per = n_int / parts, m_begin = part * m_per, m_end = m_begin + m_per;
 
-    constexpr int AIT = MF::ITL, ARL = MF::RL;                     // the matrix waves' power slots (zero and untouched on the pass-0 waves)
+    __shared__ float lacc[MF::RL * 64];                            // wave W0's left-over batch: its eight power sums per lane, [slot][lane]
+    if (wave == W0) {
+#pragma unroll
+        for (int r = 0; r < MF::RL; ++r) lacc[r * 64 + (tid & 63)] = 0.0f;
+    }
+    constexpr int AIT = MF::ITL, ARL = MF::RL, ITF = MF::ITF;       // the matrix waves' power slots (zero and untouched on the pass-0 waves)
     float acc[AIT][ARL];
 #pragma unroll
     for (int it = 0; it < AIT; ++it)
@@ -253,14 +257,37 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
         if constexpr (REF_MUL) acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y);
         else acc[it][r] = acc[it][r] + __builtin_fmaf(v.y, v.y, v.x * v.x);
     };
+    // the same for the left-over batch (wave W0; a lane reads and writes only its own words, in program order)
+    auto out_lds = [&](int, int r, cf v) {
+        float* a = &lacc[r * 64 + (tid & 63)];
+        if constexpr (REF_MUL) *a = *a + (v.x * v.x + v.y * v.y);
+        else *a = *a + __builtin_fmaf(v.y, v.y, v.x * v.x);
+    };
     if (wave < W0) {
         // ---------------------------------------------------------------- pass-0 role (vector + texture-address units)
-        const int voff = tid < NB0 ? tid * 8 : 0x7ffffff0;          // lanes 496 .. 511: out of the descriptor's range, no request
+        // Both arrays are stored in row PAIRS, in the order the radix-33 butterfly consumes its inputs (PairRows, acq_corr_plans.h):
+        // input r is stored row s = row(r), half s & 1 of the 16-byte pair s >> 1 of this lane; the two inputs of a pair are asked for
+        // one after the other, and the second request of the same pair is the same load expression (one load instruction).
+        using PR = PairRows<PLX>;
+        static_assert(PR::FORCE && PairLayout<PLX>::PAIRED && PairLayout<PLX>::NB0 == NB0, "the [33, 16, 31] plan's paired, consumption-ordered rows");
+        const int v16 = tid < NB0 ? tid * 16 : 0x7ffffff0, v8 = tid < NB0 ? tid * 8 : 0x7ffffff0;   // lanes 496 .. 511: out of range, no request
+        auto pick = [](u32x4 q, int half) { return half ? cf_make(__uint_as_float(q.z), __uint_as_float(q.w)) : cf_make(__uint_as_float(q.x), __uint_as_float(q.y)); };
         for (int m = m_begin; m < m_end; ++m) {
-            if (m > m_begin) MF::batch(0, mb, tid, mconst, out);    // wave W0 - 1 only: the left-over batch of transform m - 1 (wave-uniform)
+            u32x4 qx, qc;                                             // the pair in hand (its second half is the next input asked for)
             auto in = [&](int, int r) {
-                const cf a = buf_load_cf(xrs, voff, (m * PL::N + r * NB0) * 8);
-                const cf g = buf_load_cf(crs, voff, r * NB0 * 8);
+                const int s_ = PR::row(r);                            // (a compile-time constant after unrolling: 0, 1, 2, ... in call order)
+                cf a, g;
+                if (s_ < 32) {
+                    if ((s_ & 1) == 0) {                              // (loaded as ONE value used twice: two expressions would be narrowed to 8-byte loads)
+                        qx = __builtin_amdgcn_raw_buffer_load_b128(xrs, v16, (m * PL::N + (s_ >> 1) * 2 * NB0) * 8, 0);
+                        qc = __builtin_amdgcn_raw_buffer_load_b128(crs, v16, ((s_ >> 1) * 2 * NB0) * 8, 0);
+                    }
+                    a = pick(qx, s_ & 1);
+                    g = pick(qc, s_ & 1);
+                } else {
+                    a = buf_load_cf(xrs, v8, (m * PL::N + 32 * NB0) * 8);
+                    g = buf_load_cf(crs, v8, 32 * NB0 * 8);
+                }
                 const cf c = cf_make(g.x, -g.y);
                 // result_buf[i] *= conj(code[i])  (:184-186); REF_MUL: num-complex's own unfused form (gm_acq_cfg.reference_products)
                 if constexpr (REF_MUL) return cf_make(a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x);
@@ -293,17 +320,17 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
             MiddlePasses<PL, true, 1, true>::run(lds, nullptr, tid);   // B3, B4 inside
             ws31_stamp<STAMPS>(stb, m, 0, 5);
         }
-        MF::batch(0, mb, tid, mconst, out);                         // wave W0 - 1: the last transform's left-over batch
     } else {
         // ---------------------------------------------------------------- matrix-pipe role (owns the power sums)
         for (int m = m_begin; m < m_end; ++m) {
             ws31_stamp<STAMPS>(stb, m, 1, 0);
             if (m > m_begin) {                                      // the radix-31 pass of transform m - 1, beside pass 0 of transform m
 #pragma unroll
-                for (int it = 0; it < AIT; ++it) {
+                for (int it = 0; it < ITF; ++it) {
                     MF::batch(it, mb, tid, mconst, out);
                     __builtin_amdgcn_sched_barrier(0);             // one batch at a time: two fused ones cost 32 more registers
                 }
+                if constexpr (MF::EXTRA == 1) MF::batch(ITF, mb, tid, mconst, out_lds);     // wave W0 only (wave-uniform inside)
             }
             ws31_stamp<STAMPS>(stb, m, 1, 1);
             __syncthreads();                                        // B1: every gather of transform m - 1 has been read
@@ -314,16 +341,23 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
             ws31_stamp<STAMPS>(stb, m, 1, 5);
         }
 #pragma unroll
-        for (int it = 0; it < AIT; ++it) {                          // the last transform's
+        for (int it = 0; it < ITF; ++it) {                          // the last transform's
             MF::batch(it, mb, tid, mconst, out);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (MF::EXTRA == 1) {
+            MF::batch(ITF, mb, tid, mconst, out_lds);
+            if (wave == W0) {                                       // the left-over batch's sums join the register slots for the epilogue
+#pragma unroll
+                for (int r = 0; r < ARL; ++r) acc[ITF][r] = lacc[r * 64 + (tid & 63)];
+            }
         }
     }
 
     auto last_active = [&](int it) { return MF::batch_active(tid, it); };
     auto out_index = [&](int it, int r) { return MF::index(tid, it, r); };
     auto slot_ok = [&](int r) { return MF::slot_ok(tid, r); };
-    constexpr int WA = W0 - (MF::EXTRA ? 1 : 0), TM = T - 64 * WA;     // the waves that own power sums: WA .. 15
+    constexpr int WA = W0, TM = T - 64 * WA;                         // the waves that own power sums: WA .. 15
     constexpr int RL4 = ARL / 4;                                     // 16-byte groups of a lane's power values
     static_assert(ARL % 4 == 0, "power slots in 16-byte groups");
     const int mt = tid - 64 * WA;                                   // lane number among the waves that own power sums
@@ -475,7 +509,7 @@ template <class PL> struct Ws31 {
 template <class PL> constexpr int ws31_split_slab() {
     using W = typename Ws31PlanOf<PL::N>::type;
     using MF = Mfma31<W, 8, 8>;
-    return MF::ITL * (MF::RL / 4) * 4 * 64 * (8 + MF::EXTRA);
+    return MF::ITL * (MF::RL / 4) * 4 * 64 * 8;
 }
 
 }  // namespace gm

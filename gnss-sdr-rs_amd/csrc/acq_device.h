@@ -91,17 +91,18 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // hoisted loads cost Plan16368 20 % at 167 VGPRs) keep the natural order and the element-by-element loads.
 template <class PL> struct PairLayout {
     static constexpr int R0 = PL::R0, NB0 = PL::NB(0), NPAIR = R0 / 2;
-    static constexpr bool PAIRED = R0 <= 25;
+    static constexpr bool PAIRED = R0 <= 25 || PairRows<PL>::FORCE;
+    // (rows may be stored in another order than the natural one: PairRows, acq_corr_plans.h — the identity except for N = 16368)
     static __host__ __device__ __forceinline__ int pos(int k) {
         if constexpr (!PAIRED) return k;
-        const int r = k / NB0, b = k - r * NB0;
+        const int rn = k / NB0, b = k - rn * NB0, r = PairRows<PL>::row(rn);
         return r < 2 * NPAIR ? ((r >> 1) * NB0 + b) * 2 + (r & 1) : 2 * NPAIR * NB0 + b;
     }
     static __host__ __device__ __forceinline__ int unpos(int p) {      // the inverse of pos
         if constexpr (!PAIRED) return p;
-        if (p >= 2 * NPAIR * NB0) return (p - 2 * NPAIR * NB0) + (R0 - 1) * NB0;
+        if (p >= 2 * NPAIR * NB0) return (p - 2 * NPAIR * NB0) + PairRows<PL>::nat(R0 - 1) * NB0;
         const int pair = p >> 1, rp = pair / NB0, b = pair - rp * NB0;
-        return b + (2 * rp + (p & 1)) * NB0;
+        return b + PairRows<PL>::nat(2 * rp + (p & 1)) * NB0;
     }
 };
 
@@ -183,7 +184,8 @@ template <class PL> struct PairLoad {
         for (int rp = P0; rp < P1; ++rp) q[rp] = __builtin_amdgcn_raw_buffer_load_b128(rs, v16, (base_elems + rp * 2 * NB0) * 8, 0);
         if constexpr (ODD && TAIL) last = buf_load_cf(rs, v8, (base_elems + 2 * NPAIR * NB0) * 8);
     }
-    __device__ __forceinline__ cf get(int r) const {   // r is a compile-time constant after unrolling
+    __device__ __forceinline__ cf get(int rn) const {   // rn (natural row) is a compile-time constant after unrolling
+        const int r = PairRows<PL>::row(rn);             // its stored row
         if (ODD && r == PL::R0 - 1) return last;
         const u32x4 v = q[r >> 1];
         return (r & 1) ? cf_make(__uint_as_float(v.z), __uint_as_float(v.w)) : cf_make(__uint_as_float(v.x), __uint_as_float(v.y));
