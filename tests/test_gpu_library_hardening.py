@@ -197,3 +197,34 @@ def test_thirty_two_one_prn_workers_at_the_reference_geometry(gpu, oracle):
     assert found == {r["prn"]: (r["code_phase_samples"], r["doppler_bin"]) for r in res if r}
     assert len(found) >= 8
 
+
+
+def test_ws31_kernel_strict_sum_and_cut_items_at_the_reference_geometry(gpu, oracle):
+    """N = 16368 runs the wave-specialised stage C (csrc/acq_corr_ws31.h: radix-31 pass on the matrix pipe).  Its
+    strict_sum_order path (the plane through LDS, the reference's eight-lane sum, do_acquisition.rs:229-235) against the oracle's
+    ordered sums, and its cut items (a one-PRN handle cuts every item into its integrations and merges the planes through HBM)
+    against the uncut items of a 32-PRN handle: the same words."""
+    from gnss_sdr_rs_amd import acquisition as A
+    fs, N, M = 16.368e6, 16368, 4
+    dop = np.arange(-1000.0, 1000.1, 500.0, dtype=np.float32)
+    x, _ = _scene(oracle, fs, N, M, config_id=720, prns=(7, 21), cn0=47.0)
+    tables = [oracle.DopplerShiftTable(0.0, float(d), fs, N) for d in dop]
+    for strict in (False, True):
+        one = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=[7], n_integrations=M, strict_sum_order=strict)
+        r1 = one.search(x)
+        m1 = [a.copy() for a in one.metrics()]
+        one.close()
+        allp = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, n_integrations=M, strict_sum_order=strict)
+        r32 = allp.search(x)
+        m32 = allp.metrics()
+        allp.close()
+        assert r1[0] == r32[6] and r1[0] is not None and r32[20] is not None
+        if not strict:      # (strict_sum_order keeps the integrations in sequence: no cut, nothing to compare)
+            for a, b in zip(m1, m32):
+                assert (a[0].view(np.uint32) == b[6].view(np.uint32)).all()
+        w = oracle.AcquisitionWorker(7, N, fs)
+        exp, (bmax, barg, bsum, _) = w.search_satellite(x, tables, 0, M, want_planes=True, no_early_exit=True)
+        mx, am, sm = m32
+        assert (am[6] == barg).all()
+        assert float(np.max(np.abs(mx[6] - bmax) / bmax)) <= 1e-5
+        assert float(np.max(np.abs(sm[6] - bsum) / bsum)) <= (5e-7 if strict else 1e-5)
