@@ -228,3 +228,39 @@ def test_ws31_kernel_strict_sum_and_cut_items_at_the_reference_geometry(gpu, ora
         assert (am[6] == barg).all()
         assert float(np.max(np.abs(mx[6] - bmax) / bmax)) <= 1e-5
         assert float(np.max(np.abs(sm[6] - bsum) / bsum)) <= (5e-7 if strict else 1e-5)
+
+
+def test_ws31_edge_shapes_and_the_generic_fallback_read_the_same_layout(gpu, oracle):
+    """N = 16368 edge shapes through the wave-specialised kernel — ONE integration, one worker x one bin, a masked worker list —
+    against the oracle; and the generic kernel the size falls back to under gm_acq_debug_stamps must read the same stored order
+    (row pairs in the radix-33 butterfly's consumption order, PairRows): identical metrics words with the stamps armed."""
+    import ctypes as C
+    from gnss_sdr_rs_amd import _lib, acquisition as A
+    fs, N = 16.368e6, 16368
+    dop = np.array([-500.0, 0.0, 500.0], np.float32)
+    for M, prns, config in ((1, [7], 730), (3, [7, 8, 21], 731)):
+        x, _ = _scene(oracle, fs, N, M, config_id=config, prns=(7, 21), cn0=50.0)
+        tables = [oracle.DopplerShiftTable(0.0, float(d), fs, N) for d in dop]
+        eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=prns, n_integrations=M)
+        got = eng.search(x)
+        mx, am, sm = [a.copy() for a in eng.metrics()]
+        for i, p in enumerate(prns):
+            w = oracle.AcquisitionWorker(p, N, fs)
+            exp, (bmax, barg, bsum, _) = w.search_satellite(x, tables, 0, M, want_planes=True, no_early_exit=True)
+            assert (am[i] == barg).all(), (M, p)
+            assert float(np.max(np.abs(mx[i] - bmax) / bmax)) <= 1e-5 and float(np.max(np.abs(sm[i] - bsum) / bsum)) <= 1e-5
+            e2 = w.search_satellite(x, tables, 0, M)
+            assert (got[i] is None) == (e2 is None) and (e2 is None or got[i]["code_phase_samples"] == e2["code_phase_samples"])
+        if len(prns) == 3:
+            masked = eng.search(x, prn_mask=0b101)                  # workers 0 and 2 only
+            assert masked[1] is None and masked[0] == got[0] and masked[2] == got[2]
+            # the generic kernel (diagnostic stamps variant) on the same handle: same stored spectra, same words
+            L = _lib.lib()
+            _lib.check(L.gm_acq_debug_stamps(eng._h, None), "arm")
+            again = eng.search(x)
+            buf = np.zeros((M, 8, 8), np.int64)
+            _lib.check(L.gm_acq_debug_stamps(eng._h, buf.ctypes.data_as(C.c_void_p)), "read")
+            mx2, am2, sm2 = eng.metrics()
+            assert again == got and (am2 == am).all()
+            assert float(np.max(np.abs(mx2 - mx) / mx)) <= 2e-6 and float(np.max(np.abs(sm2 - sm) / sm)) <= 2e-6    # (another summation order)
+        eng.close()
