@@ -9,6 +9,7 @@
 
 #include "fft_core.h"
 #include "fft_plans.h"
+#include "ws31_core.h"
 
 using namespace gm;
 
@@ -131,6 +132,124 @@ template <class HP, bool INV> static double run_hybrid(const char* name) {
     return err;
 }
 
+// The wave-specialised N = 16368 transform of csrc/acq_corr_ws31.h, emulated lane by lane from csrc/ws31_core.h: the stored order
+// (prime-factor input permutation, then row pairs in the radix-33 butterfly's consumption order: PairRows) -> pass 0 as the
+// pass-0 waves run it (inputs asked for by stored row, Bfly<33> first half, streaming 11-point second half) -> the radix-16 pass
+// -> the radix-31 pass as the matrix waves run it: every batch's gathers through the two base addresses, the four 16 x 16 x 16
+// products formed from the LANES' constants exactly as v_mfma_f32_16x16x4_f32 combines them (A[l & 15][l >> 4], B[l >> 4][l & 15],
+// D[4 (l >> 4) + r][l & 15]; an fmaf chain in k order), the left-over batch, the slot -> element map.  Every element must be
+// produced exactly once and equal the float64 inverse DFT.
+static double run_ws31() {
+    using PLX = gm::Plan16368;
+    using PL = gm::Ws31PlanOf<PLX::N>::type;
+    using MF = gm::Mfma31<PL, 8, 8>;
+    using PR = gm::PairRows<PLX>;
+    constexpr int N = PL::N, T = PL::T, NB0 = PL::NB(0), NB = MF::NB;
+    static_assert(PR::FORCE && T == 1024 && NB0 == 496 && NB == 528 && MF::ITF == 4 && MF::EXTRA == 1, "the shipped shape");
+    std::vector<cf> x(N), st(N + 16), lds(PL::LDS_ELEMS + NB, cf_make(1e30f, -1e30f)), y(N, cf_make(1e30f, 1e30f));
+    unsigned sd = 4242u;
+    for (int i = 0; i < N; ++i) {
+        sd = sd * 1664525u + 1013904223u; float a = float(int(sd >> 8) % 2001 - 1000) / 100.f;
+        sd = sd * 1664525u + 1013904223u; float b = float(int(sd >> 8) % 2001 - 1000) / 100.f;
+        x[i] = cf_make(a, b);
+    }
+    // stored order: element k -> prime-factor slot e -> (row rn = e / NB0, lane b) -> stored row s = row(rn) -> position
+    std::vector<char> used(N, 0);
+    for (int r = 0; r < 33; ++r) if (PR::nat(PR::row(r)) != r || PR::row(PR::nat(r)) != r) { std::printf("ws31: PairRows row / nat are not inverse at %d\n", r); return 1.0; }
+    for (int k = 0; k < N; ++k) {
+        const int e = Pfa<PL>::in_slot(k), rn = e / NB0, b = e - rn * NB0, s_ = PR::row(rn);
+        const int pos = s_ < 32 ? ((s_ >> 1) * NB0 + b) * 2 + (s_ & 1) : 32 * NB0 + b;
+        if (pos < 0 || pos >= N || used[pos]) { std::printf("ws31: stored order is not a permutation at %d\n", k); return 1.0; }
+        used[pos] = 1;
+        st[pos] = x[k];
+    }
+    // pass 0 on lanes 0 .. 495: the s-th input the butterfly asks for must be stored row s (16-byte pair s >> 1, half s & 1)
+    {
+        std::vector<cf> regs(size_t(NB0) * 33);
+        for (int tid = 0; tid < NB0; ++tid) {
+            int calls = 0; bool in_order = true;
+            auto in = [&](int, int r) {
+                const int s_ = PR::row(r);
+                in_order = in_order && s_ == calls++;
+                return s_ < 32 ? st[((s_ >> 1) * NB0 + tid) * 2 + (s_ & 1)] : st[32 * NB0 + tid];
+            };
+            Fft<PL, true, true>::pass0_stage1(*reinterpret_cast<cf(*)[1][33]>(&regs[size_t(tid) * 33]), in, tid);
+            if (!in_order || calls != 33) { std::printf("ws31: pass 0 does not consume its rows in stored order (lane %d)\n", tid); return 1.0; }
+        }
+        for (int tid = 0; tid < NB0; ++tid) {
+            cf (&v0)[33] = *reinterpret_cast<cf(*)[33]>(&regs[size_t(tid) * 33]);
+            constexpr int EA = Bfly<33, true>::EA, EB = Bfly<33, true>::EB;
+            cf* dst = lds.data() + tid * 33;
+            for (int k1 = 0; k1 < 3; ++k1) {
+                cf u[11];
+                for (int n2 = 0; n2 < 11; ++n2) u[n2] = v0[n2 * 3 + k1];
+                gm::dft11_inv_stream(u, [&](int k2, cf val) { dst[(k1 * EA + k2 * EB) % 33] = val; });
+            }
+        }
+    }
+    Middle<PL, true, 1, true>::run(lds, std::vector<cf>(1));
+    // the radix-31 pass on waves 8 .. 15
+    std::vector<typename MF::Consts> mc(T);
+    for (int tid = 0; tid < T; ++tid) mc[tid] = MF::consts(tid);
+    int produced = 0;
+    for (int wave = 8; wave < 16; ++wave) {
+        for (int it = 0; it < MF::ITL; ++it) {
+            if (!MF::batch_active(wave * 64, it)) continue;
+            float a_re[4][64], a_im[4][64], b_re[4][64], b_im[4][64];     // [k-step][lane]
+            for (int l = 0; l < 64; ++l) {
+                const int tid = wave * 64 + l, kg = (l >> 4) & 3;
+                const typename MF::Bases bs = MF::bases(lds.data(), tid);
+                for (int stp = 0; stp < 4; ++stp) {
+                    const int k = 4 * stp + kg;
+                    const cf up = bs.pa[stp * 4 * NB + it * 16 * 8], um = bs.pb[(3 - stp) * 4 * NB + it * 16 * 8];
+                    if (k > 0 && (bs.pa + stp * 4 * NB + it * 16 * 8 != lds.data() + MF::bfly(tid, it) + k * NB ||
+                                  bs.pb + (3 - stp) * 4 * NB + it * 16 * 8 != lds.data() + MF::bfly(tid, it) + (31 - k) * NB)) {
+                        std::printf("ws31: gather addresses off (wave %d lane %d it %d step %d)\n", wave, l, it, stp); return 1.0;
+                    }
+                    const cf a = k == 0 ? up : cf_add(up, um), b = k == 0 ? cf_make(0.f, 0.f) : cf_sub(up, um);
+                    a_re[stp][l] = a.x; a_im[stp][l] = a.y; b_re[stp][l] = b.x; b_im[stp][l] = b.y;
+                }
+            }
+            for (int l = 0; l < 64; ++l) {          // D[q = 4 (l >> 4) + r][n = l & 15] = sum over k-steps, then over kg, of A[q][k] * B[k][n]
+                const int tid = wave * 64 + l, n = l & 15;
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 4 * (l >> 4) + r;
+                    float dcr = 0.f, dci = 0.f, dsr = 0.f, dsi = 0.f;
+                    for (int stp = 0; stp < 4; ++stp)
+                        for (int kg = 0; kg < 4; ++kg) {
+                            const typename MF::Consts& m = mc[wave * 64 + 16 * kg + q];      // the lane that holds A[q][4 stp + kg]
+                            const int src = 16 * kg + n;                                     // ... and the one that holds B[4 stp + kg][n]
+                            dcr = __builtin_fmaf(m.c[stp], a_re[stp][src], dcr); dci = __builtin_fmaf(m.c[stp], a_im[stp][src], dci);
+                            dsr = __builtin_fmaf(m.s[stp], b_re[stp][src], dsr); dsi = __builtin_fmaf(m.s[stp], b_im[stp][src], dsi);
+                        }
+                    for (int side = 0; side < 2; ++side) {
+                        const int r8 = 2 * r + side;
+                        if (!MF::slot_ok(tid, r8)) continue;
+                        const int idx = MF::index(tid, it, r8);
+                        if (idx < 0 || idx >= N || y[idx].x != 1e30f) { std::printf("ws31: slot -> element map is not a bijection at %d\n", idx); return 1.0; }
+                        y[idx] = side == 0 ? cf_make(dcr - dsi, dci + dsr) : cf_make(dcr + dsi, dci - dsr);
+                        ++produced;
+                    }
+                }
+            }
+        }
+    }
+    if (produced != N) { std::printf("ws31: %d of %d elements produced\n", produced, N); return 1.0; }
+    std::vector<std::complex<double>> w(N);
+    for (int i = 0; i < N; ++i) w[i] = std::polar(1.0, 2.0 * M_PI * i / N);
+    double num = 0, den = 0;
+    for (int k = 0; k < N; ++k) {
+        std::complex<double> acc = 0;
+        size_t idx = 0;
+        for (int n = 0; n < N; ++n) { acc += std::complex<double>(x[n].x, x[n].y) * w[idx]; idx += k; if (idx >= size_t(N)) idx -= N; }
+        const std::complex<double> d = acc - std::complex<double>(y[k].x, y[k].y);
+        num += std::norm(d); den += std::norm(acc);
+    }
+    const double err = std::sqrt(num / den);
+    std::printf("%-28s N=%6d T=%4d inv wave-specialised (pass 0 on 8 waves, radix 31 as 16x16x16 matrix products on 8) rel_l2_err=%.3e\n", "ws31<Plan16368>", N, T, err);
+    return err;
+}
+
 int main() {
     double worst = 0;
     worst = std::fmax(worst, run_hybrid<HybridPlan<8000, 512, 5, 25, 4, 16>, true>("Hybrid8000 [20,25,16]"));
@@ -148,6 +267,7 @@ int main() {
         using MixPlan16368 = gm::MixPlanOf<gm::Plan16368>::type;
         worst = std::fmax(worst, run_plan<MixPlan16368, false>("MixPlanOf<Plan16368>"));
     }
+    worst = std::fmax(worst, run_ws31());
     std::printf("worst %.3e\n", worst);
     return worst < 7e-7 ? 0 : 1;   // f32 FFT rounding of the largest plans; parity tolerances downstream are 1e-5
 }
