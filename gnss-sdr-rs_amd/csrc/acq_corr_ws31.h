@@ -32,6 +32,12 @@
 //   B2  pass-0 image complete
 //     [all waves: gather 16, B3, radix 16, scatter]
 //   B4  the image holds the radix-31 inputs of transform m
+// Also measured and left out: the middle pass on the matrix waves alone with a private LDS-counter barrier, or on the
+// pass-0 waves alone (two butterflies per lane either way: 64 more registers, spills inside the loops: 470 - 545 us against 336), the
+// left-over batch rotated over the matrix waves or run in two low-register halves (spills: 386 - 410 us), wave priorities (no change).
+// What bounds the kernel now: during the radix-31 phase the matrix pipe is ~77 % busy (33 x 16 instructions x 32 cycles / 4 SIMDs =
+// 4 224 cycles per transform against a phase of ~6 000), and the single image serialises that phase with pass 0's scatter and the
+// radix-16 pass.
 // The matrix-pipe role is NOT what north_star foresaw ("MFMA is not used: no dense contraction here"): for this size there is
 // one, and it is half of the kernel's arithmetic.  Measured: DESIGN.md §4.2 / §5.
 #pragma once
