@@ -947,20 +947,18 @@ def cfg5_leg(torch, stream, T, world=1, rank=0, dist=None, dev=None, debug_gloo=
             "algorithmic_GBs": C * n * 8 * periods / dt / 1e9}
 
 
-def receiver_leg(ca, A, T, synth, with_cpu, cpu_seconds=8.0, n_ms=3200, prefix_only_ms=None):
+def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
     """SURVEY §8 f1 as ONE chain, the receiver main.rs:182-227 wires: a feeder (the SDR's sample blocks) -> the digital front-end
     writing the device ring (rf_thread's block step, rf/rf_thread.rs:43-48: gm_frontend_write_ring) -> do_acquisition::run's
     snapshot + search on the ring (:297-313, the AcquisitionManager's pacing counted in SIGNAL time) + fine Doppler ->
     TrackingChannel::start -> TrackingManager::process_channels on the same ring (15 channels, the reference's constants, FIXED
     code index) -> bit sync / nav bits / preamble on every channel's prompt I.  3.2 s of int8 IQ at the reference capture's
     16.3676 Msps / 4.1304 MHz IF (N = 16368), eight satellites with 50 bit/s data; n_ms = 3200 by default (frame sync needs ~3 s).  One host thread drives it block by block
-    (16 ms blocks); reported: sustained Msps and x real time over the whole chain, when the first satellite was handed to
+    (16 ms blocks; the front-end runs asynchronously on the ring's copy stream, the stages behind the ring one block behind it); reported: sustained Msps and x real time over the whole chain, when the first satellite was handed to
     tracking / bit-synchronised / frame-synchronised (signal time and wall clock), and the wall clock per stage.  Informative,
     never `value`.  The same chain is parity-tested in tests/test_gpu_pipeline.py::test_full_chain_frontend_to_nav_bits."""
     from gnss_sdr_rs_amd import decoding as Dm, frontend as F
     fs, f_if, N, M = 16_367_600.0, 4_130_400.0, 16368, 10
-    if prefix_only_ms:
-        n_ms = prefix_only_ms
     rng = np.random.default_rng(11)
     sats = []
     for i, (prn, cn0) in enumerate([(2, 50.0), (5, 48.0), (9, 47.0), (13, 46.0), (17, 46.0), (22, 45.0), (26, 44.0), (30, 44.0)]):
@@ -1003,12 +1001,10 @@ def receiver_leg(ca, A, T, synth, with_cpu, cpu_seconds=8.0, n_ms=3200, prefix_o
     events = {}
     next_acq_ms, dwells, epochs_run, fe_blocks = 10.0, 0, 0, []
     t_start = time.perf_counter()
-    for off in range(PRE, n_ms * N, BLK):
-        t0 = time.perf_counter()
-        fe.write_ring(ring, xi8[off:off + BLK]); ring.flush()
-        head = ring.get_head()
-        t1 = time.perf_counter(); stage["frontend"] += t1 - t0
-        fe_blocks.append(t1 - t0)
+    def consume(head):
+        """everything downstream of the ring for the samples published so far: acquisition when due, tracking to the head, nav bits"""
+        nonlocal next_acq_ms, dwells, epochs_run
+        t1 = time.perf_counter()
         sig_ms = head / fs * 1e3
         # ---- do_acquisition::run's loop body, paced in signal time (:287-295: interval from the manager, then a snapshot ending at head)
         if sig_ms >= next_acq_ms:
@@ -1016,8 +1012,8 @@ def receiver_leg(ca, A, T, synth, with_cpu, cpu_seconds=8.0, n_ms=3200, prefix_o
             interval_ms, mask = amgr.get_pacing_and_list(active)
             res, local_tail = eng.search_ring(ring, prn_mask=mask)
             t2 = time.perf_counter(); stage["acquisition"] += t2 - t1
-            dwells += 1
-            if res:
+            if res is not None:
+                dwells += 1
                 hits = [r if (r and r["prn"] not in active) else None for r in res]
                 if any(hits):
                     fine = eng.finer_doppler(hits)
@@ -1030,26 +1026,42 @@ def receiver_leg(ca, A, T, synth, with_cpu, cpu_seconds=8.0, n_ms=3200, prefix_o
                             chan_prn[ch] = r["prn"]; active.add(r["prn"])
                             events.setdefault("first_handover", (sig_ms, time.perf_counter() - t_start))
                 stage["fine_doppler"] += time.perf_counter() - t2
-            next_acq_ms = sig_ms + interval_ms
+                next_acq_ms = sig_ms + interval_ms
             t1 = time.perf_counter()
         # ---- TrackingManager::process_channels until the ring's head (do_tracking.rs:407-413)
         if chan_prn:
-            outs, proc, lost, done = mgr.update_all(ring, BLK // N + 2)
+            outs, proc, lost, done = mgr.update_all(ring, 2 * (BLK // N) + 3)
             t3 = time.perf_counter(); stage["tracking"] += t3 - t1
             epochs_run += int(proc.sum())
-            for ch in chan_prn:                                        # nav_decoding's per-epoch step on the prompt I (decoding.rs:102-145)
-                for e in np.nonzero(proc[:, ch])[0]:
-                    ipv = float(outs[e, ch, 0])
-                    st = navs[ch].update(nav_old[ch], ipv, nav_cnt[ch])
-                    nav_old[ch], nav_cnt[ch], nav_st[ch] = ipv, nav_cnt[ch] + 1, st
-                    if st["flag_bit_sync"]:
+            for ch in chan_prn:                 # nav_decoding's per-epoch step on the prompt I (decoding.rs:102-145), one call per channel and block
+                sel = np.nonzero(proc[:, ch])[0]
+                if sel.size:
+                    ipv = np.ascontiguousarray(outs[sel, ch, 0], np.float32)
+                    st, fb, ff = navs[ch].update_many(nav_old[ch], ipv, nav_cnt[ch])
+                    nav_old[ch], nav_cnt[ch], nav_st[ch] = float(ipv[-1]), nav_cnt[ch] + int(sel.size), st
+                    if fb >= 0:
                         events.setdefault("first_bit_sync", (sig_ms, time.perf_counter() - t_start))
-                    if st["flag_frame_sync"]:
+                    if ff >= 0:
                         events.setdefault("first_frame_sync", (sig_ms, time.perf_counter() - t_start))
             stage["nav_bits"] += time.perf_counter() - t3
             for ch in list(chan_prn):
                 if lost[:, ch].any():
                     active.discard(chan_prn.pop(ch))
+
+    # The feeder does not wait for the front-end: gm_frontend_write_ring enqueues copy + kernel on the ring's copy stream and the
+    # head is published from there (the reference's rf_thread is a thread of its own, rf/rf_thread.rs:12-59); the stages behind the
+    # ring work on what has been published, one block behind the feeder.
+    for off in range(PRE, n_ms * N, BLK):
+        t0 = time.perf_counter()
+        fe.write_ring(ring, xi8[off:off + BLK])
+        stage["frontend"] += time.perf_counter() - t0
+        fe_blocks.append(time.perf_counter() - t0)
+        consume(ring.get_head())
+    t0 = time.perf_counter()
+    ring.flush()
+    stage["frontend"] += time.perf_counter() - t0
+    consume(ring.get_head())
+    consume(ring.get_head())          # (a second pass: a channel's last whole code periods once every other channel has caught up)
     wall = time.perf_counter() - t_start
     sig_s = n_ms * 1e-3
     truth = {s_["prn"]: s_ for s_ in sats}
@@ -1068,20 +1080,21 @@ def receiver_leg(ca, A, T, synth, with_cpu, cpu_seconds=8.0, n_ms=3200, prefix_o
            "events_signal_ms_and_wall_s": {k: {"signal_ms": v[0], "wall_s": v[1]} for k, v in events.items()},
            "wall_seconds_per_stage": stage, "frontend_block_seconds": {"first": fe_blocks[0], "median": float(np.median(fe_blocks)), "max_after_first": float(max(fe_blocks[1:]))},
            "scene_generation_seconds": t_gen,
-           "bound": "the host: %d front-end + %d tracking + %d acquisition calls, each a launch and a synchronisation, and one nav-bit step per "
-                    "channel-epoch through ctypes; the GPU is idle most of the time (DESIGN 5)" % (-(-n_ms * N // BLK), -(-n_ms * N // BLK), dwells)}
+           "bound": "the host thread: %d blocks, each one front-end enqueue (asynchronous: copy + kernel run on the ring's copy stream), one "
+                    "tracking launch with a synchronisation and a device-to-host copy of the sums, one nav-bit call per channel; the front-end's "
+                    "sequential recurrences cap one stream at ~1 Gsps = 63 x real time (DESIGN 5)" % (-(-n_ms * N // BLK))}
     for o in navs:
         o.close()
     mgr.close(); eng.close(); fe.close(); ring.close()
     if with_cpu:
         try:
-            out["cpu_oracle_chain"] = receiver_cpu_chain(ca, xi8, fs, f_if, N, M, dop, sats, cpu_seconds)
+            out["cpu_oracle_chain"] = receiver_cpu_chain(ca, xi8, fs, f_if, N, M, dop, sats)
         except Exception as e:
             out["cpu_oracle_chain"] = {"error": repr(e)}
     return out
 
 
-def receiver_cpu_chain(ca, xi8, fs, f_if, N, M, dop, sats, budget_s):
+def receiver_cpu_chain(ca, xi8, fs, f_if, N, M, dop, sats):
     """The oracle's restatement of the same chain on this host, stage by stage on bounded samples of the same stream: the
     front-end (one thread: its recurrences are sequential), one 32-PRN acquisition dwell (min(32, nproc) threads, early exit as
     in the reference), eight tracking channels (one thread each), nav-bit steps.  seconds of CPU wall clock per second of signal

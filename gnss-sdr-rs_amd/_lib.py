@@ -125,6 +125,7 @@ SIGNATURES = {
     "gm_nav_sync_create": (_i, [_i, _vp]),
     "gm_nav_sync_destroy": (_i, [_vp]),
     "gm_nav_sync_update": (_i, [_vp, _f, _f, _u64, _u64, _vp]),
+    "gm_nav_sync_update_many": (_i, [_vp, _f, _vp, _sz, _sz, _u64, _u64, _vp, _vp, _vp]),
     "gm_nav_sync_frame_bits": (_i, [_vp, _vp, _sz, _vp]),
     "gm_nav_sync_histogram": (_i, [_vp, _vp]),
     "gm_nav_parity_check": (_i, [_vp, _vp, _vp]),

@@ -171,7 +171,8 @@ struct gm_ring {
     // asynchronous writer (gm_ring_write_samples_async): pinned staging slots, a copy stream, and `head` published
     // by a host callback that the stream runs after the copy has landed
     static constexpr int SLOTS = 4;
-    static constexpr size_t SLOT_SAMPLES = size_t(1) << 16;
+    static constexpr size_t SLOT_SAMPLES_MAX = size_t(1) << 18;      // 16 ms at 16.4 Msps: one copy + one front-end launch per block of that size
+    size_t slot_samples = 0;                                        // min(ring size, SLOT_SAMPLES_MAX), set at create
     cf* staging[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t slot_done[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     bool slot_used[SLOTS] = {false, false, false, false};
@@ -195,7 +196,7 @@ static int ring_async_init(gm_ring* r) {
     if (r->copy_stream) return GM_OK;
     HIPC(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < gm_ring::SLOTS; ++i) {
-        HIPC(hipHostMalloc(reinterpret_cast<void**>(&r->staging[i]), gm_ring::SLOT_SAMPLES * 8, hipHostMallocDefault));
+        HIPC(hipHostMalloc(reinterpret_cast<void**>(&r->staging[i]), r->slot_samples * 8, hipHostMallocDefault));
         HIPC(hipEventCreateWithFlags(&r->slot_done[i], hipEventDisableTiming));
     }
     r->write_pos = r->head.load(std::memory_order_relaxed);
@@ -1135,6 +1136,7 @@ int gm_ring_create(size_t buf_size, gm_ring** out) {
     if (int rc = ensure_device(g_device)) return rc;
     gm_ring* r = new gm_ring();
     r->device = g_device; r->size = buf_size; r->mask = buf_size - 1;
+    r->slot_samples = buf_size < gm_ring::SLOT_SAMPLES_MAX ? buf_size : gm_ring::SLOT_SAMPLES_MAX;
     hipError_t e = hipMalloc(&r->d_buf, buf_size * 8);
     if (e == hipSuccess) e = hipMemset(r->d_buf, 0, buf_size * 8);
     if (e != hipSuccess) { delete r; return hip_fail(e, "hipMalloc(ring)"); }
@@ -1167,7 +1169,7 @@ int gm_ring_write_samples_async(gm_ring* r, const gm_c32* s, size_t n) {
     if (int rc = ring_async_init(r)) return rc;
     const cf* src = reinterpret_cast<const cf*>(s);
     while (n) {
-        const size_t chunk = n < gm_ring::SLOT_SAMPLES ? n : gm_ring::SLOT_SAMPLES;
+        const size_t chunk = n < r->slot_samples ? n : r->slot_samples;
         const int slot = int(r->slot_seq++ % gm_ring::SLOTS);
         if (r->slot_used[slot]) HIPC(hipEventSynchronize(r->slot_done[slot]));
         memcpy(r->staging[slot], src, chunk * 8);
@@ -1264,6 +1266,7 @@ struct gm_trk {
     cf* d_scratch = nullptr; size_t scratch_cap = 0;
     float* d_terms = nullptr; size_t terms_cap = 0;   // strict_sum_order: [C][2 * arms][terms_cap] per-sample products of one epoch
     gm_trk_out* d_outs = nullptr; uint8_t *d_proc = nullptr, *d_lost = nullptr, *d_lostprn = nullptr;
+    uint8_t* h_res = nullptr;                      // pinned landing area of gm_trk_update_all: [outs | processed | lost] of epochs_cap epochs
     uint32_t epochs_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false; uint32_t timed_launches = 0;
@@ -1289,13 +1292,17 @@ static int trk_reserve_terms(gm_trk* t, size_t samples) {
 }
 static int trk_reserve_epochs(gm_trk* t, uint32_t e) {
     if (e <= t->epochs_cap) return GM_OK;
+    HIPC(hipStreamSynchronize(t->stream));      // nothing in flight still writes the buffers about to be replaced
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
+    t->d_outs = nullptr; t->d_proc = t->d_lost = t->d_lostprn = nullptr; t->epochs_cap = 0;
     const size_t n = size_t(e) * t->C;
     HIPC(hipMalloc(&t->d_outs, n * sizeof(gm_trk_out)));
     // with three arms the persistent kernel writes the six live sums only: ive..qvl stay 0.  Ordered on the handle's stream
     // (a non-blocking stream does not synchronise with the NULL stream a plain hipMemset runs on)
     HIPC(hipMemsetAsync(t->d_outs, 0, n * sizeof(gm_trk_out), t->stream));
     HIPC(hipMalloc(&t->d_proc, n)); HIPC(hipMalloc(&t->d_lost, n)); HIPC(hipMalloc(&t->d_lostprn, n));
+    if (t->h_res) { hipHostFree(t->h_res); t->h_res = nullptr; }
+    HIPC(hipHostMalloc(reinterpret_cast<void**>(&t->h_res), n * (sizeof(gm_trk_out) + 2), hipHostMallocDefault));
     t->epochs_cap = e;
     return GM_OK;
 }
@@ -1316,6 +1323,7 @@ int gm_trk_destroy(gm_trk* t) {
     if (t->device >= 0) hipSetDevice(t->device);
     hipFree(t->d_codes); hipFree(t->d_states); hipFree(t->d_partials); hipFree(t->d_ready); hipFree(t->d_scratch); hipFree(t->d_terms);
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
+    if (t->h_res) hipHostFree(t->h_res);
     hipFree(t->d_xchg); if (t->d_error) hipHostFree(t->d_error); hipFree(t->d_error_dev); hipFree(t->d_stamps);
     if (t->ev0) hipEventDestroy(t->ev0);
     if (t->ev1) hipEventDestroy(t->ev1);
@@ -1379,7 +1387,13 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
         hipError_t _e = (expr);                                        \
         if (_e != hipSuccess) return fail(hip_fail(_e, #expr));        \
     } while (0)
-    HIPT(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    {   // the tracking loop is the receiver's latency path (one short launch per block of samples): its own stream is the device's
+        // most urgent one, so a launch is not queued behind a front-end block or an acquisition dwell in flight on another stream
+        // (measured: 0.45 ms of waiting per call behind the front-end kernel of the same block, tools/trk_call_time.py)
+        int least = 0, greatest = 0;
+        HIPT(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPT(hipStreamCreateWithPriority(&t->stream, hipStreamNonBlocking, greatest));
+    }
     t->own_stream = true;
     HIPT(hipMalloc(&t->d_codes, t->h_codes.size()));
     HIPT(hipMemcpy(t->d_codes, t->h_codes.data(), t->h_codes.size(), hipMemcpyHostToDevice));
@@ -1620,14 +1634,21 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
 int gm_trk_update_all(gm_trk* t, gm_ring* ring, uint32_t max_epochs, gm_trk_out* outs, uint8_t* processed, uint8_t* lost,
                       uint32_t* epochs_done) {
     if (int rc = gm_trk_update_all_dev(t, ring, max_epochs)) return rc;
+    // the three result arrays land in one pinned area behind the launch, on its stream: one synchronisation per call
+    // (three blocking hipMemcpy calls from pageable memory cost more than the 16 epochs of a 16 ms block)
+    const size_t n = size_t(max_epochs) * t->C;
+    uint8_t* h_outs = t->h_res;
+    uint8_t* h_proc = h_outs + n * sizeof(gm_trk_out);
+    uint8_t* h_lost = h_proc + n;
+    HIPC(hipMemcpyAsync(h_proc, t->d_proc, n, hipMemcpyDeviceToHost, t->stream));
+    if (outs) HIPC(hipMemcpyAsync(h_outs, t->d_outs, n * sizeof(gm_trk_out), hipMemcpyDeviceToHost, t->stream));
+    if (lost) HIPC(hipMemcpyAsync(h_lost, t->d_lost, n, hipMemcpyDeviceToHost, t->stream));
     HIPC(hipStreamSynchronize(t->stream));
     if (int rc = trk_check_error(t)) return rc;
-    const size_t n = size_t(max_epochs) * t->C;
-    std::vector<uint8_t> proc(n);
-    HIPC(hipMemcpy(proc.data(), t->d_proc, n, hipMemcpyDeviceToHost));
-    if (outs) HIPC(hipMemcpy(outs, t->d_outs, n * sizeof(gm_trk_out), hipMemcpyDeviceToHost));
-    if (processed) memcpy(processed, proc.data(), n);
-    if (lost) HIPC(hipMemcpy(lost, t->d_lost, n, hipMemcpyDeviceToHost));
+    const uint8_t* proc = h_proc;
+    if (outs) memcpy(outs, h_outs, n * sizeof(gm_trk_out));
+    if (processed) memcpy(processed, h_proc, n);
+    if (lost) memcpy(lost, h_lost, n);
     if (epochs_done) {
         uint32_t done = 0;
         for (uint32_t e = 0; e < max_epochs; ++e) {
@@ -1952,10 +1973,10 @@ int gm_frontend_write_ring(gm_frontend* f, gm_ring* r, const void* samples, size
     const size_t bps = fmt == GM_FMT_C32 ? 8 : 2;
     const uint8_t* src = static_cast<const uint8_t*>(samples);
     while (n_samples) {
-        const size_t chunk = n_samples < gm_ring::SLOT_SAMPLES ? n_samples : gm_ring::SLOT_SAMPLES;
+        const size_t chunk = n_samples < r->slot_samples ? n_samples : r->slot_samples;
         const int slot = int(r->slot_seq++ % gm_ring::SLOTS);
         if (r->slot_used[slot]) HIPC(hipEventSynchronize(r->slot_done[slot]));
-        if (!f->d_raw[slot]) HIPC(hipMalloc(&f->d_raw[slot], gm_ring::SLOT_SAMPLES * 8));
+        if (!f->d_raw[slot]) HIPC(hipMalloc(&f->d_raw[slot], gm_ring::SLOT_SAMPLES_MAX * 8));
         memcpy(r->staging[slot], src, chunk * bps);
         HIPC(hipMemcpyAsync(f->d_raw[slot], r->staging[slot], chunk * bps, hipMemcpyHostToDevice, r->copy_stream));
         if (int rc = frontend_launch(f, r->copy_stream, f->d_raw[slot], fmt, r->d_buf, r->write_pos, r->mask, chunk)) return rc;

@@ -104,6 +104,23 @@ int gm_nav_sync_update(gm_nav_sync* s, float old_i_prompt, float i_prompt, uint6
     return GM_OK;
 }
 
+int gm_nav_sync_update_many(gm_nav_sync* s, float old_i_prompt0, const float* i_prompt, size_t stride, size_t n, uint64_t cnt0,
+                            uint64_t buff_loc, gm_nav_status* out, int64_t* first_bit_sync, int64_t* first_frame_sync) {
+    if (!s || (!i_prompt && n) || !stride) return GM_ERR_INVALID_ARG;
+    if (first_bit_sync) *first_bit_sync = -1;
+    if (first_frame_sync) *first_frame_sync = -1;
+    float old = old_i_prompt0;
+    for (size_t k = 0; k < n; ++k) {            // nav_decoding once per epoch (:102-145), as the caller's own loop would
+        const bool had_bit = s->flag_bit_sync, had_frame = s->flag_frame_sync;
+        const float cur = i_prompt[k * stride];
+        if (int rc = gm_nav_sync_update(s, old, cur, cnt0 + k, buff_loc, k + 1 == n ? out : nullptr)) return rc;
+        if (first_bit_sync && !had_bit && s->flag_bit_sync && *first_bit_sync < 0) *first_bit_sync = int64_t(k);
+        if (first_frame_sync && !had_frame && s->flag_frame_sync && *first_frame_sync < 0) *first_frame_sync = int64_t(k);
+        old = cur;
+    }
+    return GM_OK;
+}
+
 int gm_nav_sync_frame_bits(gm_nav_sync* s, int8_t* bits, size_t cap, size_t* n) {
     if (!s || !n) return GM_ERR_INVALID_ARG;
     *n = s->frame_bits.size();

@@ -30,6 +30,16 @@ class NavSyncStatus:
         check(lib().gm_nav_sync_update(self._h, old_i_prompt, i_prompt, int(cnt), int(buff_loc), C.byref(st)), "nav_decoding")
         return {k: getattr(st, k) for k, _ in NavStatus._fields_}
 
+    def update_many(self, old_i_prompt0, i_prompts, cnt0, buff_loc=0):
+        """the same step for the consecutive epochs cnt0 .. (gm_nav_sync_update_many) -> (status dict after the last one,
+        index of the epoch of this call at which bit sync / frame sync first appeared, or -1)"""
+        ip = np.ascontiguousarray(i_prompts, np.float32)
+        st = NavStatus()
+        fb, ff = C.c_int64(-1), C.c_int64(-1)
+        check(lib().gm_nav_sync_update_many(self._h, float(old_i_prompt0), ip.ctypes.data_as(C.c_void_p), 1, ip.size, int(cnt0), int(buff_loc),
+                                            C.byref(st), C.byref(fb), C.byref(ff)), "nav_decoding (many)")
+        return {k: getattr(st, k) for k, _ in NavStatus._fields_}, fb.value, ff.value
+
     def frame_bits(self):
         n = C.c_size_t(0)
         check(lib().gm_nav_sync_frame_bits(self._h, None, 0, C.byref(n)), "frame_bits")

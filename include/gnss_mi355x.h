@@ -423,6 +423,13 @@ int gm_nav_sync_destroy(gm_nav_sync *s);
  * prompt I (TrackingResult.old_i_prompt / i_prompt) */
 int gm_nav_sync_update(gm_nav_sync *s, float old_i_prompt, float i_prompt, uint64_t cnt, uint64_t buff_loc,
                        gm_nav_status *out);
+/* The same step for n consecutive epochs cnt0 .. cnt0 + n - 1 of one channel: i_prompt[k * stride] is epoch k's prompt I, the
+ * previous one of epoch 0 is old_i_prompt0 (a caller that drives 15 channels x 1000 epochs per second through a foreign-function
+ * boundary makes one call per channel and block instead of one per epoch).  *out = the status after the last epoch;
+ * *first_bit_sync / *first_frame_sync (may be NULL) = the index k of the epoch at which the flag first became set in THIS call,
+ * -1 if it did not.  n = 0: nothing happens, *out is left as it is. */
+int gm_nav_sync_update_many(gm_nav_sync *s, float old_i_prompt0, const float *i_prompt, size_t stride, size_t n, uint64_t cnt0,
+                            uint64_t buff_loc, gm_nav_status *out, int64_t *first_bit_sync, int64_t *first_frame_sync);
 int gm_nav_sync_frame_bits(gm_nav_sync *s, int8_t *bits, size_t cap, size_t *n);
 int gm_nav_sync_histogram(gm_nav_sync *s, uint64_t hist[20]);
 /* parity_check (:259-352) on 32 symbols in +-1 form [D29*, D30*, d1..d24, D25..D30]: *ok = all six products match;

@@ -83,6 +83,33 @@ def test_write_ring_equals_process_then_write(gpu, oracle):
         ring.close()
 
 
+def test_write_ring_in_writes_longer_than_a_staging_slot(gpu, oracle):
+    """one gm_frontend_write_ring / gm_ring_write_samples_async call of more samples than a staging slot holds (2^18; min(ring, 2^18)
+    for smaller rings): the call is cut into slot-sized pieces, each with its own copy, front-end launch and head publication, and
+    the front-end's state runs through the cuts — same bits as the oracle's block-by-block front-end, and as the plain writer."""
+    from gnss_sdr_rs_amd import frontend as F, tracking as T
+    rng = np.random.default_rng(81)
+    n = 3 * (1 << 18) + 12_345                          # 4 pieces, the last one ragged
+    raw = rng.integers(-100, 101, 2 * n).astype(np.int8)
+    fe, ofe = F.DigitalFrontend(2.5e6, 10.0e6, 10.0e6), oracle.DigitalFrontend(2.5e6, 10.0e6, 10.0e6)
+    ring = T.MulticastRingBuffer(1 << 20)
+    fe.write_ring(ring, raw[:2 * 1000])                 # a short write first: the slot sequence does not start at a slot boundary
+    fe.write_ring(ring, raw[2 * 1000:])
+    ring.flush()
+    assert ring.get_head() == n
+    f32 = raw.astype(np.float32)
+    want = np.concatenate([ofe.process_block(f32[o:o + 4096].copy()).view(np.complex64) for o in range(0, 2 * n, 4096)])
+    got = ring.copy_to_slice(0, n)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    _same_state(fe, ofe)
+    a, b = T.MulticastRingBuffer(1 << 20), T.MulticastRingBuffer(1 << 20)
+    a.write_samples(want); b.write_samples_async(want); b.flush()
+    assert a.get_head() == b.get_head() == n
+    assert (a.copy_to_slice(0, n).view(np.uint32) == b.copy_to_slice(0, n).view(np.uint32)).all()
+    for h in (fe, ring, a, b):
+        h.close()
+
+
 def test_batch_of_streams_equals_single_stream_calls(gpu, oracle, hipbuf):
     """gm_frontend_process_dev_batch: 5 front-ends with different IFs in one launch, two consecutive calls (state
     continuity) — every stream bit-equal to the oracle run on its own."""

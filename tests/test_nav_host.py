@@ -99,3 +99,40 @@ def test_parity_check_against_is_gps_200_encoder(gm, oracle):
     assert n_ref_disagrees > 0
     with pytest.raises(Exception):
         Dm.parity_check(np.zeros(32, np.int8))
+
+
+def test_update_many_equals_the_per_epoch_steps(gm):
+    """gm_nav_sync_update_many = nav_decoding (decoding.rs:102-145) called once per epoch: same final status, same bits, and the
+    epochs at which bit sync / frame sync first appear are the ones the per-epoch loop sees — whatever the block boundaries."""
+    from gnss_sdr_rs_amd import decoding as Dm
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 2, 150) * 2 - 1
+    for at in (12, 45, 80, 110):
+        data[at:at + 8] = Dm.GPS_CA_PREAMBLE
+    edge, n = 7, 2900
+    ip = np.array([600.0 * data[((e - edge) // 20) % data.size] + 40.0 * rng.standard_normal() for e in range(n)], np.float32)
+    one = Dm.NavSyncStatus(Dm.NAV_FIXED)
+    old, first_bit, first_frame, st1 = 0.0, -1, -1, None
+    for e in range(n):
+        st1 = one.update(float(old), float(ip[e]), e)
+        old = ip[e]
+        if st1["flag_bit_sync"] and first_bit < 0:
+            first_bit = e
+        if st1["flag_frame_sync"] and first_frame < 0:
+            first_frame = e
+    assert first_bit > 0 and first_frame > first_bit
+    many = Dm.NavSyncStatus(Dm.NAV_FIXED)
+    old, fb, ff, st2, e = 0.0, -1, -1, None, 0
+    for blk in (1, 17, 400, 3, 1000, 16, 16, 2000):
+        blk = min(blk, n - e)
+        if blk <= 0:
+            break
+        st2, b, f = many.update_many(old, ip[e:e + blk], e)
+        if b >= 0 and fb < 0:
+            fb = e + b
+        if f >= 0 and ff < 0:
+            ff = e + f
+        old = float(ip[e + blk - 1])
+        e += blk
+    assert e == n and st2 == st1 and (fb, ff) == (first_bit, first_frame)
+    assert (many.frame_bits() == one.frame_bits()).all() and (many.histogram() == one.histogram()).all()
