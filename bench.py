@@ -1082,7 +1082,7 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
            "scene_generation_seconds": t_gen,
            "bound": "the host thread: %d blocks, each one front-end enqueue (asynchronous: copy + kernel run on the ring's copy stream), one "
                     "tracking launch with a synchronisation and a device-to-host copy of the sums, one nav-bit call per channel; the front-end's "
-                    "sequential recurrences cap one stream at ~1 Gsps = 63 x real time (DESIGN 5)" % (-(-n_ms * N // BLK))}
+                    "sequential recurrences cap one stream at ~0.9 Gsps = 55 x real time (DESIGN 5)" % (-(-n_ms * N // BLK))}
     for o in navs:
         o.close()
     mgr.close(); eng.close(); fe.close(); ring.close()
