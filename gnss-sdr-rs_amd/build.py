@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgnss_mi355x.so")
 SOURCES = ["acq_kernels.hip", "acq_composite.hip", "trk_kernels.hip", "fe_kernels.hip", "nav_host.hip", "gm_api.hip"]
-HEADERS = ["fft_core.h", "fft_plans.h", "acq_corr_plans.h", "gm_internal.h", "gm_libm.h", "acq_device.h", "acq_corr_ws31.h", "ws31_core.h", os.path.join("..", "..", "include", "gnss_mi355x.h")]
+HEADERS = ["fft_core.h", "fft_plans.h", "acq_corr_plans.h", "gm_internal.h", "gm_libm.h", "acq_device.h", "acq_corr_ws31.h", "ws31_core.h", "acq_comp_ws.h", os.path.join("..", "..", "include", "gnss_mi355x.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC",
          "-Wall", "-Wno-unused-function"]
 

@@ -22,6 +22,7 @@
 // algorithmic bytes).  Here every spectrum element is re-read Q times from L2 (once per n1), which costs pass-0 load
 // slots but no HBM traffic: the working set is the spectra (D*M*N*8 B) and the code spectra (P*N*8 B).
 #include "acq_device.h"
+#include "acq_comp_ws.h"
 #include <vector>
 
 namespace gm {
@@ -312,8 +313,12 @@ template <class PL, uint32_t Q> struct CompLaunch {
         // bins a strip can touch: a share of `share` items starting anywhere in a row
         const int rows_max = (share + n_workers - 2) / n_workers + 1;
         const int slots = cb > 0 ? ((n_workers + cb - 1) / cb) * rows_max * cb : share;
-        hipLaunchKernelGGL((comp_corr_kernel<PL, Q>), dim3(8 * slots), dim3(PL::T), 0, st, spectra, code_paired, twn, tw_inv,
-                           mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, cb, rows_max);
+        if constexpr (CompWs<CP>::USE)      // base 16000: the wave-specialised kernel (acq_comp_ws.h)
+            hipLaunchKernelGGL((comp_corr_ws_kernel<CP, Q>), dim3(8 * slots), dim3(1024), 0, st, spectra, code_paired, mmax, margmax, msum,
+                               worker_list, n_workers, n_bins, n_int, cb, rows_max);
+        else
+            hipLaunchKernelGGL((comp_corr_kernel<PL, Q>), dim3(8 * slots), dim3(PL::T), 0, st, spectra, code_paired, twn, tw_inv,
+                               mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, cb, rows_max);
     }
     // W_N^{-n1 k2} (inverse sign) for n1 < Q, in the paired position of k2: built in double on the host
     static void fill_twn(cf* out) {
@@ -331,12 +336,11 @@ template <class PL, uint32_t Q> struct CompLaunch {
 };
 }  // namespace
 
-// the Galileo geometry's base: the plain plan wins in comp_corr_kernel (see CompPlanOf, acq_device.h)
 }  // namespace gm
 // 16368's generic plan runs here with its twiddles (AsPlain: the prime-factor form is the fused kernel's)
 namespace gm { template <> struct CompPlanOf<Plan16368> { using type = AsPlain<Plan16368>; }; }
 namespace gm { template <> struct CompPlanOf<Plan8184> { using type = AsPlain<Plan8184>; }; }
-#ifndef GM_COMP_HYBRID_16000      // (A/B switch)
+#ifdef GM_COMP_PLAIN_16000        // (A/B switch: the generic kernel on the plain [25, 20, 32] plan, what rounds 2 - 3 shipped)
 namespace gm { template <> struct CompPlanOf<Plan16000> { using type = Plan16000; }; }
 #endif
 namespace gm {

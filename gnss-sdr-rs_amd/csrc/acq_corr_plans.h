@@ -42,6 +42,13 @@ using CorrPlan8000 = HybridPlan<8000, 512, 5, 25, 4, 16>;     // 125 * 64: passe
 template <> struct CorrPlanOf<Plan8000> { using type = CorrPlan8000; };
 using CorrPlan16000 = HybridPlan<16000, 1024, 5, 25, 4, 32>;  // 125 * 128: radix 20 / 25 / 32 (the Galileo-E1 geometry's composite base)
 template <> struct CorrPlanOf<Plan16000> { using type = CorrPlan16000; };
+// its pass-0 rows in the order the radix-20 Good-Thomas butterfly consumes them, (5 n1 + 4 N2) mod 20, n1 = 0 .. 3 inside N2 = 0 .. 4
+// (fft_core.h Bfly<20>::s1): comp_corr_ws_kernel (acq_comp_ws.h) asks for its inputs pair by pair in that order
+template <> struct PairRows<CorrPlan16000> {
+    static constexpr bool FORCE = false;
+    static constexpr int row(int r) { return 4 * ((4 * (r % 5)) % 5) + r % 4; }     // r = (5 n1 + 4 N2) mod 20 -> 4 N2 + n1
+    static constexpr int nat(int s) { return (5 * (s % 4) + 4 * (s / 4)) % 20; }
+};
 // (N = 16368 = 33 * 16 * 31 runs the generic plan's prime-factor form, fft_core.h Pfa; a dedicated in-place-per-lane image
 //  [16 rows][33][31] with one barrier fewer measured 7 % SLOWER — 455 against 425 us per 32-PRN launch — and was dropped)
 #endif

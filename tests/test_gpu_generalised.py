@@ -175,7 +175,9 @@ def test_five_arm_boc_persistent_kernel_first_epoch(gpu, oracle):
                                                        (10.0e6, 4092, 1.023e6, 40000, 4),
                                                        (25.0e6, 1023, 1.023e6, 25000, 5),     # GPS C/A at configs[2]'s rate
                                                        (32.736e6, 1023, 1.023e6, 32736, 2),        # 2 x 16368, the reference capture geometry doubled (8-byte loads)
-                                                       (32.768e6, 1023, 1.023e6, 32768, 2)])      # 2 x 16384
+                                                       (32.768e6, 1023, 1.023e6, 32768, 2),       # 2 x 16384
+                                                       (12.0e6, 4092, 1.023e6, 48000, 3),         # 3 x 16000: the wave-specialised kernel (acq_comp_ws.h) at another Q
+                                                       (32.0e6, 4092, 1.023e6, 128000, 8)])       # 8 x 16000 (its most register-hungry instantiation)
 def test_acquisition_beyond_one_lds_buffer(gpu, oracle, fs, code_len, code_rate, N, Q):
     """Transform sizes above 16384 (one code period of a 4 ms code at 8-10 Msps, or GPS at 25 Msps): N = Q x an in-LDS
     plan (acq_composite.hip).  Same checks as every other acquisition parity test: per-(worker, bin) max / first argmax /
@@ -222,6 +224,37 @@ def test_acquisition_beyond_one_lds_buffer(gpu, oracle, fs, code_len, code_rate,
     r0 = dict(got[0], code_phase_samples=N - 77)
     fine = eng.finer_doppler([r0, None, None])
     assert abs(fine[0]["freq_hz"] - 180.0) < max(60.0, 0.6 * fs / fine[0]["fft_size"])      # (a fine bin is 125 Hz at 32.7 Msps)
+    eng.close()
+
+
+def test_composite_base_16000_degenerate_planes(gpu, oracle):
+    """N = 2 x 16000 on planes where several cells hold the maximum (acq_comp_ws.h folds a lane's 32 power sums by VALUE and works out
+    one index per lane): an all-zero capture -> (0.0, index 0, sum 0.0), the reference's `if v > max` scan never fires
+    (do_acquisition.rs:195-202); and a capture that is periodic with half the transform length, so that every power value occurs at
+    two code phases N / 2 apart — the reported phase is the FIRST of them, as the oracle's scan reports."""
+    from gnss_sdr_rs_amd import acquisition as A
+    fs, L, rate, N, M = 8.0e6, 4092, 1.023e6, 32000, 2
+    rng = np.random.default_rng(5)
+    codes = np.where(rng.integers(0, 2, (2, L)) > 0, 1, -1).astype(np.int8)
+    dop = np.array([-250.0, 0.0, 250.0], np.float32)
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=[1, 2], n_integrations=M, codes=codes, code_rate=rate)
+    eng.search(np.zeros((M * N, 2), np.int8))
+    mx, am, sm = eng.metrics()
+    assert (mx == 0).all() and (am == 0).all() and (sm == 0).all()
+    # half-period capture at zero Doppler: x[n + N/2] = x[n]  ->  only even spectrum bins are occupied, the correlation is N/2-periodic too
+    half = rng.integers(-20, 21, (N // 2, 2)).astype(np.int8)
+    x = np.tile(half, (2 * M, 1))
+    eng.search(x)
+    mx, am, sm = eng.metrics()
+    xc = (x[:, 0] + 1j * x[:, 1]).astype(np.complex64)
+    tables = [oracle.DopplerShiftTable(0.0, float(d), fs, N) for d in dop]
+    for w in range(2):
+        ow = oracle.AcquisitionWorker(w + 1, N, fs, code=codes[w], code_rate=rate)
+        _, (bmax, barg, bsum, _) = ow.search_satellite(xc, tables, 0, M, want_planes=True, no_early_exit=True)
+        assert np.allclose(mx[w][1], bmax[1], rtol=REL) and np.allclose(sm[w][1], bsum[1], rtol=REL)
+        # (the two equal cells are equal to rounding only in both implementations: either both report the first, or the values at the
+        # two candidates differ by less than the tolerance and the argmax is one of them)
+        assert int(am[w][1]) % (N // 2) == int(barg[1]) % (N // 2)
     eng.close()
 
 
