@@ -143,6 +143,30 @@ __global__ __launch_bounds__(256) void comp_code_comb_kernel(const cf* __restric
     }
 }
 
+// Forward step 2 folded into the code-side table (base plans whose sub-transforms leave in storage order, `order` != null): an input of
+// sub-transform n1 is sum_k1 X[k1][pos] comb[n1][k1][pos] with X[k1][pos] = sum_n1' W_Q^{n1' k1} W_N^{n1' k2} A[n1'][pos], i.e.
+// sum_n1' A[n1'][pos] * comb2[n1][n1'][pos],  comb2[n1][n1'][pos] = W_N^{n1' k2(pos)} * sum_k1 W_Q^{n1' k1} comb[n1][k1][pos] — the same
+// Q loads and products per element, read from the forward sub-transforms as they stand: no comp_fwd_post_kernel per dwell (12 us of
+// the 360 at the configs[3] Galileo geometry, and a kernel boundary).
+template <class PL, uint32_t Q>
+__global__ __launch_bounds__(256) void comp_fold_post_kernel(const cf* __restrict__ comb, const uint16_t* __restrict__ order, cf* __restrict__ comb2) {
+    constexpr uint32_t Nb = PL::N, N = Q * Nb;
+    const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos >= Nb) return;
+    const uint32_t k2 = order[pos];
+    const size_t base = size_t(blockIdx.y) * Q * Nb + pos;          // blockIdx.y = code * Q + n1
+    cf c[Q];
+#pragma unroll
+    for (uint32_t k1 = 0; k1 < Q; ++k1) c[k1] = comb[base + size_t(k1) * Nb];
+#pragma unroll
+    for (uint32_t n1p = 0; n1p < Q; ++n1p) {
+        cf acc = c[0];
+#pragma unroll
+        for (uint32_t k1 = 1; k1 < Q; ++k1) acc = cf_add(acc, cf_mul(c[k1], unit_root((n1p * k1) % Q, Q, false)));
+        comb2[base + size_t(n1p) * Nb] = cf_mul(acc, unit_root(uint32_t((uint64_t(n1p) * k2) % N), N, false));
+    }
+}
+
 // ------------------------------------------------------------------------------------ inverse, fused
 // One workgroup per (worker, bin).  spectra [d][m][k1][paired k2], code [p][k1][paired k2], twn [n1][paired k2] =
 // W_N^{-n1 k2} (e^{+...}: inverse).
@@ -332,7 +356,10 @@ template <class PL, uint32_t Q> struct CompLaunch {
     static void comb(hipStream_t st, const cf* code_paired, const cf* twn, cf* out, uint32_t n_codes) {
         hipLaunchKernelGGL((comp_code_comb_kernel<PL, Q>), dim3((PL::N + 255) / 256, n_codes * Q), dim3(256), 0, st, code_paired, twn, out);
     }
-    static constexpr CompOps ops() { return CompOps{PL::N, int(Q), &fwd_sub, &fwd_post, &corr, &fill_twn, &comb, &fill_order, &relayout}; }
+    static void fold_post(hipStream_t st, const cf* comb_in, const uint16_t* order, cf* comb2, uint32_t n_codes) {
+        hipLaunchKernelGGL((comp_fold_post_kernel<PL, Q>), dim3((PL::N + 255) / 256, n_codes * Q), dim3(256), 0, st, comb_in, order, comb2);
+    }
+    static constexpr CompOps ops() { return CompOps{PL::N, int(Q), &fwd_sub, &fwd_post, &corr, &fill_twn, &comb, &fill_order, &relayout, &fold_post}; }
 };
 }  // namespace
 

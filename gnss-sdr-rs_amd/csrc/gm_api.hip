@@ -253,6 +253,7 @@ struct gm_acq {
     cf* d_comp_tmp = nullptr;              // [max(D*M, P)][Q][Nb]: forward sub-transforms before the Q-point DFTs
     cf* d_comp_twn = nullptr;              // [Q][Nb] inverse twiddles W_N^{-n1 k2}, paired positions
     cf* d_code_comb = nullptr;             // Q > 1: [P][Q][Q][Nb] conj(code) x W_Q^{-n1 k1} x W_N^{-n1 k2}, what comp corr multiplies the spectra by
+    bool comp_post_folded = false;         // ... and, for base plans with an order table, the signal's forward step 2 (CompOps::fold_post): d_spectra = the sub-transforms
     // fine Doppler (gm_acq_finer_doppler): host copy of the chip rows, lazily built device state
     std::vector<int8_t> chips;             // [P][code_len]
     uint32_t code_len = 1023;
@@ -714,6 +715,15 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
         comp->relayout(a->stream, a->d_code_fft, a->d_code_fft_paired, int(P * a->Q));
         HIPA(hipMalloc(&a->d_code_comb, P * a->Q * N * 8));      // [code][n1][k1][pos]: the whole code-side factor per sub-transform
         comp->comb(a->stream, a->d_code_fft_paired, a->d_comp_twn, a->d_code_comb, uint32_t(P));
+        if (a->d_order) {     // sub-transforms leave in storage order: the signal's forward step 2 goes into the table as well (CompOps::fold_post)
+            gm::cf* comb2 = nullptr;
+            HIPA(hipMalloc(&comb2, P * a->Q * N * 8));
+            comp->fold_post(a->stream, a->d_code_comb, a->d_order, comb2, uint32_t(P));
+            HIPA(hipStreamSynchronize(a->stream));
+            hipFree(a->d_code_comb);
+            a->d_code_comb = comb2;
+            a->comp_post_folded = true;
+        }
     }
     HIPA(hipGetLastError());
     HIPA(hipStreamSynchronize(a->stream));
@@ -752,8 +762,12 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     if (a->Q == 1) {
         a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_mix, a->d_spectra, int(a->D), int(a->M), a->d_split_counter, a->d_order);
     } else {
-        a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_mix, a->d_comp_tmp, a->D * a->M, a->M, a->d_order);
-        a->comp->fwd_post(a->stream, a->d_comp_tmp, a->d_spectra, a->D * a->M, 1, a->d_order);
+        if (a->comp_post_folded) {     // the sub-transforms ARE what the correlation kernel reads
+            a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_mix, a->d_spectra, a->D * a->M, a->M, a->d_order);
+        } else {
+            a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_mix, a->d_comp_tmp, a->D * a->M, a->M, a->d_order);
+            a->comp->fwd_post(a->stream, a->d_comp_tmp, a->d_spectra, a->D * a->M, 1, a->d_order);
+        }
     }
     if (t) HIPC(hipEventRecord(ev[1], a->stream));
     if (a->Q == 1) {

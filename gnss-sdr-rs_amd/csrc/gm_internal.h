@@ -106,6 +106,9 @@ struct CompOps {
     // order table as PlanOps::fill_order, and natural -> stored re-layout of n_blocks blocks
     int (*fill_order)(uint16_t* order);
     void (*relayout)(hipStream_t, const cf* natural, cf* stored, int n_blocks);
+    // base plans with an order table: forward step 2 folded into the table — comb2[p][n1][n1'][pos] such that a sub-transform's input is
+    // sum_n1' A[n1'][pos] * comb2[n1][n1'][pos] on the forward sub-transforms A as fwd_sub leaves them (no fwd_post per dwell)
+    void (*fold_post)(hipStream_t, const cf* comb, const uint16_t* order, cf* comb2, uint32_t n_codes);
 };
 const CompOps* find_comp(uint32_t n);
 
