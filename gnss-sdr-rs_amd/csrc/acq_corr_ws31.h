@@ -123,7 +123,7 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
     const __amdgpu_buffer_rsrc_t crs = make_rsrc(code_fft + size_t(p) * PL::N, PL::N * 8u);
     const int m_per = n_int / parts, m_begin = part * m_per, m_end = m_begin + m_per;
 
-    __shared__ float lacc[MF::RL * 64];                            // wave W0's left-over batch: its eight power sums per lane, [slot][lane]
+    __shared__ float lacc[MF::RL * 64];                            // the left-over batch's eight power sums per lane of wave W0's map, [slot][lane]
     if (wave == W0) {
 #pragma unroll
         for (int r = 0; r < MF::RL; ++r) lacc[r * 64 + (tid & 63)] = 0.0f;
@@ -143,15 +143,37 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
     auto out = [&](int it, int r, cf v) {
         if constexpr (REF_MUL) acc[it][r] = acc[it][r] + (v.x * v.x + v.y * v.y);
         else acc[it][r] = acc[it][r] + __builtin_fmaf(v.y, v.y, v.x * v.x);
+        // (pinned here: left alone, hipcc moves the sums of ALL batches behind the last batch's products — the four products' 16
+        // result registers per batch stay live until then, and the power sums go to scratch memory)
+        asm volatile("" : "+v"(acc[it][r]));
     };
-    // the same for the left-over batch (wave W0; a lane reads and writes only its own words, in program order)
+    // the same for the left-over batch (run by wave WX: a lane reads and writes only its own words, in program order)
     auto out_lds = [&](int, int r, cf v) {
         float* a = &lacc[r * 64 + (tid & 63)];
         if constexpr (REF_MUL) *a = *a + (v.x * v.x + v.y * v.y);
         else *a = *a + __builtin_fmaf(v.y, v.y, v.x * v.x);
     };
+    constexpr int WX = 0;                                         // the pass-0 wave that runs the left-over batch
+    __shared__ float xcs[8 * 64];                                 // ... and its lanes' matrix entries (Mfma31::Consts of wave W0's map)
+    const int tid_x = 64 * W0 + (tid & 63);                      // ... as lane (tid & 63) of wave W0's map
     if (wave < W0) {
         // ---------------------------------------------------------------- pass-0 role (vector + texture-address units)
+        // its lane constants wait in LDS and its gather bases are recomputed per use (lane number through an opaque move): kept in
+        // registers across the loop they were ten more live values on every pass-0 wave, and hipcc reloaded two of them from scratch
+        // memory behind B1
+        if (wave == WX) {
+            const typename MF::Consts xc0 = MF::consts(tid_x);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xcs[i * 64 + (tid & 63)] = xc0.c[i]; xcs[(4 + i) * 64 + (tid & 63)] = xc0.s[i]; }
+        }
+        auto left_over = [&]() {
+            int tx = tid_x;
+            asm volatile("" : "+v"(tx));
+            typename MF::Consts xconst;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xconst.c[i] = xcs[i * 64 + (tx & 63)]; xconst.s[i] = xcs[(4 + i) * 64 + (tx & 63)]; }
+            MF::left_over_batch(MF::bases(lds, tx), tx, xconst, out_lds);
+        };
         // Both arrays are stored in row PAIRS, in the order the radix-33 butterfly consumes its inputs (PairRows, acq_corr_plans.h):
         // input r is stored row s = row(r), half s & 1 of the 16-byte pair s >> 1 of this lane; the two inputs of a pair are asked for
         // one after the other, and the second request of the same pair is the same load expression (one load instruction).
@@ -184,6 +206,8 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
             {
                 cf v0[PL::IT0][PL::R0];
                 Fft<PL, true, true>::pass0_stage1(v0, in, tid);
+                // the left-over batch of transform m - 1 (its radix-31 inputs are in the image until B1), in this wave's wait for B1
+                if (wave == WX && m > m_begin) left_over();
                 ws31_stamp<STAMPS>(stb, m, 0, 1);
                 __syncthreads();                                    // B1: the image is free
                 ws31_stamp<STAMPS>(stb, m, 0, 2);
@@ -207,18 +231,13 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
             MiddlePasses<PL, true, 1, true>::run(lds, nullptr, tid);   // B3, B4 inside
             ws31_stamp<STAMPS>(stb, m, 0, 5);
         }
+        if (wave == WX) left_over();                                // the last transform's
+        __syncthreads();                                            // the left-over batch's sums are complete
     } else {
         // ---------------------------------------------------------------- matrix-pipe role (owns the power sums)
         for (int m = m_begin; m < m_end; ++m) {
             ws31_stamp<STAMPS>(stb, m, 1, 0);
-            if (m > m_begin) {                                      // the radix-31 pass of transform m - 1, beside pass 0 of transform m
-#pragma unroll
-                for (int it = 0; it < ITF; ++it) {
-                    MF::batch(it, mb, tid, mconst, out);
-                    __builtin_amdgcn_sched_barrier(0);             // one batch at a time: two fused ones cost 32 more registers
-                }
-                if constexpr (MF::EXTRA == 1) MF::batch(ITF, mb, tid, mconst, out_lds);     // wave W0 only (wave-uniform inside)
-            }
+            if (m > m_begin) MF::pass(mb, tid, mconst, out);        // the radix-31 pass of transform m - 1, beside pass 0 of transform m
             ws31_stamp<STAMPS>(stb, m, 1, 1);
             __syncthreads();                                        // B1: every gather of transform m - 1 has been read
             ws31_stamp<STAMPS>(stb, m, 1, 2);
@@ -227,13 +246,9 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
             MiddlePasses<PL, true, 1, true>::run(lds, nullptr, tid);   // B3, B4 inside
             ws31_stamp<STAMPS>(stb, m, 1, 5);
         }
-#pragma unroll
-        for (int it = 0; it < ITF; ++it) {                          // the last transform's
-            MF::batch(it, mb, tid, mconst, out);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        MF::pass(mb, tid, mconst, out);                             // the last transform's
+        __syncthreads();                                            // the left-over batch's sums are complete (wave WX)
         if constexpr (MF::EXTRA == 1) {
-            MF::batch(ITF, mb, tid, mconst, out_lds);
             if (wave == W0) {                                       // the left-over batch's sums join the register slots for the epilogue
 #pragma unroll
                 for (int r = 0; r < ARL; ++r) acc[ITF][r] = lacc[r * 64 + (tid & 63)];

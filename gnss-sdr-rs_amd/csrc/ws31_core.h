@@ -11,11 +11,11 @@ namespace gm {
 template <int N_> struct Ws31PlanOf { using type = Plan<N_, 1024, 33, 16, 31>; };
 
 // the matrix-pipe radix-31 pass: NWM waves starting at wave W0 share the NB / 16 batches — wave w takes batches (w - W0) + NWM it,
-// it < ITF = NBATCH / NWM, power sums in registers — and the one batch left over (33 = 8 x 4 + 1) is wave W0's batch it = ITF, whose
-// eight power sums per lane live in LDS (2 KB of the 25 KB the image leaves free) while the integrations run: a fifth set of
-// registers (40 power sums + the pass's ~80) spills under the 128-register cap, and a scratch reload inside the matrix loop queues
-// behind the pass-0 waves' 528 loads (measured: 3 300 cycles per batch instead of 1 200); on a pass-0 wave instead, the batch delays
-// that wave's loads and the whole workgroup waits for it at B1 (2 400 - 4 000 cycles per transform).
+// it < ITF = NBATCH / NWM, power sums in registers — and the one batch left over (33 = 8 x 4 + 1) has wave W0's lane map at it = ITF;
+// its eight power sums per lane live in LDS (2 KB of the 25 KB the image leaves free) while the integrations run.  It is run by a
+// PASS-0 wave, behind that wave's first half and in front of B1, where the pass-0 waves wait for the matrix waves anyway (~4 500
+// cycles per transform): on a matrix wave it made that wave's phase five batches long against the others' four (the whole
+// workgroup waits for the longest), and a fifth register set of power sums spills under the 128-register cap.
 template <class PL, int W0, int NWM> struct Mfma31 {
     static constexpr int NB = PL::NB(PL::NP - 1), NBATCH = NB / 16;
     static constexpr int ITF = NBATCH / NWM, EXTRA = NBATCH - NWM * ITF, ITL = ITF + EXTRA, RL = 8;
@@ -63,24 +63,48 @@ template <class PL, int W0, int NWM> struct Mfma31 {
         return Bases{lds + col + kg * NB, lds + col + (19 - kg) * NB};
     }
 #if defined(__HIPCC__)
+    // One batch in two steps, so that the caller can request batch it + 1's gathers before it runs batch it's products (asked for
+    // where they are used, every pair of LDS reads was followed by a full wait: eight exposed LDS latencies per batch, 32 per transform).
+    struct Gather { cf up[4], um[4]; };
+    static __device__ __forceinline__ void gather(int it, const Bases& bs, int tid, Gather& g) {
+        if (batch_active(tid, it)) {                              // wave-uniform
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                g.up[st] = bs.pa[st * 4 * NB + it * 16 * NWM];
+                g.um[st] = bs.pb[(3 - st) * 4 * NB + it * 16 * NWM];
+            }
+        }
+    }
     template <class Out>
-    static __device__ __forceinline__ void batch(int it, const Bases& bs, int tid, const Consts& m, Out&& out) {
+    static __device__ __forceinline__ void products(int it, const Gather& g, int tid, const Consts& m, Out&& out) {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         const int kg = (tid >> 4) & 3;
         if (batch_active(tid, it)) {                              // wave-uniform
             f32x4 dcr = {0.f, 0.f, 0.f, 0.f}, dci = dcr, dsr = dcr, dsi = dcr;
+            // the 16 operands first, then the 16 matrix instructions back to back: with a vector instruction in front of every matrix
+            // instruction (the form hipcc picks to save registers) each of them waits for its turn on the vector pipe, which the
+            // pass-0 waves of the same SIMD keep busy, and the matrix pipe idles in between (measured: 42 % busy in this phase)
+            cf a[4], b[4];
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const int k = 4 * st + kg;
-                const cf up = bs.pa[st * 4 * NB + it * 16 * NWM];
-                const cf um = bs.pb[(3 - st) * 4 * NB + it * 16 * NWM];
-                const cf a = k == 0 ? up : cf_add(up, um);
-                const cf b = k == 0 ? cf_make(0.f, 0.f) : cf_sub(up, um);
-                dcr = __builtin_amdgcn_mfma_f32_16x16x4f32(m.c[st], a.x, dcr, 0, 0, 0);
-                dci = __builtin_amdgcn_mfma_f32_16x16x4f32(m.c[st], a.y, dci, 0, 0, 0);
-                dsr = __builtin_amdgcn_mfma_f32_16x16x4f32(m.s[st], b.x, dsr, 0, 0, 0);
-                dsi = __builtin_amdgcn_mfma_f32_16x16x4f32(m.s[st], b.y, dsi, 0, 0, 0);
+                const cf up = g.up[st], um = g.um[st];
+                a[st] = k == 0 ? up : cf_add(up, um);
+                b[st] = k == 0 ? cf_make(0.f, 0.f) : cf_sub(up, um);
             }
+#ifndef X_NOGROUP
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                dcr = __builtin_amdgcn_mfma_f32_16x16x4f32(m.c[st], a[st].x, dcr, 0, 0, 0);
+                dci = __builtin_amdgcn_mfma_f32_16x16x4f32(m.c[st], a[st].y, dci, 0, 0, 0);
+                dsr = __builtin_amdgcn_mfma_f32_16x16x4f32(m.s[st], b[st].x, dsr, 0, 0, 0);
+                dsi = __builtin_amdgcn_mfma_f32_16x16x4f32(m.s[st], b[st].y, dsi, 0, 0, 0);
+            }
+#ifndef X_NOGROUP
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float car = dcr[r], cai = dci[r], sbr = dsr[r], sbi = dsi[r];
@@ -89,6 +113,30 @@ template <class PL, int W0, int NWM> struct Mfma31 {
                 out(it, 2 * r + 1, none ? cf_make(0.f, 0.f) : cf_make(car + sbi, cai - sbr));      // y[31 - q] = ca - j sb
             }
         }
+    }
+    template <class Out>
+    static __device__ __forceinline__ void batch(int it, const Bases& bs, int tid, const Consts& m, Out&& out) {
+        Gather g;
+        gather(it, bs, tid, g);
+        products(it, g, tid, m, out);
+    }
+    // the radix-31 pass of one transform on this lane's wave: batches 0 .. ITF - 1 into out(it, r8, y); the gathers of batch it + 1 are
+    // in flight while batch it's products run
+    template <class Out>
+    static __device__ __forceinline__ void pass(const Bases& bs, int tid, const Consts& m, Out&& out) {
+        Gather g[2];
+        gather(0, bs, tid, g[0]);
+#pragma unroll
+        for (int it = 0; it < ITF; ++it) {
+            if (it + 1 < ITF) gather(it + 1, bs, tid, g[(it + 1) & 1]);
+            products(it, g[it & 1], tid, m, out);
+        }
+    }
+    // the left-over batch (it = ITF of wave W0's lane map): run by whichever wave has the time, with tid = that map's lane
+    // (64 W0 + lane) and the constants / bases of that lane
+    template <class Out>
+    static __device__ __forceinline__ void left_over_batch(const Bases& bs, int tid_w0, const Consts& m, Out&& out) {
+        if constexpr (EXTRA == 1) batch(ITF, bs, tid_w0, m, out);
     }
 #endif
 };
