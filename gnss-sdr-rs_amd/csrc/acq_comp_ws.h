@@ -14,8 +14,8 @@
 //     middle pass — its ten wave-slots on eight waves, waves 0 and 1 take two — separated from the last pass by a barrier of their own
 //     (an LDS word, comp_ws_wave_group_barrier: the hardware barrier would stop the other waves too);
 //   * waves 8 - 15 do pass 0 and nothing else: the 2Q loads per row pair, the Q products, the radix-20 Good-Thomas butterfly's first
-//     half — 800 butterflies on 512 lanes: two per lane on lanes 0 - 287, whose second butterfly parks 12 of its 20 intermediate values
-//     in the 35 KB of LDS the image leaves free.  From B2 of sub-transform s they go straight to the loads of s + 1, which are in flight
+//     half — 800 butterflies on 512 lanes: two per lane on lanes 0 - 287, whose second butterfly parks 15 of its 20 intermediate values
+//     in the 35 KB of LDS the image leaves free; the first loads of s + 1 are requested in front of B1 of s.  From B2 of sub-transform s they go straight to the loads of s + 1, which are in flight
 //     during the middle AND the last pass of s.  They hold no power sums and never run a radix-25 or radix-32 butterfly.
 //
 // Workgroup barriers per sub-transform (every wave executes the same two):
@@ -27,7 +27,7 @@
 // load feeds the next two inputs and nothing waits in registers for its partner.
 //
 // Measured (configs[3] Galileo geometry, 36 codes x 41 bins x 2 periods; tools/corr_lab/comp_ws_stamps.hip): 307 us for
-// the lockstep kernel on the plain [25, 20, 32] plan -> 258 us.  The pass-0 waves now stream 512 KB per 5.3 us and CU (~100 GB/s of the
+// the lockstep kernel on the plain [25, 20, 32] plan -> 255 us (rocprofv3 in bench.py: 243).  The pass-0 waves now stream 512 KB per 5.3 us and CU (~100 GB/s of the
 // 125 the load path gives): the kernel is bound by its loads.  What it took beyond the roles — every item cost a multiple of its size
 // in a first version that ran at 531 us:
 //   * no scratch memory inside the loops.  A spilled register is reloaded through the same load path as the pass-0 waves' requests and
@@ -40,6 +40,7 @@
 #pragma once
 #include "acq_device.h"
 #include <type_traits>
+
 
 namespace gm {
 
@@ -98,30 +99,37 @@ template <class PL, uint32_t Q, int A> struct CompWsGroup {
         }
     }
 };
-template <class PL, uint32_t Q, int DEPTH, class Emit>
-__device__ __forceinline__ void comp_ws_first_half(Emit&& emit, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t crs, int v16, int xoff) {
+template <class PL, uint32_t Q> struct CompWsStream {
     using B0 = Bfly<PL::R0, true>;
-    static_assert(B0::KIND == 2 && B0::A % 2 == 0 && (DEPTH == 1 || DEPTH == 2), "first radix: Good-Thomas, groups of an even number of rows");
+    static_assert(B0::KIND == 2 && B0::A % 2 == 0 && B0::B >= 2, "first radix: Good-Thomas, groups of an even number of rows");
+    // groups in flight (a group is 4Q 16-byte loads = 16Q registers): two at Q = 2, one above (two would be 96+ registers)
+    static constexpr int DEPTH = Q <= 2 ? 2 : 1;
     CompWsGroup<PL, Q, B0::A> buf[DEPTH];
-    buf[0].request(xrs, crs, v16, xoff, 0);
+    // request the first DEPTH groups of a butterfly (they may then be in flight across a barrier: run() consumes them first)
+    __device__ __forceinline__ void start(__amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t crs, int v16, int xoff) {
 #pragma unroll
-    for (int g = 0; g < B0::B; ++g) {
-        if (DEPTH == 2 && g + 1 < B0::B) buf[(g + 1) & 1].request(xrs, crs, v16, xoff, g + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        cf t[B0::A];
-        buf[DEPTH == 2 ? (g & 1) : 0].inputs(t);
-        if (DEPTH == 1 && g + 1 < B0::B) buf[0].request(xrs, crs, v16, xoff, g + 1);     // (behind the last use of the group in hand)
-        Dft<B0::A, true>::run(t);
-#pragma unroll
-        for (int k1 = 0; k1 < B0::A; ++k1) {
-            // (the values are pinned HERE: left alone, hipcc requests all 20Q loads at once and moves every product and the whole
-            // butterfly behind the barrier that follows, 128 registers of loads in flight across it and 9 spilled 16-byte loads)
-            asm volatile("" : "+v"(t[k1].x), "+v"(t[k1].y));
-            emit(g * B0::A + k1, t[k1]);                      // (index: a compile-time constant after unrolling)
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < DEPTH; ++g) buf[g].request(xrs, crs, v16, xoff, g);
     }
-}
+    template <class Emit>
+    __device__ __forceinline__ void run(Emit&& emit, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t crs, int v16, int xoff) {
+#pragma unroll
+        for (int g = 0; g < B0::B; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            cf t[B0::A];
+            buf[g % DEPTH].inputs(t);
+            if (g + DEPTH < B0::B) buf[g % DEPTH].request(xrs, crs, v16, xoff, g + DEPTH);      // (behind the last use of the group in hand)
+            Dft<B0::A, true>::run(t);
+#pragma unroll
+            for (int k1 = 0; k1 < B0::A; ++k1) {
+                // (the values are pinned HERE: left alone, hipcc requests all 20Q loads at once and moves every product and the whole
+                // butterfly behind the barrier that follows, 128 registers of loads in flight across it and 9 spilled 16-byte loads)
+                asm volatile("" : "+v"(t[k1].x), "+v"(t[k1].y));
+                emit(g * B0::A + k1, t[k1]);                  // (index: a compile-time constant after unrolling)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
 
 // The last pass as a function of its own, the image handed over as a pointer: called on the __shared__ array itself from the kernel body,
 // the same two calls cost 220 spilled registers (tools/ubench/ README: what hipcc's scheduler does with exact alias information)
@@ -201,15 +209,13 @@ __device__ __forceinline__ void comp_corr_ws_body(
         stb = (blockIdx.x % 504 == 0 && blockIdx.x < 2016 && (tid & 63) == 0 && (wave == 0 || wave == WB - 1 || wave == WB) && g_comp_ws_stamps)
                   ? g_comp_ws_stamps + size_t(blockIdx.x / 504) * S * 24 : nullptr;
     // sub-transform s reads the spectrum blocks of integration m and the combined tables of n1; b0: the lane's pass-0 butterfly
-    auto first_half = [&](int s, int b0, auto depth, auto&& emit) {
-        const int n1 = s / n_int, m = s - n1 * n_int;
-        const __amdgpu_buffer_rsrc_t crs = make_rsrc(code_fft + (size_t(p) * Q + n1) * N, N * 8u);
-        comp_ws_first_half<PL, Q, decltype(depth)::value>(emit, xrs, crs, b0 * 16, m * int(Q) * Nb);
-    };
+    // sub-transform s reads the spectrum blocks of integration m and the combined tables of n1
+    auto crs_of = [&](int s) { return make_rsrc(code_fft + (size_t(p) * Q + s / n_int) * N, N * 8u); };
+    auto xoff_of = [&](int s) { return (s % n_int) * int(Q) * Nb; };
     // A lane with two butterflies keeps the first NST intermediate values of its second one in LDS until the image is free (the 35 KB
     // the image leaves: a lane reads and writes only its own words): with all 40 values of both in registers beside the loads in
     // flight, hipcc spilled 11 registers and the scatter phase began with their reloads from scratch memory
-    constexpr int NST = 12;
+    constexpr int NST = 15;
     __shared__ cf stage[NST * (NA2 > 0 ? NA2 : 1)];
     __syncthreads();                                          // (group_word is zero)
 
@@ -225,6 +231,8 @@ __device__ __forceinline__ void comp_corr_ws_body(
     if (wave >= WB) {
         // ---------------------------------------------------------------- pass 0 only (vector memory + a radix-20 butterfly or two)
         const int a0 = tid - 64 * WB;
+        CompWsStream<PL, Q> st;
+        st.start(xrs, crs_of(0), a0 * 16, xoff_of(0));
         for (int s = 0; s < S; ++s) {
             // (the lane number goes through an opaque move in every iteration: the addresses derived from it — load offsets, the staging
             // slot, the scatter bases — are then worked out where they are used, a few instructions each; hoisted out of the loop they were
@@ -234,11 +242,18 @@ __device__ __forceinline__ void comp_corr_ws_body(
             const bool two = a < NA2;
             cf va[1][R0], vb[1][R0];
             comp_ws_stamp<STAMPS>(stb, s, wslot, 0);
-            first_half(s, a, std::integral_constant<int, 2>(), [&](int i, cf val) { va[0][i] = val; });
-            if (two) first_half(s, NA + a, std::integral_constant<int, 2>(), [&](int i, cf val) {
-                if (i < NST) stage[i * NA2 + a] = val;
-                else vb[0][i] = val;
-            });
+            const __amdgpu_buffer_rsrc_t crs = crs_of(s);
+            const int xoff = xoff_of(s);
+            st.run([&](int i, cf val) { va[0][i] = val; }, xrs, crs, a * 16, xoff);
+            if (two) {
+                st.start(xrs, crs, (NA + a) * 16, xoff);
+                st.run([&](int i, cf val) {
+                    if (i < NST) stage[i * NA2 + a] = val;
+                    else vb[0][i] = val;
+                }, xrs, crs, (NA + a) * 16, xoff);
+            }
+            // the first groups of the NEXT sub-transform are requested here: in flight while this wave waits for B1 and scatters
+            if (s + 1 < S) st.start(xrs, crs_of(s + 1), a * 16, xoff_of(s + 1));
             comp_ws_stamp<STAMPS>(stb, s, wslot, 1);
             __syncthreads();                                  // B1
             comp_ws_stamp<STAMPS>(stb, s, wslot, 2);
