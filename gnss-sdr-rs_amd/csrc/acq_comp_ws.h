@@ -208,8 +208,7 @@ __device__ __forceinline__ void comp_corr_ws_body(
     if constexpr (STAMPS)
         stb = (blockIdx.x % 504 == 0 && blockIdx.x < 2016 && (tid & 63) == 0 && (wave == 0 || wave == WB - 1 || wave == WB) && g_comp_ws_stamps)
                   ? g_comp_ws_stamps + size_t(blockIdx.x / 504) * S * 24 : nullptr;
-    // sub-transform s reads the spectrum blocks of integration m and the combined tables of n1; b0: the lane's pass-0 butterfly
-    // sub-transform s reads the spectrum blocks of integration m and the combined tables of n1
+    // sub-transform s reads the spectrum blocks of integration m = s mod n_int and the combined tables of n1 = s / n_int
     auto crs_of = [&](int s) { return make_rsrc(code_fft + (size_t(p) * Q + s / n_int) * N, N * 8u); };
     auto xoff_of = [&](int s) { return (s % n_int) * int(Q) * Nb; };
     // A lane with two butterflies keeps the first NST intermediate values of its second one in LDS until the image is free (the 35 KB
