@@ -258,6 +258,31 @@ def test_composite_base_16000_degenerate_planes(gpu, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("M", [1, 3])
+def test_composite_base_16000_other_integration_counts(gpu, oracle, M):
+    """N = 2 x 16000 with one and with three integrations (the wave-specialised kernel's pipeline has Q x M stages: its first and its
+    last stage are special, and with M = 1 every stage is the first or the last of an n1 block): planes against the oracle."""
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    fs, L, rate, N = 8.0e6, 4092, 1.023e6, 32000
+    rng = np.random.default_rng(50 + M)
+    codes = np.where(rng.integers(0, 2, (2, L)) > 0, 1, -1).astype(np.int8)
+    dop = np.array([-250.0, 0.0, 250.0], np.float32)
+    sats = [dict(prn_row=1, cn0_dbhz=52.0, doppler_hz=90.0, code_start=31990)]
+    x = synth.to_i8_iq(synth.make_scene(codes, fs, 0.0, M * N, sats, config_id=90 + M, code_rate=rate))
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=[1, 2], n_integrations=M, codes=codes, code_rate=rate)
+    eng.search(x)
+    mx, am, sm = eng.metrics()
+    xc = (x[:, 0] + 1j * x[:, 1]).astype(np.complex64)
+    tables = [oracle.DopplerShiftTable(0.0, float(d), fs, N) for d in dop]
+    for w in range(2):
+        ow = oracle.AcquisitionWorker(w + 1, N, fs, code=codes[w], code_rate=rate)
+        _, (bmax, barg, bsum, _) = ow.search_satellite(xc, tables, 0, M, want_planes=True, no_early_exit=True)
+        assert np.allclose(mx[w], bmax, rtol=REL) and np.allclose(sm[w], bsum, rtol=REL)
+        assert (am[w] == barg).all(), (w, am[w], barg)
+    assert am[1][1] == 31990
+    eng.close()
+
+
 def test_composite_size_with_mask_and_ring(gpu, oracle):
     """The composite path (N = 25000 = 5 x 5000) behind the other entry points: a PRN mask (only the selected workers'
     planes are recomputed, the others report None) and the device-ring snapshot."""
