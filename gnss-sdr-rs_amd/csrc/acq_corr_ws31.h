@@ -237,7 +237,7 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
         // ---------------------------------------------------------------- matrix-pipe role (owns the power sums)
         for (int m = m_begin; m < m_end; ++m) {
             ws31_stamp<STAMPS>(stb, m, 1, 0);
-            if (m > m_begin) MF::pass(mb, tid, mconst, out);        // the radix-31 pass of transform m - 1, beside pass 0 of transform m
+            if (m > m_begin) MF::pass(mb, tid, mconst, out, [&](int it) { ws31_stamp<STAMPS>(stb, m, 2, it); });      // the radix-31 pass of transform m - 1, beside pass 0 of transform m
             ws31_stamp<STAMPS>(stb, m, 1, 1);
             __syncthreads();                                        // B1: every gather of transform m - 1 has been read
             ws31_stamp<STAMPS>(stb, m, 1, 2);

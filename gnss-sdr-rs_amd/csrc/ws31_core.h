@@ -122,14 +122,16 @@ template <class PL, int W0, int NWM> struct Mfma31 {
     }
     // the radix-31 pass of one transform on this lane's wave: batches 0 .. ITF - 1 into out(it, r8, y); the gathers of batch it + 1 are
     // in flight while batch it's products run
-    template <class Out>
-    static __device__ __forceinline__ void pass(const Bases& bs, int tid, const Consts& m, Out&& out) {
+    struct NoMark { __device__ __forceinline__ void operator()(int) const {} };
+    template <class Out, class Mark = NoMark>
+    static __device__ __forceinline__ void pass(const Bases& bs, int tid, const Consts& m, Out&& out, Mark&& mark = Mark()) {
         Gather g[2];
         gather(0, bs, tid, g[0]);
 #pragma unroll
         for (int it = 0; it < ITF; ++it) {
             if (it + 1 < ITF) gather(it + 1, bs, tid, g[(it + 1) & 1]);
             products(it, g[it & 1], tid, m, out);
+            mark(it);                                           // (diagnostic hook: phase stamps of tools/corr_lab/ws31_stamps.hip)
         }
     }
     // the left-over batch (it = ITF of wave W0's lane map): run by whichever wave has the time, with tid = that map's lane
