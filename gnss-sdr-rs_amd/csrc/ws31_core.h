@@ -92,9 +92,7 @@ template <class PL, int W0, int NWM> struct Mfma31 {
                 a[st] = k == 0 ? up : cf_add(up, um);
                 b[st] = k == 0 ? cf_make(0.f, 0.f) : cf_sub(up, um);
             }
-#ifndef X_NOGROUP
             __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 dcr = __builtin_amdgcn_mfma_f32_16x16x4f32(m.c[st], a[st].x, dcr, 0, 0, 0);
@@ -102,9 +100,7 @@ template <class PL, int W0, int NWM> struct Mfma31 {
                 dsr = __builtin_amdgcn_mfma_f32_16x16x4f32(m.s[st], b[st].x, dsr, 0, 0, 0);
                 dsi = __builtin_amdgcn_mfma_f32_16x16x4f32(m.s[st], b[st].y, dsi, 0, 0, 0);
             }
-#ifndef X_NOGROUP
             __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float car = dcr[r], cai = dci[r], sbr = dsr[r], sbi = dsi[r];
