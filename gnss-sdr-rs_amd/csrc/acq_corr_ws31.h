@@ -32,7 +32,10 @@
 //   B2  pass-0 image complete
 //     [all waves: gather 16, B3, radix 16, scatter]
 //   B4  the image holds the radix-31 inputs of transform m
-// Also measured and left out: the middle pass on the matrix waves alone with a private LDS-counter barrier, or on the
+// Also measured and left out: the middle pass on the matrix waves alone with their own LDS-word barrier (two butterflies per lane; the
+// pass-0 waves then go from B2 straight to the next loads, as in acq_comp_ws.h) — correct, no scratch, and no faster (303 against
+// 299-304 us in the library, 311-321 against 309 in the lab): the matrix waves become the whole critical path.
+// Earlier: the middle pass on the matrix waves alone with a private LDS-counter barrier, or on the
 // pass-0 waves alone (two butterflies per lane either way: 64 more registers, spills inside the loops: 470 - 545 us against 336), the
 // left-over batch rotated over the matrix waves or run in two low-register halves (spills: 386 - 410 us), wave priorities (no change).
 // What bounds the kernel now: during the radix-31 phase the matrix pipe is ~77 % busy (33 x 16 instructions x 32 cycles / 4 SIMDs =
