@@ -71,44 +71,53 @@ template <bool STAMPS> __device__ __forceinline__ void comp_ws_stamp(long long* 
 // loads requested together.  DEPTH groups are in flight: group g + DEPTH - 1 is requested before group g is consumed, and the groups stay
 // apart in the schedule (hoisted to the top, the 20Q loads of a butterfly cost 270 spilled registers).  xoff: element offset of spectrum
 // block (m, k1 = 0); emit(i, value) receives value i of the butterfly's R0 intermediate values.
-template <class PL, uint32_t Q, int A> struct CompWsGroup {
-    u32x4 x[A / 2][Q], c[A / 2][Q];
-    __device__ __forceinline__ void request(__amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t crs, int v16, int xoff, int g) {
+template <class PL, uint32_t Q, int ROWS> struct CompWsGroup {       // a load unit: ROWS stored rows (an even number) = ROWS / 2 row pairs x Q blocks of both arrays
+    u32x4 x[ROWS / 2][Q], c[ROWS / 2][Q];
+    __device__ __forceinline__ void request(__amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t crs, int v16, int xoff, int u) {
 #pragma unroll
-        for (int h = 0; h < A / 2; ++h)
+        for (int h = 0; h < ROWS / 2; ++h)
 #pragma unroll
             for (uint32_t k1 = 0; k1 < Q; ++k1) {
-                const int st = g * A + 2 * h;                 // stored rows st, st + 1 = inputs 2h, 2h + 1 of group g
+                const int st = u * ROWS + 2 * h;              // stored rows st, st + 1
                 x[h][k1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, v16, (xoff + int(k1) * PL::N + st * PL::NB(0)) * 8, 0);
                 c[h][k1] = __builtin_amdgcn_raw_buffer_load_b128(crs, v16, (int(k1) * PL::N + st * PL::NB(0)) * 8, 0);
             }
     }
-    __device__ __forceinline__ void inputs(cf (&t)[A]) const {
+    template <int OFF, int A> __device__ __forceinline__ void inputs(cf (&t)[A]) const {        // t[OFF .. OFF + ROWS - 1]
         auto lo = [](u32x4 v) { return cf_make(__uint_as_float(v.x), __uint_as_float(v.y)); };
         auto hi = [](u32x4 v) { return cf_make(__uint_as_float(v.z), __uint_as_float(v.w)); };
 #pragma unroll
-        for (int h = 0; h < A / 2; ++h) {
+        for (int h = 0; h < ROWS / 2; ++h) {
             cf s0 = cf_mul(lo(x[h][0]), lo(c[h][0])), s1 = cf_mul(hi(x[h][0]), hi(c[h][0]));
 #pragma unroll
             for (uint32_t k1 = 1; k1 < Q; ++k1) {
                 s0 = cf_add(s0, cf_mul(lo(x[h][k1]), lo(c[h][k1])));
                 s1 = cf_add(s1, cf_mul(hi(x[h][k1]), hi(c[h][k1])));
             }
-            t[2 * h] = s0;
-            t[2 * h + 1] = s1;
+            t[OFF + 2 * h] = s0;
+            t[OFF + 2 * h + 1] = s1;
         }
     }
 };
 template <class PL, uint32_t Q> struct CompWsStream {
     using B0 = Bfly<PL::R0, true>;
-    static_assert(B0::KIND == 2 && B0::A % 2 == 0 && B0::B >= 2, "first radix: Good-Thomas, groups of an even number of rows");
-    // groups in flight (a group is 4Q 16-byte loads = 16Q registers): two at Q = 2, one above (two would be 96+ registers)
+    static_assert(B0::KIND == 2 && B0::A % 2 == 0 && B0::B >= 2 && (B0::A == 4 || B0::A == 2), "first radix: Good-Thomas, groups of two or four rows");
+    // Load units in flight.  A unit of ROWS rows is 2 Q ROWS / 2 16-byte loads = 4 Q ROWS registers: whole groups (ROWS = A = 4), two in
+    // flight at Q = 2 (64 registers), one at Q = 3, 4; above that single row pairs (ROWS = 2: 8 Q registers), one in flight.
+    static constexpr int ROWS = Q <= 4 ? B0::A : 2, UPG = B0::A / ROWS, NU = B0::B * UPG;      // units per group, units per butterfly
     static constexpr int DEPTH = Q <= 2 ? 2 : 1;
-    CompWsGroup<PL, Q, B0::A> buf[DEPTH];
-    // request the first DEPTH groups of a butterfly (they may then be in flight across a barrier: run() consumes them first)
+    CompWsGroup<PL, Q, ROWS> buf[DEPTH];
+    // request the first DEPTH units of a butterfly (they may then be in flight across a barrier: run() consumes them first)
     __device__ __forceinline__ void start(__amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t crs, int v16, int xoff) {
 #pragma unroll
-        for (int g = 0; g < DEPTH; ++g) buf[g].request(xrs, crs, v16, xoff, g);
+        for (int u = 0; u < DEPTH; ++u) buf[u].request(xrs, crs, v16, xoff, u);
+    }
+    // unit J of group g: its inputs into t[J * ROWS ..], then (behind the last use of the unit in hand) the request of unit + DEPTH
+    template <int J> __device__ __forceinline__ void unit(cf (&t)[B0::A], int g, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t crs, int v16, int xoff) {
+        const int u = g * UPG + J;
+        buf[u % DEPTH].template inputs<J * ROWS>(t);
+        if (u + DEPTH < NU) buf[u % DEPTH].request(xrs, crs, v16, xoff, u + DEPTH);
+        if (UPG > 1) __builtin_amdgcn_sched_barrier(0);
     }
     template <class Emit>
     __device__ __forceinline__ void run(Emit&& emit, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t crs, int v16, int xoff) {
@@ -116,8 +125,8 @@ template <class PL, uint32_t Q> struct CompWsStream {
         for (int g = 0; g < B0::B; ++g) {
             __builtin_amdgcn_sched_barrier(0);
             cf t[B0::A];
-            buf[g % DEPTH].inputs(t);
-            if (g + DEPTH < B0::B) buf[g % DEPTH].request(xrs, crs, v16, xoff, g + DEPTH);      // (behind the last use of the group in hand)
+            unit<0>(t, g, xrs, crs, v16, xoff);
+            if constexpr (UPG > 1) unit<1>(t, g, xrs, crs, v16, xoff);
             Dft<B0::A, true>::run(t);
 #pragma unroll
             for (int k1 = 0; k1 < B0::A; ++k1) {
