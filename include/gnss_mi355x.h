@@ -392,6 +392,9 @@ int gm_trk_update_all(gm_trk *t, gm_ring *ring, uint32_t max_epochs, gm_trk_out 
 /* Asynchronous device-resident form for benchmarking: enqueues `epochs` passes, no host readback. */
 int gm_trk_update_all_dev(gm_trk *t, gm_ring *ring, uint32_t epochs);
 int gm_trk_synchronize(gm_trk *t);
+/* The handle's own stream is created at the device's HIGHEST priority: the tracking loop is the receiver's latency path (one short
+ * launch per block of samples) and must not queue behind a front-end block or an acquisition dwell in flight on another stream.
+ * gm_trk_set_stream replaces it with the caller's (whose priority is then the caller's choice). */
 int gm_trk_set_stream(gm_trk *t, void *hip_stream);
 /* Diagnostic (not in the reference): call with out == NULL to arm `cap` epochs of per-phase shader-clock stamps
  * of workgroup 0 in the persistent kernel, then with out = [cap][48] int64 after a launch to read them. */
