@@ -460,6 +460,11 @@ def main():
                      "hbm_model": {"algorithmic_bytes_per_launch": corr_bytes, "model_GBs": achieved, "hbm_peak_GBs": HBM_PEAK_GBS,
                                    "model_over_peak": achieved / HBM_PEAK_GBS,
                                    "note": "16 B per (PRN, bin, ms, k): not a fraction of a physical roof"},
+                     # the physical path those algorithmic bytes DO take: L2 -> CU through the load path, which streams cache-resident
+                     # 16-byte loads at 125 GB/s per CU (tools/ubench/l2_read.hip, profiles/r04_ubench_l2_read.txt)
+                     "load_path": {"bytes_per_launch": corr_bytes, "achieved_GBs_per_cu": achieved / 256.0, "measured_peak_GBs_per_cu": 125.0,
+                                   "frac": achieved / 256.0 / 125.0,
+                                   "note": "the kernel's loads (spectrum + code spectrum, 16 B per cell and integration) against the measured L2-resident read rate of a CU: the second busiest resource after vector issue"},
                      "avg_launch_ms": tsum["avg_corr_ms"], "launches_timed": tsum["launches"],
                      "stage_F": {"kernel": "acq_mix_fft_kernel", "algorithmic_bytes_per_launch": mix_bytes,
                                  "avg_launch_ms": tsum["avg_mix_fft_ms"],
