@@ -41,7 +41,6 @@
 #include "acq_device.h"
 #include <type_traits>
 
-
 namespace gm {
 
 template <class CP> struct CompWs { static constexpr bool USE = false; };
@@ -49,8 +48,8 @@ template <class CP> struct CompWs { static constexpr bool USE = false; };
 template <> struct CompWs<HybridPlan<16000, 1024, 5, 25, 4, 32>> { static constexpr bool USE = true; };
 #endif
 
-// STAMPS (diagnostic, instantiated by tools/corr_lab only): lane 0 of waves 0, 4, 8 of workgroup 0 writes the shader clock at the phase
-// boundaries of every sub-transform into g_comp_ws_stamps[s][wave slot][8]
+// STAMPS (diagnostic, instantiated by tools/corr_lab only): lane 0 of waves 0, 7 and 8 of four workgroups writes the shader clock at the
+// phase boundaries of every sub-transform into g_comp_ws_stamps[workgroup][s][wave slot][8]
 __device__ long long* g_comp_ws_stamps = nullptr;
 __device__ long long* g_comp_ws_wg = nullptr;          // (diagnostic) [workgroup][2]: clock at entry and exit of every workgroup that has an item
 template <bool STAMPS> __device__ __forceinline__ void comp_ws_stamp(long long* base, int s, int slot, int phase) {
