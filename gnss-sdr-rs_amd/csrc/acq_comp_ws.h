@@ -39,7 +39,6 @@
 //     indices: 36 000 cycles per fold, as much as two sub-transforms).
 #pragma once
 #include "acq_device.h"
-#include <type_traits>
 
 namespace gm {
 
