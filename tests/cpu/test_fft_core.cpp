@@ -250,8 +250,47 @@ static double run_ws31() {
     return err;
 }
 
+// What the wave-specialised composite kernel (csrc/acq_comp_ws.h) assumes about the hybrid base-16000 plan, checked for every lane:
+//   * the rows of the stored spectra are in the radix-20 butterfly's consumption order: stored row s holds natural row
+//     (5 n1 + 4 N2) mod 20 with s = 4 N2 + n1 (Bfly<20>::s1 asks for its inputs in that order), and row() / nat() are inverse;
+//   * a last-pass lane's 32 outputs are the elements (e0 + STEP q2) mod N, STEP = N / 32: one wrap — its fold of the power sums
+//     picks the lowest element among equal values from the slot numbers alone (first slot at or behind the wrap, else the first).
+static int check_comp_ws_assumptions() {
+    using HP = HybridPlan<16000, 1024, 5, 25, 4, 32>;
+    using PR = PairRows<HP>;
+    int bad = 0;
+    for (int s = 0; s < 20; ++s) {
+        const int n1 = s % 4, n2 = s / 4;
+        if (PR::nat(s) != (5 * n1 + 4 * n2) % 20 || PR::row(PR::nat(s)) != s) ++bad;
+    }
+    constexpr int STEP = HP::N / HP::RL;
+    for (int tid = 0; tid < 512; ++tid) {
+        if (!HP::last_active(tid)) continue;
+        const int e0 = HP::out_index(tid, 0), rw = (HP::N - e0 + STEP - 1) / STEP;
+        int prev = -1, wraps = 0;
+        for (int r = 0; r < HP::RL; ++r) {
+            const int e = HP::out_index(tid, r);
+            if (e != (e0 + STEP * r) % HP::N) ++bad;
+            if ((r >= rw) != (e0 + STEP * r >= HP::N)) ++bad;
+            if (e < prev) ++wraps;
+            prev = e;
+        }
+        if (wraps > 1) ++bad;
+        // the rule itself against a search over indices, on every pair of slots holding the maximum
+        for (int a = 0; a < HP::RL; ++a)
+            for (int b = a + 1; b < HP::RL; ++b) {
+                const int lowest = HP::out_index(tid, a) < HP::out_index(tid, b) ? a : b;
+                const int r_any = a, r_wrapped = a >= rw ? a : (b >= rw ? b : -1);
+                if ((r_wrapped >= 0 ? r_wrapped : r_any) != lowest) ++bad;
+            }
+    }
+    std::printf("comp_ws assumptions on Hybrid16000: %d violations\n", bad);
+    return bad;
+}
+
 int main() {
     double worst = 0;
+    if (check_comp_ws_assumptions()) return 1;
     worst = std::fmax(worst, run_hybrid<HybridPlan<8000, 512, 5, 25, 4, 16>, true>("Hybrid8000 [20,25,16]"));
     worst = std::fmax(worst, run_hybrid<HybridPlan<8000, 512, 5, 25, 4, 16>, false>("Hybrid8000 [20,25,16]"));
     worst = std::fmax(worst, run_hybrid<HybridPlan<16000, 1024, 5, 25, 4, 32>, true>("Hybrid16000 [20,25,32]"));

@@ -152,6 +152,7 @@ def test_fft_core_cpu_emulation_of_every_plan():
     assert r.returncode == 0, r.stdout[-2000:]
     assert "Plan8000" in r.stdout and "Plan256" in r.stdout and "worst" in r.stdout
     assert "ws31<Plan16368>" in r.stdout          # the wave-specialised N = 16368 transform incl. its matrix-product radix-31 pass (csrc/ws31_core.h)
+    assert "comp_ws assumptions on Hybrid16000: 0 violations" in r.stdout      # the stored row order and the one-wrap slot rule of csrc/acq_comp_ws.h
 
 
 def test_device_atanf_restatement_matches_host_libm_bit_for_bit():
