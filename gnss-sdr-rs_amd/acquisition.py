@@ -119,7 +119,11 @@ class AcquisitionEngine:
             lib().gm_acq_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):      # (at interpreter shutdown the module globals close() uses may be gone already)
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @staticmethod
     def _fmt(samples):

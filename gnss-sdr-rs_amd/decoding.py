@@ -22,7 +22,11 @@ class NavSyncStatus:
             lib().gm_nav_sync_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):      # (at interpreter shutdown the module globals close() uses may be gone already)
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def update(self, old_i_prompt, i_prompt, cnt, buff_loc=0):
         """nav_decoding's step (:102-145) -> dict of NavStatus fields"""

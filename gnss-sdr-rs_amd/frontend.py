@@ -26,7 +26,11 @@ class DigitalFrontend:
             lib().gm_frontend_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):      # (at interpreter shutdown the module globals close() uses may be gone already)
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def nco(self):
         """(lut_re, lut_im, phase_step) of NcoLut::new (nco_lut.rs:25-42)"""

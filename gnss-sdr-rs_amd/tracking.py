@@ -45,7 +45,11 @@ class MulticastRingBuffer:
             lib().gm_ring_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):      # (at interpreter shutdown the module globals close() uses may be gone already)
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def write_samples(self, samples):
         s = np.ascontiguousarray(samples, np.complex64)
@@ -110,7 +114,11 @@ class TrackingManager:
             lib().gm_trk_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):      # (at interpreter shutdown the module globals close() uses may be gone already)
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def update_all(self, ring, max_epochs=1):
         """-> (outs [E][C][2*arms] f32, processed [E][C] u8, lost [E][C] u8, epochs_done)"""
