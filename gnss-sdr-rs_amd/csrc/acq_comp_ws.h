@@ -306,9 +306,9 @@ __device__ __forceinline__ void comp_corr_ws_body(
                 constexpr int STEP = Nb / RL;
                 static_assert(STEP == PL::A * PL::B1 && STEP * RL == Nb, "slot q2 of a lane is element e0 + A B1 q2 (mod Nb): HybridPlan::out_index");
                 const int e0 = PL::out_index(tid, 0), rw = (Nb - e0 + STEP - 1) / STEP;      // slots rw .. RL - 1 have wrapped
-                float m1 = acc[0], ps = 0.0f;
+                float m1 = 0.0f, ps = 0.0f;                  // (from 0.0 like the reference's scan, :195-202: a NaN never becomes the maximum)
 #pragma unroll
-                for (int r = 1; r < RL; ++r) m1 = acc[r] > m1 ? acc[r] : m1;
+                for (int r = 0; r < RL; ++r) m1 = acc[r] > m1 ? acc[r] : m1;
                 int r_any = -1, r_wrapped = -1;
 #pragma unroll
                 for (int r = RL - 1; r >= 0; --r) {
