@@ -242,6 +242,12 @@ def test_composite_base_16000_degenerate_planes(gpu, oracle):
     eng.search(np.zeros((M * N, 2), np.int8))
     mx, am, sm = eng.metrics()
     assert (mx == 0).all() and (am == 0).all() and (sm == 0).all()
+    # one NaN sample: every power is NaN, `power > local_max` is never true -> (0.0, 0) and a NaN sum, like the fused sizes
+    zn = np.zeros(M * N, np.complex64)
+    zn[5] = np.nan
+    assert eng.search(zn) == [None, None]
+    mx, am, sm = eng.metrics()
+    assert (mx == 0).all() and (am == 0).all() and np.isnan(sm).all()
     # half-period capture at zero Doppler: x[n + N/2] = x[n]  ->  only even spectrum bins are occupied, the correlation is N/2-periodic too
     half = rng.integers(-20, 21, (N // 2, 2)).astype(np.int8)
     x = np.tile(half, (2 * M, 1))
