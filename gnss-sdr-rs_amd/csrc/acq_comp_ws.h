@@ -28,6 +28,7 @@
 //
 // Measured and left out: the 288 second butterflies dealt evenly to the eight pass-0 waves (36 lanes each) instead of to the first
 // 4.5 — every wave then runs both code paths and B1 comes no earlier: 266 against 253 us.
+// Non-temporal hints (`nt`) on the code-table loads or on the spectrum loads, to keep the other array in L2: 333 / 302 us.
 // Measured (configs[3] Galileo geometry, 36 codes x 41 bins x 2 periods; tools/corr_lab/comp_ws_stamps.hip): 307 us for
 // the lockstep kernel on the plain [25, 20, 32] plan -> 255 us (rocprofv3 in bench.py: 243).  The pass-0 waves now stream 512 KB per 5.3 us and CU (~100 GB/s of the
 // 125 the load path gives): the kernel is bound by its loads.  What it took beyond the roles — every item cost a multiple of its size
