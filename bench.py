@@ -325,8 +325,11 @@ def main():
                 eng.decide_dev(d_gather.data_ptr(), n_prn=world * P, prn_ids=ids_all)
             else:
                 eng.decide_dev(d_metrics.data_ptr())
+        eng.synchronize()        # runs the last dwell's decision if it is still pending (set_deferred_decision): all n_steps decisions are inside
         return keep
 
+    if world == 1 and os.environ.get("GM_BENCH_NO_DEFER") != "1":
+        eng.set_deferred_decision(True)      # back-to-back dwells: dwell k's decision runs beside dwell k+1's forward transforms
     keep = run(args.warmup)
     torch.cuda.synchronize()
     # every 5th dwell carries HIP events (four records cost ~8 us of stream time per dwell when all are timed)

@@ -223,6 +223,11 @@ class AcquisitionEngine:
     def synchronize(self):
         check(lib().gm_acq_synchronize(self._h), "gm_acq_synchronize")
 
+    def set_deferred_decision(self, on=True):
+        """Back-to-back dwells: let decide_dev() ride with the next search_dev()'s first kernel (include/gnss_mi355x.h);
+        synchronize() / fetch_results() run whatever is still pending."""
+        check(lib().gm_acq_set_deferred_decision(self._h, int(on)), "gm_acq_set_deferred_decision")
+
     def enable_timing(self, on=True):
         check(lib().gm_acq_enable_timing(self._h, int(on)), "gm_acq_enable_timing")
 

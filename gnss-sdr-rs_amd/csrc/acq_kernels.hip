@@ -22,6 +22,98 @@
 
 namespace gm {
 
+// ------------------------------------------------------------------------------------ decision replay
+// One wavefront per worker: the D metric triples are staged to LDS (dsm: 3 D words) with coalesced loads, then the wave replays the
+// reference's sequential scan out of LDS (no dependent global-memory round trips).  WG: the wave is a workgroup of its own
+// (decide_kernel) — else it is wave 0 of a stage-F workgroup (acq_mix_fft_kernel's trailing workgroups) and orders its LDS
+// accesses by itself.
+template <bool WG>
+__device__ __forceinline__ void decide_body(const DecideArgs& a, int p, int lane, float* dsm) {
+    const int D = a.n_bins;
+    float* smax = dsm;
+    float* ssum = dsm + D;
+    uint32_t* sarg = reinterpret_cast<uint32_t*>(dsm + 2 * D);
+    for (int d = lane; d < D; d += 64) {
+        const size_t o = size_t(p) * D + d;
+        smax[d] = a.mmax[o]; ssum[d] = a.msum[o]; sarg[d] = a.margmax[o];
+    }
+    if constexpr (WG) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+    // The reference scans the bins in ascending order keeping a running best plane (first strict maximum, :195-202) and
+    // stops at the first bin where that running best passes max/avg > threshold (:204-223).  Here lane d holds the running
+    // best THROUGH bin d (its own scan of smax[0..d], same comparisons), evaluates the test for it with the same two IEEE
+    // divisions, and the lowest passing lane is the reference's exit point: 41 dependent iterations become one.
+    const bool searched = (p >= 64) || ((a.mask_lo >> p) & 1ull);
+    float gmax = 0.0f, bsum = 0.0f;                        // best plane starts all-zero (:168)
+    uint32_t bphase = 0;
+    int bbin = -1;
+    bool pass = false;
+    float carry_v = 0.0f;                                  // (prefix-scan form) the running best at the end of the previous 64 bins
+    int carry_b = -1;
+    for (int d0 = 0; d0 < D; d0 += 64) {                   // D <= 64 in practice: one trip
+        const int d = d0 + lane;
+        if (d0 > 0) { gmax = 0.0f; bsum = 0.0f; bphase = 0; bbin = -1; }
+#ifdef GM_DECIDE_SERIAL_SCAN      // the scan as it was: every lane walks smax[0..d] out of LDS (41 dependent round trips: ~2 us)
+        if (d < D && searched) {
+            for (int q = 0; q <= d; ++q) {
+                const float lm = smax[q];
+                if (lm > gmax) { gmax = lm; bphase = sarg[q]; bsum = ssum[q]; bbin = q; }
+            }
+        }
+#else
+        // running best THROUGH bin d as a wave prefix scan of (value, bin) with the reference's comparison — a later bin replaces
+        // the running best only if strictly larger (:195-202), the start value 0.0 never loses to a non-positive or NaN maximum —
+        // six shuffle steps instead of d + 1 dependent LDS reads
+        {
+            const float own = (d < D) ? smax[d] : 0.0f;
+            gmax = own > 0.0f ? own : 0.0f;
+            bbin = own > 0.0f ? d : -1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float ev = __shfl_up(gmax, off, 64);      // the running best of the lanes before
+                const int eb = __shfl_up(bbin, off, 64);
+                if (lane >= off && !(gmax > ev)) { gmax = ev; bbin = eb; }
+            }
+            if (d0 > 0 && !(gmax > carry_v)) { gmax = carry_v; bbin = carry_b; }     // D > 64: the best through bin d0 - 1
+            carry_v = __shfl(gmax, 63, 64); carry_b = __shfl(bbin, 63, 64);
+            bphase = bbin >= 0 ? sarg[bbin] : 0u;
+            bsum = bbin >= 0 ? ssum[bbin] : 0.0f;
+        }
+#endif
+        if (d < D && searched) {
+            if (!a.best_bin_mode || d + 1 == D) {          // strongest-bin mode: test once, after the last bin
+                const float avg = __fdiv_rn(bsum - gmax, float(a.fft_size - 1));   // (sum - max) / (N-1)  (:236)
+                pass = __fdiv_rn(gmax, avg) > a.threshold;                          // max/avg > 7.0       (:237)
+            }
+        }
+        const unsigned long long votes = __ballot(pass);
+        if (votes) {
+            if (lane == __ffsll((long long)votes) - 1) {       // the first bin that passes: early exit (:211-222)
+                gm_acq_result r;
+                r.prn = a.prn_ids[p];
+                r.code_phase_samples = bphase;
+                r.code_phase_chips = __fdiv_rn(float(bphase) * a.code_rate, a.fs);   // (:215-216)
+                r.carrier_freq = a.table_freq[bbin]; r.fs = a.fs; r.mag_relative = gmax;
+                r.sample_global_index = a.local_tail + bphase; r.doppler_bin = bbin;
+                a.results[p] = r;
+                a.found[p] = 1;
+            }
+            return;
+        }
+    }
+    if (lane == 0) {
+        gm_acq_result r;
+        r.prn = a.prn_ids[p]; r.code_phase_samples = 0; r.code_phase_chips = 0.f; r.carrier_freq = 0.f;
+        r.fs = 0.f; r.mag_relative = 0.f; r.sample_global_index = 0; r.doppler_bin = -1;   // AcquisitionResult::new
+        a.results[p] = r;
+        a.found[p] = 0;
+    }
+}
+__global__ __launch_bounds__(64) void decide_kernel(DecideArgs a) {
+    extern __shared__ float dsm[];
+    decide_body<true>(a, blockIdx.x, threadIdx.x, dsm);
+}
+
 // ------------------------------------------------------------------------------------ stage F
 template <class PLX>
 __global__ __launch_bounds__(MixPlanOf<PLX>::type::T) void acq_mix_fft_kernel(const void* __restrict__ samples, int fmt,
@@ -29,7 +121,7 @@ __global__ __launch_bounds__(MixPlanOf<PLX>::type::T) void acq_mix_fft_kernel(co
                                                             const cf* __restrict__ tw_fwd,
                                                             cf* __restrict__ spectra, int n_int,
                                                             uint32_t* __restrict__ clear_tickets,
-                                                            const uint16_t* __restrict__ order) {
+                                                            const uint16_t* __restrict__ order, int n_items, DecideArgs dec) {
     // PLX: the size's registered plan (its correlation plan CP fixes the stored order); PL: the plan the FORWARD transform runs
     // on (MixPlanOf, acq_device.h) — `tw_fwd` is PL's base-twiddle table (PlanOps::fill_tw_mix)
     // (permuted storage orders stage the outputs through LDS, one padding element per 32: see below)
@@ -40,6 +132,16 @@ __global__ __launch_bounds__(MixPlanOf<PLX>::type::T) void acq_mix_fft_kernel(co
     constexpr int STAGE = PERMUTED ? PL::N + PL::N / 32 + 1 : 0;
     constexpr int LDS_N = PL::LDS_ELEMS + PL::TW_TOTAL > STAGE ? PL::LDS_ELEMS + PL::TW_TOTAL : STAGE;
     __shared__ cf lds[LDS_N];
+    // Trailing workgroups (blockIdx >= n_items, dec.n_prn of them): the PREVIOUS dwell's decision, one wave per worker — its
+    // metrics are complete (this kernel follows that dwell's stage C on the stream) and stay untouched until this dwell's stage C,
+    // which follows this kernel.  As a kernel of its own between stage C and the next stage F the decision costs 5 us and a
+    // dependent launch per dwell with 255 CUs idle (gm_acq_set_deferred_decision: gm_acq_decide_dev then keeps it for the next
+    // search; any other consumer of the results runs decide_kernel first).  n_bins <= 64 (checked by the caller).
+    if (int(blockIdx.x) >= n_items) {
+        static_assert(LDS_N * 8 >= 3 * 64 * 4, "room for the decision's staging");
+        if (threadIdx.x < 64) decide_body<false>(dec, int(blockIdx.x) - n_items, threadIdx.x, reinterpret_cast<float*>(lds));
+        return;
+    }
     cf* tw = lds + PL::LDS_ELEMS;
     const int tid = threadIdx.x;
     const int d = blockIdx.x / n_int, m = blockIdx.x % n_int;
@@ -725,9 +827,12 @@ template <class PL> struct Launch {
         fill_twiddles<MP>(tw, inverse, [](double a) { return ::cos(a); }, [](double a) { return ::sin(a); });
     }
     static void mix_fft(hipStream_t st, const void* samples, int fmt, const cf* tables, const cf* tw_fwd,
-                        cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets, const uint16_t* order) {
-        hipLaunchKernelGGL(acq_mix_fft_kernel<PL>, dim3(n_bins * n_int), dim3(MP::T), 0, st, samples, fmt,
-                           tables, tw_fwd, spectra, n_int, clear_tickets, order);
+                        cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets, const uint16_t* order, const DecideArgs* dec) {
+        // dec (may be null): the previous dwell's deferred decision rides along as dec->n_prn trailing workgroups
+        const int n_items = n_bins * n_int, n_dec = dec ? dec->n_prn : 0;
+        DecideArgs none{};
+        hipLaunchKernelGGL(acq_mix_fft_kernel<PL>, dim3(n_items + n_dec), dim3(MP::T), 0, st, samples, fmt,
+                           tables, tw_fwd, spectra, n_int, clear_tickets, order, n_items, dec ? *dec : none);
     }
     static int fill_order(uint16_t* order) { return fill_order_table<CP>(order); }
     static constexpr bool WS31 = Ws31<CP>::USE && CorrMode<CP>::PFA;      // stage C runs acq_corr_ws31_kernel (acq_corr_ws31.h)
@@ -907,90 +1012,6 @@ void launch_power(hipStream_t st, const cf* x, float* p, size_t n) {
     hipLaunchKernelGGL(power_kernel, dim3(blocks), dim3(256), 0, st, x, p, n);
 }
 
-// ------------------------------------------------------------------------------------ decision replay
-__global__ __launch_bounds__(64) void decide_kernel(DecideArgs a) {
-    // one wavefront per worker: the D metric triples are staged to LDS with coalesced loads, then lane 0
-    // replays the reference's sequential scan out of LDS (no dependent global-memory round trips)
-    extern __shared__ float dsm[];
-    const int p = blockIdx.x, lane = threadIdx.x, D = a.n_bins;
-    float* smax = dsm;
-    float* ssum = dsm + D;
-    uint32_t* sarg = reinterpret_cast<uint32_t*>(dsm + 2 * D);
-    for (int d = lane; d < D; d += 64) {
-        const size_t o = size_t(p) * D + d;
-        smax[d] = a.mmax[o]; ssum[d] = a.msum[o]; sarg[d] = a.margmax[o];
-    }
-    __syncthreads();
-    // The reference scans the bins in ascending order keeping a running best plane (first strict maximum, :195-202) and
-    // stops at the first bin where that running best passes max/avg > threshold (:204-223).  Here lane d holds the running
-    // best THROUGH bin d (its own scan of smax[0..d], same comparisons), evaluates the test for it with the same two IEEE
-    // divisions, and the lowest passing lane is the reference's exit point: 41 dependent iterations become one.
-    const bool searched = (p >= 64) || ((a.mask_lo >> p) & 1ull);
-    float gmax = 0.0f, bsum = 0.0f;                        // best plane starts all-zero (:168)
-    uint32_t bphase = 0;
-    int bbin = -1;
-    bool pass = false;
-    float carry_v = 0.0f;                                  // (prefix-scan form) the running best at the end of the previous 64 bins
-    int carry_b = -1;
-    for (int d0 = 0; d0 < D; d0 += 64) {                   // D <= 64 in practice: one trip
-        const int d = d0 + lane;
-        if (d0 > 0) { gmax = 0.0f; bsum = 0.0f; bphase = 0; bbin = -1; }
-#ifdef GM_DECIDE_SERIAL_SCAN      // the scan as it was: every lane walks smax[0..d] out of LDS (41 dependent round trips: ~2 us)
-        if (d < D && searched) {
-            for (int q = 0; q <= d; ++q) {
-                const float lm = smax[q];
-                if (lm > gmax) { gmax = lm; bphase = sarg[q]; bsum = ssum[q]; bbin = q; }
-            }
-        }
-#else
-        // running best THROUGH bin d as a wave prefix scan of (value, bin) with the reference's comparison — a later bin replaces
-        // the running best only if strictly larger (:195-202), the start value 0.0 never loses to a non-positive or NaN maximum —
-        // six shuffle steps instead of d + 1 dependent LDS reads
-        {
-            const float own = (d < D) ? smax[d] : 0.0f;
-            gmax = own > 0.0f ? own : 0.0f;
-            bbin = own > 0.0f ? d : -1;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float ev = __shfl_up(gmax, off, 64);      // the running best of the lanes before
-                const int eb = __shfl_up(bbin, off, 64);
-                if (lane >= off && !(gmax > ev)) { gmax = ev; bbin = eb; }
-            }
-            if (d0 > 0 && !(gmax > carry_v)) { gmax = carry_v; bbin = carry_b; }     // D > 64: the best through bin d0 - 1
-            carry_v = __shfl(gmax, 63, 64); carry_b = __shfl(bbin, 63, 64);
-            bphase = bbin >= 0 ? sarg[bbin] : 0u;
-            bsum = bbin >= 0 ? ssum[bbin] : 0.0f;
-        }
-#endif
-        if (d < D && searched) {
-            if (!a.best_bin_mode || d + 1 == D) {          // strongest-bin mode: test once, after the last bin
-                const float avg = __fdiv_rn(bsum - gmax, float(a.fft_size - 1));   // (sum - max) / (N-1)  (:236)
-                pass = __fdiv_rn(gmax, avg) > a.threshold;                          // max/avg > 7.0       (:237)
-            }
-        }
-        const unsigned long long votes = __ballot(pass);
-        if (votes) {
-            if (lane == __ffsll((long long)votes) - 1) {       // the first bin that passes: early exit (:211-222)
-                gm_acq_result r;
-                r.prn = a.prn_ids[p];
-                r.code_phase_samples = bphase;
-                r.code_phase_chips = __fdiv_rn(float(bphase) * a.code_rate, a.fs);   // (:215-216)
-                r.carrier_freq = a.table_freq[bbin]; r.fs = a.fs; r.mag_relative = gmax;
-                r.sample_global_index = a.local_tail + bphase; r.doppler_bin = bbin;
-                a.results[p] = r;
-                a.found[p] = 1;
-            }
-            return;
-        }
-    }
-    if (lane == 0) {
-        gm_acq_result r;
-        r.prn = a.prn_ids[p]; r.code_phase_samples = 0; r.code_phase_chips = 0.f; r.carrier_freq = 0.f;
-        r.fs = 0.f; r.mag_relative = 0.f; r.sample_global_index = 0; r.doppler_bin = -1;   // AcquisitionResult::new
-        a.results[p] = r;
-        a.found[p] = 0;
-    }
-}
 void launch_decide(hipStream_t st, const DecideArgs& a) {
     if (a.n_prn <= 0) return;
     hipLaunchKernelGGL(decide_kernel, dim3(a.n_prn), dim3(64), size_t(a.n_bins) * 12, st, a);

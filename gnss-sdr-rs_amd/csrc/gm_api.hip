@@ -253,6 +253,12 @@ struct gm_acq {
     cf* d_comp_tmp = nullptr;              // [max(D*M, P)][Q][Nb]: forward sub-transforms before the Q-point DFTs
     cf* d_comp_twn = nullptr;              // [Q][Nb] inverse twiddles W_N^{-n1 k2}, paired positions
     cf* d_code_comb = nullptr;             // Q > 1: [P][Q][Q][Nb] conj(code) x W_Q^{-n1 k1} x W_N^{-n1 k2}, what comp corr multiplies the spectra by
+    // gm_acq_decide_dev on the metrics of the last search, on a handle of an in-LDS size: the decision is NOT launched but kept here
+    // and rides along with the next search's stage F (PlanOps::mix_fft: trailing workgroups) — anything else that consumes or
+    // invalidates it (fetch, synchronize, another decide, a stream change, timing) launches decide_kernel first (acq_flush_decision)
+    bool defer_decisions = false;   // gm_acq_set_deferred_decision
+    bool dec_deferred = false;
+    gm::DecideArgs dec_args{};
     bool comp_post_folded = false;         // ... and, for base plans with an order table, the signal's forward step 2 (CompOps::fold_post): d_spectra = the sub-transforms
     // fine Doppler (gm_acq_finer_doppler): host copy of the chip rows, lazily built device state
     std::vector<int8_t> chips;             // [P][code_len]
@@ -285,8 +291,18 @@ static int acq_set_mask(gm_acq* a, uint64_t mask) {
     return GM_OK;
 }
 
+static int acq_flush_decision(gm_acq* a) {
+    if (a->dec_deferred) {
+        a->dec_deferred = false;
+        gm::launch_decide(a->stream, a->dec_args);
+        HIPC(hipGetLastError());
+    }
+    return GM_OK;
+}
+
 static int acq_reserve_results(gm_acq* a, uint32_t n) {
     if (n <= a->results_cap) return GM_OK;
+    if (int rc = acq_flush_decision(a)) return rc;
     // results + found flags live in ONE host-pinned, device-visible block: decide_kernel writes its P x 41 bytes straight into
     // host memory and gm_acq_fetch_results is a stream synchronisation and a memcpy — the two device-to-host copies it used to
     // issue cost the host-buffer entry (gm_acq_search) ~25 us per dwell
@@ -737,6 +753,7 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
 
 int gm_acq_set_stream(gm_acq* a, void* s) {
     if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (a->dec_deferred) { if (int rc = ensure_device(a->device)) return rc; if (int rc = acq_flush_decision(a)) return rc; }
     if (a->own_stream && a->stream) { hipStreamSynchronize(a->stream); hipStreamDestroy(a->stream); }
     a->stream = reinterpret_cast<hipStream_t>(s);
     a->own_stream = false;
@@ -760,7 +777,9 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     hipEvent_t* ev = t ? &a->tm.ev[size_t(a->tm.count % Timing::CAP) * 4] : nullptr;
     if (t) HIPC(hipEventRecord(ev[0], a->stream));
     if (a->Q == 1) {
-        a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_mix, a->d_spectra, int(a->D), int(a->M), a->d_split_counter, a->d_order);
+        a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_mix, a->d_spectra, int(a->D), int(a->M), a->d_split_counter, a->d_order,
+                         a->dec_deferred ? &a->dec_args : nullptr);
+        a->dec_deferred = false;
     } else {
         if (a->comp_post_folded) {     // the sub-transforms ARE what the correlation kernel reads
             a->comp->fwd_sub(a->stream, d_samples, fmt, a->d_tables, nullptr, a->d_tw_mix, a->d_spectra, a->D * a->M, a->M, a->d_order);
@@ -789,6 +808,7 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
 int gm_acq_decide_dev(gm_acq* a, const void* d_metrics, uint32_t n_prn, const uint8_t* prn_ids, uint64_t local_tail) {
     if (!a || !n_prn) return set_err(GM_ERR_INVALID_ARG, "null handle / n_prn == 0");
     if (int rc = ensure_device(a->device)) return rc;
+    if (int rc = acq_flush_decision(a)) return rc;
     if (int rc = acq_reserve_results(a, n_prn)) return rc;
     const uint32_t* met = d_metrics ? static_cast<const uint32_t*>(d_metrics) : a->d_metrics;
     const uint8_t* ids = prn_ids ? prn_ids : (n_prn == a->P ? a->prn_ids.data() : nullptr);
@@ -811,6 +831,11 @@ int gm_acq_decide_dev(gm_acq* a, const void* d_metrics, uint32_t n_prn, const ui
     da.best_bin_mode = a->cfg.decision_mode == GM_DECIDE_BEST_BIN ? 1 : 0;
     da.local_tail = local_tail;
     da.results = a->d_results; da.found = a->d_found;
+    if (a->defer_decisions && a->Q == 1 && !(a->tm.on && a->tm.this_call) && met == a->last_metrics && a->D <= 64) {
+        a->dec_args = da;          // runs with the next gm_acq_search_dev's stage F, or at the next flush point
+        a->dec_deferred = true;
+        return GM_OK;
+    }
     gm::launch_decide(a->stream, da);
     if (a->tm.on && a->tm.this_call && a->tm.count > 0) {
         a->tm.this_call = false;
@@ -824,7 +849,15 @@ int gm_acq_decide_dev(gm_acq* a, const void* d_metrics, uint32_t n_prn, const ui
 int gm_acq_synchronize(gm_acq* a) {
     if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
     if (int rc = ensure_device(a->device)) return rc;
+    if (int rc = acq_flush_decision(a)) return rc;
     HIPC(hipStreamSynchronize(a->stream));
+    return GM_OK;
+}
+
+int gm_acq_set_deferred_decision(gm_acq* a, int on) {
+    if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (!on && a->dec_deferred) { if (int rc = ensure_device(a->device)) return rc; if (int rc = acq_flush_decision(a)) return rc; }
+    a->defer_decisions = on != 0;
     return GM_OK;
 }
 
@@ -832,6 +865,7 @@ int gm_acq_fetch_results(gm_acq* a, uint32_t n_prn, gm_acq_result* results, uint
     if (!a || !results || !found) return set_err(GM_ERR_INVALID_ARG, "null pointer");
     if (n_prn > a->results_cap) return set_err(GM_ERR_INVALID_ARG, "n_prn exceeds the last decide call");
     if (int rc = ensure_device(a->device)) return rc;
+    if (int rc = acq_flush_decision(a)) return rc;
     HIPC(hipStreamSynchronize(a->stream));          // decide_kernel's stores to the pinned block are visible once its stream has drained
     memcpy(results, a->d_results, sizeof(gm_acq_result) * n_prn);
     memcpy(found, a->d_found, n_prn);

@@ -24,6 +24,7 @@ struct FineArgs {
 };
 
 // One entry per shipped transform size: launchers for the kernels instantiated on that plan.
+struct DecideArgs;
 struct PlanOps {
     int n;             // transform length
     int threads;       // workgroup size
@@ -40,8 +41,9 @@ struct PlanOps {
     // (do_acquisition.rs:177-182).  One workgroup per (doppler bin, ms block); shared by all PRNs.
     // clear_tickets (may be null): the tail split's ticket counters, zeroed by the first workgroup for the corr() launch
     // that follows on the same stream (saves that launch its own hipMemsetAsync: ~8 us per dwell)
+    // dec (may be null): a decision deferred by gm_acq_decide_dev — the PREVIOUS dwell's — runs as dec->n_prn trailing workgroups
     void (*mix_fft)(hipStream_t, const void* samples, int fmt, const cf* tables, const cf* tw_fwd,
-                    cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets, const uint16_t* order);
+                    cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets, const uint16_t* order, const DecideArgs* dec);
     // stage C (spectra and code_fft in the PAIRED layout): x conj(code spectrum) -> inverse FFT -> |.|^2 accumulated over the integrations ->
     // {max, first argmax, sum} per (worker, bin)  (do_acquisition.rs:184-202, 229-235)
     void (*corr)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,

@@ -236,6 +236,13 @@ int gm_acq_decide_host(const float *max, const uint32_t *argmax, const float *su
                        float code_rate, float threshold, uint64_t local_tail, gm_acq_result *results,
                        uint8_t *found);
 int gm_acq_synchronize(gm_acq *a);
+/* Back-to-back dwells (a receiver that searches dwell after dwell): with `on`, a gm_acq_decide_dev on the metrics block the
+ * LAST gm_acq_search_dev wrote is not launched on its own but kept, and runs inside the first kernel of the NEXT
+ * gm_acq_search_dev (extra workgroups beside the forward transforms, one launch and one kernel boundary fewer per dwell), or
+ * at the next gm_acq_synchronize / gm_acq_fetch_results / gm_acq_decide_dev / gm_acq_set_stream, whichever comes first.
+ * Until then that metrics block must stay as the search left it; results are the same either way.  Off by default
+ * (in-LDS transform sizes with n_bins <= 64 only; other handles accept the call and decide at once as before). */
+int gm_acq_set_deferred_decision(gm_acq *a, int on);
 /* Use an existing HIP stream (e.g. torch's current stream) instead of the handle's own. */
 int gm_acq_set_stream(gm_acq *a, void *hip_stream);
 

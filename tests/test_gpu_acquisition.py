@@ -381,6 +381,58 @@ def test_native_comm_single_rank_allgather_and_decide(gpu, hipbuf):
     eng.close()
 
 
+def test_deferred_decision_rides_with_the_next_search(gpu, hipbuf):
+    """gm_acq_set_deferred_decision: dwell k's decision runs inside dwell k + 1's first kernel (trailing workgroups of stage F)
+    or at the next flush point — the results are those of the immediate decision, bit for bit, whichever way it ran."""
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    t = A.ca_code_table()
+    fs, N, M = 2.048e6, 2048, 2
+    dop = np.arange(-2000.0, 2001.0, 500.0, dtype=np.float32)
+    prns = [5, 10, 31, 1, 2, 20, 17]
+    P, D = len(prns), dop.size
+    scenes = []
+    for k, sats in enumerate(([dict(prn_row=4, cn0_dbhz=52.0, doppler_hz=-430.0, code_start=1234)],
+                              [dict(prn_row=9, cn0_dbhz=51.0, doppler_hz=910.0, code_start=77), dict(prn_row=16, cn0_dbhz=50.0, doppler_hz=-1400.0, code_start=1999)],
+                              [])):
+        scenes.append(synth.to_c32(synth.make_scene(t, fs, 10_000.0, M * N, sats, config_id=40 + k)))
+    eng = A.AcquisitionEngine(fs, 10_000.0, N, doppler_hz=dop, prn_ids=prns, n_integrations=M)
+    key = lambda r: r and (r["prn"], r["code_phase_samples"], r["doppler_bin"], r["mag_relative"], r["sample_global_index"])
+    want = []
+    for k, x in enumerate(scenes):
+        eng.search_dev(hipbuf.upload(x), A.FMT_C32, None)
+        eng.decide_dev(None, local_tail=1000 * k)
+        want.append([key(r) for r in eng.fetch_results(P)])
+    assert want[0] != want[1] and want[1] != want[2] and want[0] != want[2]
+    d_x = [hipbuf.upload(x) for x in scenes]
+    eng.set_deferred_decision(True)
+    # (a) flushed by fetch_results right away
+    for k in range(3):
+        eng.search_dev(d_x[k], A.FMT_C32, None)
+        eng.decide_dev(None, local_tail=1000 * k)
+        assert [key(r) for r in eng.fetch_results(P)] == want[k]
+    # (b) carried by the next search: after search(k + 1) and a drain, the results are dwell k's (nothing else decided)
+    eng.search_dev(d_x[0], A.FMT_C32, None)
+    eng.decide_dev(None, local_tail=0)
+    eng.search_dev(d_x[1], A.FMT_C32, None)
+    assert [key(r) for r in eng.fetch_results(P)] == want[0]
+    eng.decide_dev(None, local_tail=1000)
+    eng.search_dev(d_x[2], A.FMT_C32, None)
+    eng.decide_dev(None, local_tail=2000)
+    eng.synchronize()
+    assert [key(r) for r in eng.fetch_results(P)] == want[2]
+    # (c) a caller's own metrics block, a decision on another block than the last search's (immediate), switching off with one pending
+    d_met = hipbuf.alloc(3 * P * D * 4)
+    d_other = hipbuf.alloc(3 * P * D * 4)
+    eng.search_dev(d_x[1], A.FMT_C32, d_other)
+    eng.search_dev(d_x[0], A.FMT_C32, d_met)
+    eng.decide_dev(d_other, local_tail=1000)
+    assert [key(r) for r in eng.fetch_results(P)] == want[1]
+    eng.decide_dev(d_met, local_tail=0)
+    eng.set_deferred_decision(False)
+    assert [key(r) for r in eng.fetch_results(P)] == want[0]
+    eng.close()
+
+
 def test_composite_sizes_accepted_and_rejected(gpu):
     """The transform sizes beyond one LDS buffer the acquisition handle takes are exactly Q x base with Q in {2,3,4,5,6,8} and
     base in {16384, 16368, 16000, 8000, 8192, 6000, 5000, 4000} (acq_composite.hip; 16368 and 16384 — whose plans start with a

@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     hipMemcpy(dt, ht.data(), ht.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dtw, htw.data(), htw.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dord, ho.data(), ho.size() * 2, hipMemcpyHostToDevice);
-    auto go = [&]() { pl->mix_fft(0, ds, GM_FMT_I8_IQ, dt, dtw, dsp, D, M, nullptr, no > 0 ? dord : nullptr); };
+    auto go = [&]() { pl->mix_fft(0, ds, GM_FMT_I8_IQ, dt, dtw, dsp, D, M, nullptr, no > 0 ? dord : nullptr, nullptr); };
     for (int i = 0; i < 3; ++i) go();
     hipDeviceSynchronize();
     std::vector<float> t;
