@@ -8,6 +8,8 @@
 #define GM_FOR_EACH_PLAN(X) X(LAB_PLAN)
 #include "../../gnss-sdr-rs_amd/csrc/acq_kernels.hip"
 #include <cstdio>
+#include <cstdlib>
+namespace gm { int diag_int(const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; } }
 #include <vector>
 #include <random>
 #include <algorithm>
