@@ -831,17 +831,41 @@ def cfg1_leg(torch, dev, stream, ca, A, synth, with_cpu=False):
         eng.search_dev(x.data_ptr(), A.FMT_I8_REAL)
         eng.decide_dev()
     torch.cuda.synchronize()
-    eng.enable_timing(True)
+    reps = 20
     t0 = time.perf_counter()
-    reps = 10
     for _ in range(reps):
         eng.search_dev(x.data_ptr(), A.FMT_I8_REAL)
         eng.decide_dev()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    ts = eng.timing_summary()
     res = eng.fetch_results()
     found = sorted(r["prn"] for r in res if r)
+    # the stages by the library's HIP events, outside the clocked dwells (four event records cost ~8 us of stream time per dwell)
+    eng.enable_timing(True)
+    for _ in range(10):
+        eng.search_dev(x.data_ptr(), A.FMT_I8_REAL)
+        eng.decide_dev()
+    torch.cuda.synchronize()
+    ts = eng.timing_summary()
+    eng.enable_timing(False)
+    # dwell after dwell with stage F of dwell k + 1 beside stage C of dwell k (gm_acq_prepare_dev: second stream, second spectrum
+    # buffer): 928 one-per-CU workgroups are 3.6 rounds, stage F fits into the rest
+    eng.prepare_dev(x.data_ptr(), A.FMT_I8_REAL)
+    for i in range(3):
+        eng.search_dev(x.data_ptr(), A.FMT_I8_REAL); eng.prepare_dev(x.data_ptr(), A.FMT_I8_REAL); eng.decide_dev()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        eng.search_dev(x.data_ptr(), A.FMT_I8_REAL)
+        if i + 1 < reps:
+            eng.prepare_dev(x.data_ptr(), A.FMT_I8_REAL)
+        eng.decide_dev()
+    torch.cuda.synchronize()
+    dt_ahead = (time.perf_counter() - t0) / reps
+    res_ahead = eng.fetch_results()
+    same = sorted(r["prn"] for r in res_ahead if r) == found and \
+        all((a is None) == (b is None) and (a is None or (a["code_phase_samples"], a["doppler_bin"], a["mag_relative"]) ==
+                                            (b["code_phase_samples"], b["doppler_bin"], b["mag_relative"])) for a, b in zip(res, res_ahead))
     eng.close()
     # BASELINE configs[0] proper: ONE PRN (the reference's test_acquisition_with_real_data searches a single worker at a
     # time): 29 items would leave the chip idle, so every item is cut into five parts (grid split of acq_corr_kernel)
@@ -881,6 +905,8 @@ def cfg1_leg(torch, dev, stream, ca, A, synth, with_cpu=False):
                                                                                 (sc["sats"][0]["code_start"] - r1["code_phase_samples"]) % N) <= 3)},
             "workload": "32 PRN x 29 bins (+-7 kHz / 500 Hz) x 16368 phases, 10 x 1 ms, real int8 (reference test geometry)",
             "cells_per_s": P * D * N / dt, "ms_per_dwell": dt * 1e3, "corr_kernel_ms": ts["avg_corr_ms"],
+            "stage_f_ahead": {"ms_per_dwell": dt_ahead * 1e3, "cells_per_s": P * D * N / dt_ahead, "same_results": bool(same),
+                              "api": "search_dev(k), prepare_dev(k + 1), decide_dev(k): stage F of the next dwell on the handle's second stream"},
             "corr_algorithmic_GBs": corr_bytes / (ts["avg_corr_ms"] * 1e-3) / 1e9 if ts["avg_corr_ms"] > 0 else None,
             "prns_found": found, "prns_in_scene": sorted(s["prn"] for s in sc["sats"])}
 

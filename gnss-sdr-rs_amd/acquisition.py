@@ -223,6 +223,11 @@ class AcquisitionEngine:
     def synchronize(self):
         check(lib().gm_acq_synchronize(self._h), "gm_acq_synchronize")
 
+    def prepare_dev(self, d_samples_ptr, fmt):
+        """Stage F of the next dwell ahead of time, beside the current dwell's stage C (include/gnss_mi355x.h); a following
+        search_dev() with the same pointer and format launches stage C only."""
+        check(lib().gm_acq_prepare_dev(self._h, C.c_void_p(d_samples_ptr), fmt), "gm_acq_prepare_dev")
+
     def set_deferred_decision(self, on=True):
         """Back-to-back dwells: let decide_dev() ride with the next search_dev()'s first kernel (include/gnss_mi355x.h);
         synchronize() / fetch_results() run whatever is still pending."""

@@ -433,6 +433,65 @@ def test_deferred_decision_rides_with_the_next_search(gpu, hipbuf):
     eng.close()
 
 
+@pytest.mark.parametrize("N,fmt_name", [(2048, "c32"), (16368, "i8_real"), (8000, "i8_iq")])
+def test_prepare_dev_same_words_as_the_plain_search(gpu, hipbuf, N, fmt_name):
+    """gm_acq_prepare_dev: stage F of the next dwell on the handle's second stream into the second spectrum buffer.  Dwell after
+    dwell on alternating snapshots — search(k), prepare(k + 1), decide(k) — the metric words and the decisions are those of the plain
+    search, bit for bit; a search with OTHER samples than the prepared ones runs as if nothing had been prepared."""
+    from gnss_sdr_rs_amd import acquisition as A
+    rng = np.random.default_rng(N)
+    fs, M = N * 1000.0, 2
+    dop = np.arange(-1000.0, 1001.0, 500.0, dtype=np.float32)
+    prns = [3, 7, 12, 25, 30, 1]
+    P, D = len(prns), dop.size
+    words = 3 * P * D
+    if fmt_name == "c32":
+        fmt, snaps = A.FMT_C32, [(rng.standard_normal(2 * M * N)).astype(np.float32) for _ in range(3)]
+    elif fmt_name == "i8_iq":
+        fmt, snaps = A.FMT_I8_IQ, [rng.integers(-90, 90, 2 * M * N, dtype=np.int8) for _ in range(3)]
+    else:
+        fmt, snaps = A.FMT_I8_REAL, [rng.integers(-90, 90, M * N, dtype=np.int8) for _ in range(3)]
+    d_x = [hipbuf.upload(x) for x in snaps]
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=prns, n_integrations=M)
+    d_met = hipbuf.alloc(words * 4)
+    key = lambda r: r and (r["prn"], r["code_phase_samples"], r["doppler_bin"], r["mag_relative"])
+    want = []
+    for k in range(3):
+        eng.search_dev(d_x[k], fmt, d_met)
+        eng.decide_dev(d_met)
+        res = [key(r) for r in eng.fetch_results(P)]
+        want.append((hipbuf.download(d_met, words * 4, np.uint32).copy(), res))
+    assert not (want[0][0] == want[1][0]).all()
+    order = [0, 1, 2, 1, 0, 0, 2]
+    eng.prepare_dev(d_x[order[0]], fmt)
+    for i, k in enumerate(order):
+        eng.search_dev(d_x[k], fmt, d_met)
+        if i + 1 < len(order):
+            eng.prepare_dev(d_x[order[i + 1]], fmt)
+        eng.decide_dev(d_met)
+        res = [key(r) for r in eng.fetch_results(P)]
+        assert (hipbuf.download(d_met, words * 4, np.uint32) == want[k][0]).all(), (i, k)
+        assert res == want[k][1], (i, k)
+    # prepared for one snapshot, searched with another (plain path), then the prepared one after all, then plain again
+    eng.prepare_dev(d_x[2], fmt)
+    eng.search_dev(d_x[0], fmt, d_met); eng.synchronize()
+    assert (hipbuf.download(d_met, words * 4, np.uint32) == want[0][0]).all()
+    eng.search_dev(d_x[2], fmt, d_met); eng.synchronize()
+    assert (hipbuf.download(d_met, words * 4, np.uint32) == want[2][0]).all()
+    eng.search_dev(d_x[1], fmt, d_met); eng.synchronize()
+    assert (hipbuf.download(d_met, words * 4, np.uint32) == want[1][0]).all()
+    # with the deferred decision switched on as well
+    eng.set_deferred_decision(True)
+    eng.prepare_dev(d_x[1], fmt)
+    for k in (1, 0, 2):
+        eng.search_dev(d_x[k], fmt, d_met)
+        nxt = {1: 0, 0: 2, 2: 1}[k]
+        eng.prepare_dev(d_x[nxt], fmt)
+        eng.decide_dev(d_met)
+        assert [key(r) for r in eng.fetch_results(P)] == want[k][1]
+    eng.close()
+
+
 def test_composite_sizes_accepted_and_rejected(gpu):
     """The transform sizes beyond one LDS buffer the acquisition handle takes are exactly Q x base with Q in {2,3,4,5,6,8} and
     base in {16384, 16368, 16000, 8000, 8192, 6000, 5000, 4000} (acq_composite.hip; 16368 and 16384 — whose plans start with a
