@@ -480,6 +480,20 @@ def test_prepare_dev_same_words_as_the_plain_search(gpu, hipbuf, N, fmt_name):
     assert (hipbuf.download(d_met, words * 4, np.uint32) == want[2][0]).all()
     eng.search_dev(d_x[1], fmt, d_met); eng.synchronize()
     assert (hipbuf.download(d_met, words * 4, np.uint32) == want[1][0]).all()
+    # 120 dwells enqueued back to back (no host synchronisation in between: the host runs far ahead of the device), each into a
+    # metrics block of its own
+    K = 120
+    seq = [int(v) for v in rng.integers(0, 3, K)]
+    d_all = hipbuf.alloc(K * words * 4)
+    eng.prepare_dev(d_x[seq[0]], fmt)
+    for i, k in enumerate(seq):
+        eng.search_dev(d_x[k], fmt, d_all + i * words * 4)
+        if i + 1 < K:
+            eng.prepare_dev(d_x[seq[i + 1]], fmt)
+    eng.synchronize()
+    got = hipbuf.download(d_all, K * words * 4, np.uint32).reshape(K, words)
+    for i, k in enumerate(seq):
+        assert (got[i] == want[k][0]).all(), (i, k)
     # with the deferred decision switched on as well
     eng.set_deferred_decision(True)
     eng.prepare_dev(d_x[1], fmt)
