@@ -127,6 +127,10 @@ extern "C" {
                                     d_found: *mut u8, hip_stream: *mut c_void) -> c_int;
     pub fn gm_acq_decide_dev(a: *mut GmAcq, d_metrics: *const c_void, n_prn: u32, prn_ids: *const u8, local_tail: u64) -> c_int;
     pub fn gm_acq_fetch_results(a: *mut GmAcq, n_prn: u32, results: *mut GmAcqResult, found: *mut u8) -> c_int;
+    /// back-to-back dwells: the decision rides inside the next search's first kernel
+    pub fn gm_acq_set_deferred_decision(a: *mut GmAcq, on: c_int) -> c_int;
+    /// back-to-back dwells: stage F of the next dwell beside the current stage C (pays at N = 16368)
+    pub fn gm_acq_prepare_dev(a: *mut GmAcq, d_samples: *const c_void, fmt: c_int) -> c_int;
 }
 
 /// status -> the last error text of the library (for panics that mirror the reference's)
