@@ -70,12 +70,7 @@ __global__ __launch_bounds__(1024, 1) void acq_corr_ws31_kernel(
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
     const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int map_mode,
     int split_from, int split_k, int split_items, float* __restrict__ split_scratch, uint32_t* __restrict__ split_counter,
-    int strict_sum, unsigned long long* __restrict__ start_flag, unsigned long long start_value) {
-    // the FIRST workgroup tells the handle's second stream (gm_acq_prepare_dev: a stream memory wait on this word) that this launch
-    // has begun, i.e. that every earlier launch of the handle's stream has ended — what an event recorded in front of the launch
-    // would say, without the event's packet between the decision and this kernel
-    if (start_flag && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(start_flag, start_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int strict_sum) {
     using PL = typename Ws31PlanOf<PLX::N>::type;
     static_assert(PLX::NP == 3 && PLX::R[0] == 33 && PLX::R[1] == 16 && PLX::R[2] == 31, "the stored order is the [33, 16, 31] prime-factor plan's");
     constexpr int T = PL::T, NB0 = PL::NB(0), W0 = 8, NWM = 8;

@@ -842,11 +842,11 @@ template <class PL> struct Launch {
         else return generic;
     }
     static constexpr int SPLIT_SLAB = slab();                             // floats per power plane of the tail split
-    static int corr(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
+    static void corr(hipStream_t st, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
                      uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
                      int n_int, float* split_scratch, int split_planes, uint32_t* split_counter, int strict_sum, int tickets_cleared,
-                     int ref_mul, unsigned long long* start_flag, unsigned long long start_value) {
-        if (n_workers <= 0) return 0;
+                     int ref_mul) {
+        if (n_workers <= 0) return;
         // Tile map: whole Doppler bins per XCD (best L2 locality) unless that costs an XCD an extra round of
         // workgroups (2 x 32 resident per XCD) compared with equal shares of the item list.  Measured on configs[1]
         // geometry: P = 12: 125 -> 88 us, P = 24: 195 -> 165 us with equal shares; P = 32: whole bins 3 % faster.
@@ -909,13 +909,11 @@ template <class PL> struct Launch {
             if (!g_corr_stamps_armed) {
                 if (ref_mul)
                     hipLaunchKernelGGL((acq_corr_ws31_kernel<CP, true>), dim3(grid), dim3(1024), 0, st, spectra, code_fft, mmax, margmax, msum,
-                                       worker_list, n_workers, n_bins, n_int, map_mode, split_from, split_k, split_items, split_scratch, split_counter, strict_sum,
-                                       start_flag, start_value);
+                                       worker_list, n_workers, n_bins, n_int, map_mode, split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
                 else
                     hipLaunchKernelGGL((acq_corr_ws31_kernel<CP, false>), dim3(grid), dim3(1024), 0, st, spectra, code_fft, mmax, margmax, msum,
-                                       worker_list, n_workers, n_bins, n_int, map_mode, split_from, split_k, split_items, split_scratch, split_counter, strict_sum,
-                                       start_flag, start_value);
-                return start_flag ? 1 : 0;
+                                       worker_list, n_workers, n_bins, n_int, map_mode, split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
+                return;
             }
         }
         if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
@@ -930,7 +928,6 @@ template <class PL> struct Launch {
             hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, false, false>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
                                split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
-        return 0;      // (these kernels do not publish the start word)
     }
     static void code_fft(hipStream_t st, const int8_t* code_samples, const cf* tw_fwd, cf* out, int n_codes) {
         hipLaunchKernelGGL(acq_code_fft_kernel<PL>, dim3(n_codes), dim3(PL::T), 0, st, code_samples, tw_fwd, out);

@@ -265,11 +265,6 @@ struct gm_acq {
         cf* d_spectra_alt = nullptr;
         hipStream_t side = nullptr;
         hipEvent_t ev_s = nullptr, ev_f = nullptr;
-        // where the stage C kernel can say so itself (PlanOps::corr returns 1: N = 16368), ev_s is not recorded: the kernel's FIRST
-        // workgroup sets a word as it starts and the preparation waits for that word (a stream memory wait, no CU involved)
-        unsigned long long* d_start = nullptr;      // signal memory (hipMallocSignalMemory): the count of stage C launches that publish it
-        unsigned long long n_start = 0;
-        bool start_armed = false;                   // the most recent stage C launch publishes n_start
         bool valid = false;                 // d_spectra_alt holds (or will hold: ev_f) the spectra of samples / fmt
         const void* samples = nullptr;
         int fmt = 0;
@@ -604,7 +599,7 @@ int gm_acq_destroy(gm_acq* a) {
     if (a->ahead.side) { hipStreamSynchronize(a->ahead.side); hipStreamDestroy(a->ahead.side); }
     if (a->ahead.ev_s) hipEventDestroy(a->ahead.ev_s);
     if (a->ahead.ev_f) hipEventDestroy(a->ahead.ev_f);
-    hipFree(a->ahead.d_spectra_alt); if (a->ahead.d_start) hipFree(a->ahead.d_start);
+    hipFree(a->ahead.d_spectra_alt);
     if (a->own_stream && a->stream) hipStreamDestroy(a->stream);
     delete a;
     return GM_OK;
@@ -821,21 +816,12 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
         }
     }
     if (t) HIPC(hipEventRecord(ev[1], a->stream));
+    if (ah.side) HIPC(hipEventRecord(ah.ev_s, a->stream));
     if (a->Q == 1) {
-        const bool want_start = ah.d_start && a->n_workers > 0;
-        if (ah.side && !want_start) HIPC(hipEventRecord(ah.ev_s, a->stream));
-        const int armed = a->plan->corr(a->stream, a->d_spectra, a->plan->code_paired ? a->d_code_fft_paired : a->d_code_fft, a->d_tw_inv, reinterpret_cast<float*>(met), met + PD,
+        a->plan->corr(a->stream, a->d_spectra, a->plan->code_paired ? a->d_code_fft_paired : a->d_code_fft, a->d_tw_inv, reinterpret_cast<float*>(met), met + PD,
                       reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M),
                       a->d_split_scratch, a->split_planes, a->d_split_counter, a->cfg.strict_sum_order ? 1 : 0, tickets_cleared ? 1 : 0,
-                      a->cfg.reference_products ? 1 : 0, want_start ? ah.d_start : nullptr, ah.n_start + 1);
-        if (ah.side) {
-            ah.start_armed = want_start && armed;
-            if (ah.start_armed) ++ah.n_start;
-            else if (want_start) {       // this plan's kernel has no start word: events from now on (this once behind the launch)
-                HIPC(hipEventRecord(ah.ev_s, a->stream));
-                HIPC(hipFree(ah.d_start)); ah.d_start = nullptr;
-            }
-        }
+                      a->cfg.reference_products ? 1 : 0);
     } else if (a->n_workers) {
         a->comp->corr(a->stream, a->d_spectra, a->d_code_comb, a->d_comp_twn, a->d_tw_inv, reinterpret_cast<float*>(met),
                       met + PD, reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M));
@@ -856,29 +842,18 @@ int gm_acq_prepare_dev(gm_acq* a, const void* d_samples, int fmt) {
     if (!ah.side) {
         HIPC(hipMalloc(&ah.d_spectra_alt, size_t(a->D) * a->M * a->N * 8));
         // lowest priority: its workgroups are wanted where stage C has none left to place (the idle CUs of its last round), not
-        // beside stage C's first round on every CU — the dispatcher honours that only in part (N = 16368: 317.8 us per dwell
-        // plain, 307.3 prepared at normal priority, 304.7 at the lowest; DESIGN 4.2 has the variants that did worse)
+        // beside stage C's first round on every CU — the dispatcher honours that only in part (N = 16368: 307.3 us per dwell at
+        // normal priority, 304.7 at the lowest, before the ticket memset went: DESIGN_HISTORY R4 has the table)
         int least = 0, greatest = 0;
         HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPC(hipStreamCreateWithPriority(&ah.side, hipStreamNonBlocking, gm::diag_int("GM_PREPARE_PRIORITY", least)));
         HIPC(hipEventCreateWithFlags(&ah.ev_s, hipEventDisableTiming));
         HIPC(hipEventCreateWithFlags(&ah.ev_f, hipEventDisableTiming));
         HIPC(hipEventRecord(ah.ev_s, a->stream));               // first time: behind whatever the handle's stream holds so far
-        int can = 0;
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, a->device) == hipSuccess && can &&
-            gm::diag_int("GM_PREPARE_NO_START_WORD", 0) == 0) {
-            const unsigned long long zero = 0ull;
-            if (hipExtMallocWithFlags(reinterpret_cast<void**>(&ah.d_start), 8, hipMallocSignalMemory) != hipSuccess ||
-                hipMemcpy(ah.d_start, &zero, 8, hipMemcpyHostToDevice) != hipSuccess) {
-                if (ah.d_start) (void)hipFree(ah.d_start);
-                ah.d_start = nullptr; (void)hipGetLastError();
-            }
-        }
     }
     // the buffer to fill was last read by a stage C in front of the most recent one: free at ev_s (an earlier, unclaimed
     // preparation is overwritten in stream order)
-    if (ah.start_armed) HIPC(hipStreamWaitValue64(ah.side, ah.d_start, ah.n_start, hipStreamWaitValueGte, ~0ull));
-    else HIPC(hipStreamWaitEvent(ah.side, ah.ev_s, 0));
+    HIPC(hipStreamWaitEvent(ah.side, ah.ev_s, 0));
     a->plan->mix_fft(ah.side, d_samples, fmt, a->d_tables, a->d_tw_mix, ah.d_spectra_alt, int(a->D), int(a->M), nullptr, a->d_order, nullptr);
     HIPC(hipEventRecord(ah.ev_f, ah.side));
     HIPC(hipGetLastError());

@@ -46,11 +46,10 @@ struct PlanOps {
                     cf* spectra, int n_bins, int n_int, uint32_t* clear_tickets, const uint16_t* order, const DecideArgs* dec);
     // stage C (spectra and code_fft in the PAIRED layout): x conj(code spectrum) -> inverse FFT -> |.|^2 accumulated over the integrations ->
     // {max, first argmax, sum} per (worker, bin)  (do_acquisition.rs:184-202, 229-235)
-    // start_flag (may be null): a word the launch's FIRST workgroup sets to start_value as it starts; returns 1 if the launched kernel does that
-    int (*corr)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
-                uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
-                int n_int, float* split_scratch, int split_planes, uint32_t* split_counter, int strict_sum, int tickets_cleared,
-                int ref_mul, unsigned long long* start_flag, unsigned long long start_value);   // ref_mul: gm_acq_cfg.reference_products;   // split_planes: power planes the scratch holds (<= GM_CORR_SPLIT_MAX_SLABS); tickets_cleared: mix_fft(.., split_counter) ran just before on this stream
+    void (*corr)(hipStream_t, const cf* spectra, const cf* code_fft, const cf* tw_inv, float* mmax,
+                 uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins,
+                 int n_int, float* split_scratch, int split_planes, uint32_t* split_counter, int strict_sum, int tickets_cleared,
+                 int ref_mul);   // ref_mul: gm_acq_cfg.reference_products;   // split_planes: power planes the scratch holds (<= GM_CORR_SPLIT_MAX_SLABS); tickets_cleared: mix_fft(.., split_counter) ran just before on this stream
     // AcquisitionWorker::new's replica spectrum (do_acquisition.rs:132-138)
     void (*code_fft)(hipStream_t, const int8_t* code_samples, const cf* tw_fwd, cf* code_fft, int n_codes);
     // the same spectra re-stored in the paired layout stage C reads (PairLayout in acq_kernels.hip); stage F writes its

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     hipMemcpy(dtw, htw.data(), htw.size() * 8, hipMemcpyHostToDevice);
     std::vector<uint32_t> hwl(P); for (int i = 0; i < P; ++i) hwl[i] = i;
     hipMemcpy(wl, hwl.data(), P * 4, hipMemcpyHostToDevice);
-    auto go = [&]() { pl->corr(0, dx, dc, dtw, met, reinterpret_cast<uint32_t*>(met) + P * D, met + 2 * P * D, wl, P, D, M, scratch, GM_CORR_SPLIT_MAX_SLABS, counter, 0, 0, LAB_REF_MUL, nullptr, 0); };
+    auto go = [&]() { pl->corr(0, dx, dc, dtw, met, reinterpret_cast<uint32_t*>(met) + P * D, met + 2 * P * D, wl, P, D, M, scratch, GM_CORR_SPLIT_MAX_SLABS, counter, 0, 0, LAB_REF_MUL); };
     for (int i = 0; i < 3; ++i) go();
     hipDeviceSynchronize();
     std::vector<float> t;

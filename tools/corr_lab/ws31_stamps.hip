@@ -22,7 +22,7 @@ int main() {
     const int share = (P * D + 7) / 8;
     for (int rep = 0; rep < 3; ++rep)
         hipLaunchKernelGGL((acq_corr_ws31_kernel<Plan16368, false, true>), dim3(8 * share), dim3(1024), 0, 0, dx, dc, met, reinterpret_cast<uint32_t*>(met) + P * D,
-                           met + 2 * P * D, wl, P, D, M, 0, share, 1, 0, nullptr, nullptr, 0, nullptr, 0ull);
+                           met + 2 * P * D, wl, P, D, M, 0, share, 1, 0, nullptr, nullptr, 0);
     hipDeviceSynchronize();
     std::vector<long long> h(M * 3 * 8);
     hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
