@@ -250,7 +250,8 @@ int gm_acq_set_deferred_decision(gm_acq *a, int on);
  * (e.g. a published part of a device ring) and stay unchanged until that search has run.  Call order for dwell after dwell:
  * search(k), prepare(k + 1), decide(k).  Pays where stage C leaves CUs idle in its last round — N = 16368: 32 PRN x 29 bins are
  * 3.6 rounds of one workgroup per CU and stage F fits into the rest; not at N = 8000, whose last round is already filled.
- * Same results either way.  Composite sizes accept the call and prepare nothing. */
+ * Same results either way.  The first call allocates the second spectrum buffer (n_bins * n_integrations * fft_size * 8 bytes), the
+ * stream and two events; gm_acq_destroy releases them.  Composite sizes accept the call and prepare nothing. */
 int gm_acq_prepare_dev(gm_acq *a, const void *d_samples, int fmt);
 /* Use an existing HIP stream (e.g. torch's current stream) instead of the handle's own. */
 int gm_acq_set_stream(gm_acq *a, void *hip_stream);
