@@ -804,6 +804,7 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
         HIPC(hipStreamWaitEvent(a->stream, ah.ev_f, 0));
         tickets_cleared = false;
     } else if (a->Q == 1) {
+        ah.valid = false;          // a preparation for other samples is dropped, not kept for a later search that happens to name its buffer
         a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_mix, a->d_spectra, int(a->D), int(a->M), a->d_split_counter, a->d_order,
                          a->dec_deferred ? &a->dec_args : nullptr);
         a->dec_deferred = false;

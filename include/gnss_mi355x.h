@@ -246,7 +246,7 @@ int gm_acq_set_deferred_decision(gm_acq *a, int on);
 /* Stage F (carrier mix + forward transforms) of the NEXT dwell ahead of time: runs on a stream of the handle's own into a second
  * spectrum buffer, beside whatever the handle's stream is doing, as soon as that buffer is free (the stage C that last read it
  * has ended).  A following gm_acq_search_dev with the SAME d_samples and fmt takes the prepared spectra and launches stage C
- * only; with other arguments it runs as if nothing had been prepared.  d_samples must hold the samples when the call is made
+ * only; with other arguments it runs as if nothing had been prepared and the preparation is dropped.  d_samples must hold the samples when the call is made
  * (e.g. a published part of a device ring) and stay unchanged until that search has run.  Call order for dwell after dwell:
  * search(k), prepare(k + 1), decide(k).  Pays where stage C leaves CUs idle in its last round — N = 16368: 32 PRN x 29 bins are
  * 3.6 rounds of one workgroup per CU and stage F fits into the rest; not at N = 8000, whose last round is already filled.

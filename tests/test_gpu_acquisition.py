@@ -472,7 +472,7 @@ def test_prepare_dev_same_words_as_the_plain_search(gpu, hipbuf, N, fmt_name):
         res = [key(r) for r in eng.fetch_results(P)]
         assert (hipbuf.download(d_met, words * 4, np.uint32) == want[k][0]).all(), (i, k)
         assert res == want[k][1], (i, k)
-    # prepared for one snapshot, searched with another (plain path), then the prepared one after all, then plain again
+    # prepared for one snapshot, searched with another (plain path: the preparation is dropped), then that snapshot after all (plain as well)
     eng.prepare_dev(d_x[2], fmt)
     eng.search_dev(d_x[0], fmt, d_met); eng.synchronize()
     assert (hipbuf.download(d_met, words * 4, np.uint32) == want[0][0]).all()
