@@ -4,11 +4,11 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, importlib
 A = importlib.import_module("gnss_sdr_rs_amd.acquisition")
-def leg(name, fs, N, M, dop, fmt, n_per):
-    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=list(range(1, 33)), n_integrations=M)
+def leg(name, fs, N, M, dop, fmt, n_per, prns=32):
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=list(range(1, prns + 1)), n_integrations=M)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     xs = [torch.randint(-100, 100, (M * N * n_per,), dtype=torch.int8, device="cuda") for _ in range(2)]
-    met = torch.empty(3 * 32 * dop.size, dtype=torch.int32, device="cuda")
+    met = torch.empty(3 * prns * dop.size, dtype=torch.int32, device="cuda")
     def run(k, ahead):
         if ahead:
             eng.prepare_dev(xs[0].data_ptr(), fmt)
@@ -26,3 +26,4 @@ def leg(name, fs, N, M, dop, fmt, n_per):
     eng.close()
 leg("N=16368 32x29", 16.368e6, 16368, 10, np.arange(-7000.0, 7001.0, 500.0, dtype=np.float32), A.FMT_I8_REAL, 1)
 leg("N=8000 32x41", 8.0e6, 8000, 10, np.arange(-5000.0, 5001.0, 250.0, dtype=np.float32), A.FMT_I8_IQ, 2)
+leg("N=16368 1x29 (configs[0] proper)", 16.368e6, 16368, 10, np.arange(-7000.0, 7001.0, 500.0, dtype=np.float32), A.FMT_I8_REAL, 1, prns=1)
