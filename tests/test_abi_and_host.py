@@ -58,6 +58,17 @@ def test_compute_entry_fails_loudly_without_device(gm):
         assert int(rc) == -3, out.stdout + out.stderr
 
 
+def test_null_handles_are_refused_not_dereferenced(gm):
+    """Argument checks that need no device: every handle-taking entry of the back-to-back-dwell additions returns GM_ERR_INVALID_ARG
+    (-1) on a null handle, and gm_last_error says why."""
+    import ctypes as C
+    L = gm.lib()
+    assert L.gm_acq_set_deferred_decision(None, 1) == -1
+    assert b"null handle" in L.gm_last_error()
+    assert L.gm_acq_prepare_dev(None, C.c_void_p(16), 0) == -1
+    assert L.gm_acq_synchronize(None) == -1
+
+
 def test_ca_table_and_resampler_host(gm, oracle):
     from gnss_sdr_rs_amd import acquisition as A
     g = golden("ca_code_known_answers.json")
