@@ -1,7 +1,6 @@
 // tools/mix_lab/mix_lab.hip — timing laboratory for stage F (acq_mix_fft_kernel) at BASELINE configs[1] geometry (41 bins x 10
-// integrations of N = 8000, complex int8): the product kernel source included as is, one plan, optional ablation macros
-// (-DGM_LAB_MIX_NOSTORE: the spectrum write-out is skipped unless a value is NaN; -DGM_LAB_MIX_NOTAB: the Doppler table is not
-// read).  Timing only.  Not product code, not a test.
+// integrations of N = 8000, complex int8; arguments: bins, integrations): the product kernel source included as is, one plan
+// (-DLAB_PLAN=...), timed beside an EMPTY launch of the same shape.  Timing only.  Not product code, not a test.
 #ifndef LAB_PLAN
 #define LAB_PLAN gm::Plan8000
 #endif
@@ -13,6 +12,8 @@ namespace gm { int diag_int(const char* name, int dflt) { const char* v = getenv
 #include <vector>
 #include <random>
 #include <algorithm>
+
+__global__ void lab_empty_kernel() {}
 
 int main(int argc, char** argv) {
     using namespace gm;
@@ -45,6 +46,16 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1); t.push_back(ms * 1e3f);
     }
     std::sort(t.begin(), t.end());
+    {   // what an event-timed launch of this shape reads with nothing in it
+        std::vector<float> te;
+        for (int rep = 0; rep < 25; ++rep) {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, 0); hipLaunchKernelGGL(lab_empty_kernel, dim3(D * M), dim3(pl->threads), 0, 0); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); te.push_back(ms * 1e3f);
+        }
+        std::sort(te.begin(), te.end());
+        printf("empty kernel %d x %d: median %.1f us\n", D * M, pl->threads, te[te.size() / 2]);
+    }
     printf("stage F N=%d D=%d M=%d: median %.1f us, min %.1f us per launch\n", N, D, M, t[t.size() / 2], t[0]);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
