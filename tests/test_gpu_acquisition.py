@@ -506,6 +506,48 @@ def test_prepare_dev_same_words_as_the_plain_search(gpu, hipbuf, N, fmt_name):
     eng.close()
 
 
+@pytest.mark.parametrize("opts", [dict(strict_sum_order=True), dict(reference_products=True), dict()])
+def test_back_to_back_dwell_entries_with_options_and_mask_changes(gpu, hipbuf, opts):
+    """The two back-to-back-dwell entries together, on handles with strict_sum_order / reference_products, at the headline size
+    (cut tail: the prepared path leaves the ticket clear to the correlation launch) and with the PRN mask changed between a
+    deferred decision and the search that carries it: the decision uses the mask it was asked with."""
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    t = A.ca_code_table()
+    fs, N, M = 8.0e6, 8000, 3
+    dop = np.arange(-1500.0, 1501.0, 250.0, dtype=np.float32)
+    P = 32
+    sats = [dict(prn_row=4, cn0_dbhz=50.0, doppler_hz=-430.0, code_start=1234), dict(prn_row=20, cn0_dbhz=49.0, doppler_hz=900.0, code_start=4321)]
+    xs = [synth.to_i8_iq(synth.make_scene(t, fs, 0.0, M * N, sats[:k + 1], config_id=70 + k)) for k in range(2)]
+    d_x = [hipbuf.upload(x) for x in xs]
+    key = lambda r: r and (r["prn"], r["code_phase_samples"], r["doppler_bin"], r["mag_relative"])
+    masks = [0xFFFFFFFF, 0xFFFFFFFF & ~(1 << 4), 1 << 20]
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, n_integrations=M, **opts)
+    want = {}
+    for k in range(2):
+        for mi, m in enumerate(masks):
+            eng.set_prn_mask(m)
+            eng.search_dev(d_x[k], A.FMT_I8_IQ, None); eng.decide_dev(None)
+            want[(k, mi)] = [key(r) for r in eng.fetch_results(P)]
+    assert want[(1, 0)][4] and want[(1, 0)][20] and want[(1, 1)][4] is None and want[(1, 2)][4] is None and want[(1, 2)][20]
+    eng.set_deferred_decision(True)
+    seq = [(0, 0), (1, 1), (1, 2), (0, 1), (1, 0), (0, 2)]
+    got = []
+    eng.set_prn_mask(masks[seq[0][1]])
+    eng.prepare_dev(d_x[seq[0][0]], A.FMT_I8_IQ)
+    for i, (k, mi) in enumerate(seq):
+        eng.search_dev(d_x[k], A.FMT_I8_IQ, None)            # carries the decision of dwell i - 1 only on the plain path
+        if i + 1 < len(seq) and i % 2 == 0:
+            eng.prepare_dev(d_x[seq[i + 1][0]], A.FMT_I8_IQ)
+        eng.decide_dev(None)                                 # deferred: asked with mask mi
+        if i + 1 < len(seq):
+            eng.set_prn_mask(masks[seq[i + 1][1]])           # changed BEFORE the deferred decision has run
+        if i % 3 == 2 or i + 1 == len(seq):
+            got.append((i, [key(r) for r in eng.fetch_results(P)]))
+    for i, res in got:
+        assert res == want[seq[i]], (opts, i)
+    eng.close()
+
+
 def test_composite_sizes_accepted_and_rejected(gpu):
     """The transform sizes beyond one LDS buffer the acquisition handle takes are exactly Q x base with Q in {2,3,4,5,6,8} and
     base in {16384, 16368, 16000, 8000, 8192, 6000, 5000, 4000} (acq_composite.hip; 16368 and 16384 — whose plans start with a
