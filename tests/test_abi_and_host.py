@@ -308,7 +308,8 @@ def test_rust_binding_source_matches_the_abi(gm):
     # the three patches: lib.rs gains `pub mod mi355x;` behind its last module; main.rs switches exactly the two stage modules,
     # and the lines it removes are the reference's own imports
     lib_diff = open(os.path.join(root, "rust", "patches", "lib_rs.diff")).read()
-    assert "+pub mod mi355x;" in lib_diff and " pub mod %s;" % ref["_lib_rs_mods"][-1] in lib_diff
+    # (the reference's last line `pub mod constants;` has no trailing newline, so `diff -u` re-states it: tests/test_rust_patches.py)
+    assert "+pub mod mi355x;" in lib_diff and "+pub mod %s;\n+pub mod mi355x;" % ref["_lib_rs_mods"][-1] in lib_diff
     main_diff = open(os.path.join(root, "rust", "patches", "main_rs.diff")).read()
     removed = [l[1:].strip() for l in main_diff.splitlines() if l.startswith("-") and not l.startswith("---")]
     added = [l[1:].strip() for l in main_diff.splitlines() if l.startswith("+") and not l.startswith("+++")]
