@@ -444,7 +444,10 @@ def main():
                                 else "torch.distributed nccl" if world > 1 else None),
                    "exchange_fallback_reason": carrier_note, "exchange_us_per_dwell": exchange_us,
                    "detections_ok": bool(detections_ok)},
-        # the binding roof of the dominant kernel is f32 VALU issue (MFMA is not used: no dense contraction on this path);
+        # the binding roof of the dominant kernel is f32 VALU issue.  (Matrix instructions ARE used on this path where a pass is a
+        # dense contraction — the radix-31 pass of N = 16368, csrc/ws31_core.h — but not in this kernel: every pass of N = 8000 has a
+        # fast algorithm, and v_mfma_f32_16x16x4_f32 holds its SIMD's vector issue for its whole duration, so the dense form of the
+        # radix-16 pass is 3 x the issue time of the vector form: tools/corr_lab/mfma16_8000, profiles/r05_ubench_mfma_coissue.txt.)
         # SURVEY 8d's algorithmic-byte model sits beside it as `hbm_model`, without a `frac` of a physical peak: it counts
         # every worker's re-read of a Doppler bin's spectra (P x) as HBM bytes, and on the chip those are L2 hits
         "roofline": {"bound": "valu-f32", "kernel": "acq_corr_kernel", "achieved": compute["achieved"], "peak": FP32_VALU_PEAK_TFLOPS,
@@ -456,8 +459,9 @@ def main():
                      "fabric_frac_of_hbm_peak": (traffic / corr_s / 1e9 / HBM_PEAK_GBS) if (traffic and corr_s > 0) else None,
                      "reading": "frac = useful f32 flops (5 N log2 N + 10 N per inverse transform) / kernel time / the 157.3 TF vector "
                                 "peak; issue_frac = VALU wave-instructions x 1.02 ns per SIMD / kernel time (the share of the f32 issue "
-                                "slots the kernel fills); traffic = measured fabric bytes per launch (a few % of the HBM peak: the "
-                                "kernel is not HBM-bound); hbm_model = SURVEY 8d's algorithmic bytes / time, a model figure that "
+                                "slots the kernel fills; f32 matrix instructions share that issue port — measured, tools/corr_lab/mfma16_8000 — "
+                                "and are used only for the dense radix-31 pass of N = 16368); traffic = measured fabric bytes per launch (a few % "
+                                "of the HBM peak: the kernel is not HBM-bound); hbm_model = SURVEY 8d's algorithmic bytes / time, a model figure that "
                                 "can exceed the 8 TB/s peak because the re-reads it counts are served by L2",
                      "compute": compute,
                      "hbm_model": {"algorithmic_bytes_per_launch": corr_bytes, "model_GBs": achieved, "hbm_peak_GBs": HBM_PEAK_GBS,
@@ -585,6 +589,31 @@ def main():
 
     eng.close()
     if rank == 0:
+        # The other half of BASELINE's metric (tracking ch x Msps) and the informative legs' headline numbers once more as SCALARS
+        # inside `config`: a record that keeps only the flat part of the line (the driver's `parsed`) then still carries them
+        # (VERDICT round 4, item 3a).  Same values as in the legs' own objects; None where a leg did not run.
+        def pick(leg, *path):
+            v = out.get(leg)
+            for k in path:
+                v = v.get(k) if isinstance(v, dict) else None
+            return v if isinstance(v, (int, float, bool)) else None
+        out["config"].update({
+            "tracking_ch_msps": pick("tracking", "value"), "tracking_ms_per_epoch": pick("tracking", "ms_per_epoch"),
+            "tracking_frac": pick("tracking", "roofline", "frac"), "tracking_channels_locked": pick("tracking", "channels_locked"),
+            "tracking_cpu_ch_msps": pick("tracking", "cpu_baseline", "value"),
+            "tracking_256ch_ch_msps": pick("tracking_256ch", "value"), "tracking_256ch_frac": pick("tracking_256ch", "roofline", "frac"),
+            "cfg1_ms_per_dwell": pick("cfg1_geometry", "ms_per_dwell"), "cfg1_corr_kernel_ms": pick("cfg1_geometry", "corr_kernel_ms"),
+            "cfg1_stage_f_ahead_ms_per_dwell": pick("cfg1_geometry", "stage_f_ahead", "ms_per_dwell"),
+            "cfg1_cells_per_s": pick("cfg1_geometry", "cells_per_s"),
+            "cfg2_m1_ms_per_dwell": pick("cfg2_single_integration", "ms_per_dwell"),
+            "cfg4_galileo_ms_per_dwell": pick("cfg4_galileo_geometry", "ms_per_dwell"),
+            "cfg4_galileo_corr_kernel_ms": pick("cfg4_galileo_geometry", "corr_kernel_ms"),
+            "cfg4_grid_ms_per_dwell": pick("cfg4_grid", "ms_per_dwell"), "cfg4_grid_cells_per_s": pick("cfg4_grid", "cells_per_s"),
+            "cfg5_ch_msps": pick("cfg5_geometry", "ch_msps"), "cfg5_channels_locked": pick("cfg5_geometry", "channels_locked"),
+            "frontend_msps": pick("frontend", "msps"),
+            "receiver_x_real_time": pick("receiver", "x_real_time"), "receiver_tracking_wall_s": pick("receiver", "wall_seconds_per_stage", "tracking"),
+            "receiver_channels_frame_synchronised": pick("receiver", "channels_frame_synchronised"),
+        })
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
