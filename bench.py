@@ -64,11 +64,53 @@ def rank_commands(n_gpus, argv, port, base_env=None, python=None, script=None):
     return cmds
 
 
-def visible_gpus():
-    """Devices this process could hand to its ranks.  torch.cuda.device_count() does not initialise the GPU on this image
-    (it reads the driver's topology), so the launcher stays a process that never touched the card."""
-    import torch
-    return int(torch.cuda.device_count())
+def _visible_filter(n, env=None):
+    """Apply HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (index lists) to a count of n physical devices."""
+    env = os.environ if env is None else env
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is None:
+            continue
+        ids = [t.strip() for t in v.split(",") if t.strip() != ""]
+        if all(t.lstrip("-").isdigit() for t in ids):
+            keep = []
+            for t in ids:                       # the runtime stops at the first invalid index
+                if not (0 <= int(t) < n):
+                    break
+                keep.append(int(t))
+            n = len(set(keep))
+        # (UUID lists: left alone — every listed device is assumed present)
+        elif ids:
+            n = min(n, len(ids))
+    return n
+
+
+def visible_gpus(sysfs="/sys/class/kfd/kfd/topology/nodes", env=None):
+    """Devices this process could hand to its ranks, counted WITHOUT touching HIP: the KFD topology in sysfs (a node with
+    simd_count > 0 is a GPU), filtered by the *_VISIBLE_DEVICES variables.  The launcher starts its ranks as child processes and
+    must not hold a GPU context of its own; torch.cuda.device_count() may fall back to hipGetDeviceCount (which initialises HIP)
+    on builds without amdsmi, so it is asked only in a short-lived child process when sysfs is not there."""
+    n = None
+    try:
+        n = 0
+        for node in sorted(os.listdir(sysfs)):
+            try:
+                props = dict(l.split(None, 1) for l in open(os.path.join(sysfs, node, "properties")).read().splitlines() if " " in l)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        n = None
+    if n is None:
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, timeout=300, text=True)
+            return int(r.stdout.strip().splitlines()[-1])       # (the child applied the visibility variables itself)
+        except Exception:
+            return 0
+    return _visible_filter(n, env)
 
 
 def launch_ranks(n_gpus, argv, timeout_s, script=None, have=None, grace_s=30.0):
@@ -879,15 +921,15 @@ def cfg1_leg(torch, dev, stream, ca, A, synth, with_cpu=False):
     eng.enable_timing(False)
     # dwell after dwell with stage F of dwell k + 1 beside stage C of dwell k (gm_acq_prepare_dev: second stream, second spectrum
     # buffer): 928 one-per-CU workgroups are 3.6 rounds, stage F fits into the rest
-    eng.prepare_dev(x.data_ptr(), A.FMT_I8_REAL)
+    tok = eng.prepare_dev(x.data_ptr(), A.FMT_I8_REAL)
     for i in range(3):
-        eng.search_dev(x.data_ptr(), A.FMT_I8_REAL); eng.prepare_dev(x.data_ptr(), A.FMT_I8_REAL); eng.decide_dev()
+        eng.search_prepared_dev(tok); tok = eng.prepare_dev(x.data_ptr(), A.FMT_I8_REAL); eng.decide_dev()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(reps):
-        eng.search_dev(x.data_ptr(), A.FMT_I8_REAL)
+        eng.search_prepared_dev(tok)
         if i + 1 < reps:
-            eng.prepare_dev(x.data_ptr(), A.FMT_I8_REAL)
+            tok = eng.prepare_dev(x.data_ptr(), A.FMT_I8_REAL)
         eng.decide_dev()
     torch.cuda.synchronize()
     dt_ahead = (time.perf_counter() - t0) / reps
@@ -935,7 +977,7 @@ def cfg1_leg(torch, dev, stream, ca, A, synth, with_cpu=False):
             "workload": "32 PRN x 29 bins (+-7 kHz / 500 Hz) x 16368 phases, 10 x 1 ms, real int8 (reference test geometry)",
             "cells_per_s": P * D * N / dt, "ms_per_dwell": dt * 1e3, "corr_kernel_ms": ts["avg_corr_ms"],
             "stage_f_ahead": {"ms_per_dwell": dt_ahead * 1e3, "cells_per_s": P * D * N / dt_ahead, "same_results": bool(same),
-                              "api": "search_dev(k), prepare_dev(k + 1), decide_dev(k): stage F of the next dwell on the handle's second stream"},
+                              "api": "search_prepared_dev(token k), prepare_dev(k + 1) -> token, decide_dev(k): stage F of the next dwell on the handle's second stream"},
             "corr_algorithmic_GBs": corr_bytes / (ts["avg_corr_ms"] * 1e-3) / 1e9 if ts["avg_corr_ms"] > 0 else None,
             "prns_found": found, "prns_in_scene": sorted(s["prn"] for s in sc["sats"])}
 

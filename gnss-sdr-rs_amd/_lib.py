@@ -105,7 +105,9 @@ SIGNATURES = {
     "gm_acq_decide_host": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _f, _f, _f, _u64, _vp, _vp]),
     "gm_acq_synchronize": (_i, [_vp]),
     "gm_acq_set_deferred_decision": (_i, [_vp, _i]),
-    "gm_acq_prepare_dev": (_i, [_vp, _vp, _i]),
+    "gm_acq_prepare_dev": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_uint64)]),
+    "gm_acq_search_prepared_dev": (_i, [_vp, C.c_uint64, _vp]),
+    "gm_acq_drop_prepared": (_i, [_vp]),
     "gm_acq_set_stream": (_i, [_vp, _vp]),
     "gm_acq_metrics": (_i, [_vp, _vp, _vp, _vp]),
     "gm_acq_code_fft": (_i, [_vp, _u32, _vp]),

@@ -223,10 +223,23 @@ class AcquisitionEngine:
     def synchronize(self):
         check(lib().gm_acq_synchronize(self._h), "gm_acq_synchronize")
 
-    def prepare_dev(self, d_samples_ptr, fmt):
-        """Stage F of the next dwell ahead of time, beside the current dwell's stage C (include/gnss_mi355x.h); a following
-        search_dev() with the same pointer and format launches stage C only."""
-        check(lib().gm_acq_prepare_dev(self._h, C.c_void_p(d_samples_ptr), fmt), "gm_acq_prepare_dev")
+    def prepare_dev(self, d_samples_ptr, fmt, ready_stream=None):
+        """Stage F of the next dwell ahead of time, beside the current dwell's stage C (include/gnss_mi355x.h): a SNAPSHOT of the
+        samples, named by the token this returns; search_prepared_dev(token) launches stage C on it.  ready_stream: the HIP stream
+        whose queued work produces the samples (None: they are there already).  The samples must stay unchanged until the search
+        that consumes the token has been synchronised."""
+        tok = C.c_uint64(0)
+        check(lib().gm_acq_prepare_dev(self._h, C.c_void_p(d_samples_ptr), fmt, C.c_void_p(ready_stream) if ready_stream else None,
+                                       C.byref(tok)), "gm_acq_prepare_dev")
+        return tok.value
+
+    def search_prepared_dev(self, token, d_metrics_ptr=None):
+        """Stage C on the spectra prepared under `token` (GmError INVALID_ARG when the token is stale, consumed, replaced or dropped)."""
+        check(lib().gm_acq_search_prepared_dev(self._h, int(token), C.c_void_p(d_metrics_ptr) if d_metrics_ptr else None),
+              "gm_acq_search_prepared_dev")
+
+    def drop_prepared(self):
+        check(lib().gm_acq_drop_prepared(self._h), "gm_acq_drop_prepared")
 
     def set_deferred_decision(self, on=True):
         """Back-to-back dwells: let decide_dev() ride with the next search_dev()'s first kernel (include/gnss_mi355x.h);

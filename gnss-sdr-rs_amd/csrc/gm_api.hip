@@ -261,12 +261,16 @@ struct gm_acq {
     // EARLIER stage C than the most recent one.  ev_s: recorded on the handle's stream just in front of every stage C launch — a
     // preparation that waits for it starts together with the most recent stage C (every earlier one has ended by then) and, at the
     // lowest priority, gets the CUs that stage C no longer needs
+    // A preparation is named by a TOKEN (a generation number, never 0), not by the address of the samples it was made from: a
+    // ring-backed receiver reuses addresses by construction, and a search that matched on the pointer would silently take the OLD
+    // samples' spectra.  Only gm_acq_search_prepared_dev(token) consumes it.
     struct Ahead {
         cf* d_spectra_alt = nullptr;
         hipStream_t side = nullptr;
-        hipEvent_t ev_s = nullptr, ev_f = nullptr;
-        bool valid = false;                 // d_spectra_alt holds (or will hold: ev_f) the spectra of samples / fmt
-        const void* samples = nullptr;
+        hipEvent_t ev_s = nullptr, ev_f = nullptr, ev_in = nullptr;   // ev_in: the caller's `ready_stream` at the time of the call
+        bool valid = false;                 // d_spectra_alt holds (or will hold: ev_f) the spectra of the preparation `token`
+        uint64_t token = 0, next_token = 1;
+        const void* samples = nullptr;      // composite sizes only (nothing is prepared: the search runs from these at search_prepared)
         int fmt = 0;
     } ahead;
     bool defer_decisions = false;   // gm_acq_set_deferred_decision
@@ -599,6 +603,7 @@ int gm_acq_destroy(gm_acq* a) {
     if (a->ahead.side) { hipStreamSynchronize(a->ahead.side); hipStreamDestroy(a->ahead.side); }
     if (a->ahead.ev_s) hipEventDestroy(a->ahead.ev_s);
     if (a->ahead.ev_f) hipEventDestroy(a->ahead.ev_f);
+    if (a->ahead.ev_in) hipEventDestroy(a->ahead.ev_in);
     hipFree(a->ahead.d_spectra_alt);
     if (a->own_stream && a->stream) hipStreamDestroy(a->stream);
     delete a;
@@ -624,7 +629,7 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
         comp = gm::find_comp(cfg->fft_size);
         if (comp) { pl = gm::find_plan(comp->nb); comp_q = uint32_t(comp->q); }
     }
-    if (!pl) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this fft_size, nor Q x {16000, 8000, 8192, 6000, 5000, 4000} with Q in {2,3,4,5,6,8}");
+    if (!pl) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this fft_size, nor Q x {16384, 16368, 16000, 8192, 8184, 8000, 6000, 5000, 4000} with Q in {2,3,4,5,6,8}");
     if (cfg->strict_sum_order && comp_q > 1)
         return set_err(GM_ERR_INVALID_ARG, "strict_sum_order needs an fft_size with an in-LDS plan (gm_fft_supported_sizes)");
     if (cfg->reference_products && comp_q > 1)
@@ -783,28 +788,28 @@ int gm_acq_set_prn_mask(gm_acq* a, uint64_t mask) {
     return acq_set_mask(a, mask);
 }
 
-int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics) {
-    if (!a || !d_samples) return set_err(GM_ERR_INVALID_ARG, "null handle/samples");
-    if (fmt < GM_FMT_C32 || fmt > GM_FMT_I8_REAL) return set_err(GM_ERR_INVALID_ARG, "bad sample format");
-    if (int rc = ensure_device(a->device)) return rc;
+// stage F (unless `prepared`: then the spectra wait in the second buffer) + stage C of one dwell on the handle's stream
+static int acq_search_common(gm_acq* a, const void* d_samples, int fmt, void* d_metrics, bool prepared) {
     uint32_t* met = d_metrics ? static_cast<uint32_t*>(d_metrics) : a->d_metrics;
     const size_t PD = size_t(a->P) * a->D;
     const bool t = a->tm.on && (a->tm.calls++ % a->tm.stride == 0);
     a->tm.this_call = t;
+    // a timed dwell measures its own kernels only: a decision still pending from the dwell before runs now, in front of the first
+    // event, not as trailing workgroups of the timed stage F
+    if (t) { if (int rc = acq_flush_decision(a)) return rc; }
     hipEvent_t* ev = t ? &a->tm.ev[size_t(a->tm.count % Timing::CAP) * 4] : nullptr;
     if (t) HIPC(hipEventRecord(ev[0], a->stream));
     gm_acq::Ahead& ah = a->ahead;
     bool tickets_cleared = a->d_split_counter != nullptr;
-    if (a->Q == 1 && ah.valid && ah.samples == d_samples && ah.fmt == fmt) {
-        // the spectra of these samples were prepared (gm_acq_prepare_dev): take that buffer once its stage F is through; the
-        // tail split's tickets, which the in-stream stage F clears on its way, are left to corr() (a memset, if it cuts the tail)
+    if (prepared) {
+        // the spectra were prepared (gm_acq_prepare_dev): take that buffer once its stage F is through; the tail split's tickets,
+        // which the in-stream stage F clears on its way, are left to corr() (a memset, if it cuts the tail)
         if (int rc = acq_flush_decision(a)) return rc;
         ah.valid = false;
         std::swap(a->d_spectra, ah.d_spectra_alt);
         HIPC(hipStreamWaitEvent(a->stream, ah.ev_f, 0));
         tickets_cleared = false;
     } else if (a->Q == 1) {
-        ah.valid = false;          // a preparation for other samples is dropped, not kept for a later search that happens to name its buffer
         a->plan->mix_fft(a->stream, d_samples, fmt, a->d_tables, a->d_tw_mix, a->d_spectra, int(a->D), int(a->M), a->d_split_counter, a->d_order,
                          a->dec_deferred ? &a->dec_args : nullptr);
         a->dec_deferred = false;
@@ -834,31 +839,75 @@ int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics
     return GM_OK;
 }
 
-int gm_acq_prepare_dev(gm_acq* a, const void* d_samples, int fmt) {
+int gm_acq_search_dev(gm_acq* a, const void* d_samples, int fmt, void* d_metrics) {
     if (!a || !d_samples) return set_err(GM_ERR_INVALID_ARG, "null handle/samples");
     if (fmt < GM_FMT_C32 || fmt > GM_FMT_I8_REAL) return set_err(GM_ERR_INVALID_ARG, "bad sample format");
-    if (a->Q != 1) return GM_OK;            // composite sizes: nothing is prepared, the search does all of it
     if (int rc = ensure_device(a->device)) return rc;
+    // always from the samples as they are NOW: a preparation (gm_acq_prepare_dev) is never matched by address
+    return acq_search_common(a, d_samples, fmt, d_metrics, false);
+}
+
+int gm_acq_search_prepared_dev(gm_acq* a, uint64_t token, void* d_metrics) {
+    if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
     gm_acq::Ahead& ah = a->ahead;
+    if (!token || !ah.valid || ah.token != token)
+        return set_err(GM_ERR_INVALID_ARG, "no such preparation (token stale, consumed, replaced or dropped)");
+    if (int rc = ensure_device(a->device)) return rc;
+    if (a->Q != 1) {                        // composite sizes prepare nothing: the whole search runs now, from the samples named then
+        ah.valid = false;
+        return acq_search_common(a, ah.samples, ah.fmt, d_metrics, false);
+    }
+    return acq_search_common(a, ah.samples, ah.fmt, d_metrics, true);
+}
+
+int gm_acq_drop_prepared(gm_acq* a) {
+    if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    a->ahead.valid = false;                 // (a stage F still running on the side stream finishes into the spare buffer: harmless)
+    return GM_OK;
+}
+
+int gm_acq_prepare_dev(gm_acq* a, const void* d_samples, int fmt, void* ready_stream, uint64_t* token) {
+    if (!a || !d_samples || !token) return set_err(GM_ERR_INVALID_ARG, "null handle/samples/token");
+    if (fmt < GM_FMT_C32 || fmt > GM_FMT_I8_REAL) return set_err(GM_ERR_INVALID_ARG, "bad sample format");
+    *token = 0;
+    gm_acq::Ahead& ah = a->ahead;
+    if (a->Q != 1) {                        // composite sizes: nothing is prepared, gm_acq_search_prepared_dev does all of it
+        ah.valid = true; ah.samples = d_samples; ah.fmt = fmt; ah.token = *token = ah.next_token++;
+        return GM_OK;
+    }
+    if (int rc = ensure_device(a->device)) return rc;
     if (!ah.side) {
-        HIPC(hipMalloc(&ah.d_spectra_alt, size_t(a->D) * a->M * a->N * 8));
+        // all four resources or none: a failure half-way must leave the handle as it was (a later call starts over)
+        cf* buf = nullptr; hipStream_t side = nullptr; hipEvent_t e[3] = {nullptr, nullptr, nullptr};
         // lowest priority: its workgroups are wanted where stage C has none left to place (the idle CUs of its last round), not
         // beside stage C's first round on every CU — the dispatcher honours that only in part (N = 16368: 307.3 us per dwell at
         // normal priority, 304.7 at the lowest, before the ticket memset went: DESIGN_HISTORY R4 has the table)
         int least = 0, greatest = 0;
-        HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPC(hipStreamCreateWithPriority(&ah.side, hipStreamNonBlocking, gm::diag_int("GM_PREPARE_PRIORITY", least)));
-        HIPC(hipEventCreateWithFlags(&ah.ev_s, hipEventDisableTiming));
-        HIPC(hipEventCreateWithFlags(&ah.ev_f, hipEventDisableTiming));
-        HIPC(hipEventRecord(ah.ev_s, a->stream));               // first time: behind whatever the handle's stream holds so far
+        hipError_t er = hipMalloc(&buf, size_t(a->D) * a->M * a->N * 8);
+        if (er == hipSuccess) er = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (er == hipSuccess) er = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, gm::diag_int("GM_PREPARE_PRIORITY", least));
+        for (int i = 0; i < 3 && er == hipSuccess; ++i) er = hipEventCreateWithFlags(&e[i], hipEventDisableTiming);
+        if (er == hipSuccess) er = hipEventRecord(e[0], a->stream);      // first time: behind whatever the handle's stream holds so far
+        if (er != hipSuccess) {
+            for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x);
+            if (side) (void)hipStreamDestroy(side);
+            if (buf) (void)hipFree(buf);
+            return set_err(GM_ERR_HIP, hipGetErrorString(er));
+        }
+        ah.d_spectra_alt = buf; ah.side = side; ah.ev_s = e[0]; ah.ev_f = e[1]; ah.ev_in = e[2];
     }
     // the buffer to fill was last read by a stage C in front of the most recent one: free at ev_s (an earlier, unclaimed
     // preparation is overwritten in stream order)
     HIPC(hipStreamWaitEvent(ah.side, ah.ev_s, 0));
+    if (ready_stream) {                     // ... and the samples are complete once the work queued on `ready_stream` so far has run
+        HIPC(hipEventRecord(ah.ev_in, reinterpret_cast<hipStream_t>(ready_stream)));
+        HIPC(hipStreamWaitEvent(ah.side, ah.ev_in, 0));
+    }
+    ah.valid = false;
     a->plan->mix_fft(ah.side, d_samples, fmt, a->d_tables, a->d_tw_mix, ah.d_spectra_alt, int(a->D), int(a->M), nullptr, a->d_order, nullptr);
     HIPC(hipEventRecord(ah.ev_f, ah.side));
     HIPC(hipGetLastError());
-    ah.valid = true; ah.samples = d_samples; ah.fmt = fmt;
+    ah.valid = true; ah.samples = d_samples; ah.fmt = fmt; ah.token = *token = ah.next_token++;
     return GM_OK;
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GM_ABI_VERSION 5
+#define GM_ABI_VERSION 6   /* 6: gm_acq_prepare_dev returns a token, gm_acq_search_prepared_dev / gm_acq_drop_prepared (round 5) */
 
 typedef enum {
     GM_OK = 0,
@@ -245,14 +245,29 @@ int gm_acq_synchronize(gm_acq *a);
 int gm_acq_set_deferred_decision(gm_acq *a, int on);
 /* Stage F (carrier mix + forward transforms) of the NEXT dwell ahead of time: runs on a stream of the handle's own into a second
  * spectrum buffer, beside whatever the handle's stream is doing, as soon as that buffer is free (the stage C that last read it
- * has ended).  A following gm_acq_search_dev with the SAME d_samples and fmt takes the prepared spectra and launches stage C
- * only; with other arguments it runs as if nothing had been prepared and the preparation is dropped.  d_samples must hold the samples when the call is made
- * (e.g. a published part of a device ring) and stay unchanged until that search has run.  Call order for dwell after dwell:
- * search(k), prepare(k + 1), decide(k).  Pays where stage C leaves CUs idle in its last round — N = 16368: 32 PRN x 29 bins are
- * 3.6 rounds of one workgroup per CU and stage F fits into the rest; not at N = 8000, whose last round is already filled.
- * Same results either way.  The first call allocates the second spectrum buffer (n_bins * n_integrations * fft_size * 8 bytes), the
- * stream and two events; gm_acq_destroy releases them.  Composite sizes accept the call and prepare nothing. */
-int gm_acq_prepare_dev(gm_acq *a, const void *d_samples, int fmt);
+ * has ended).  The preparation is a SNAPSHOT of d_samples — the counterpart of the reference copying its 10 ms out of the ring
+ * before it searches them (do_acquisition.rs:297-301) — and is named by the generation number written to *token (never 0), NOT by
+ * the address: gm_acq_search_prepared_dev(a, token, d_metrics) launches stage C on those spectra, and nothing else ever uses
+ * them.  gm_acq_search_dev always transforms the samples its own argument holds at that moment, whatever was prepared from the
+ * same address before (ABI 5 matched a following search by pointer and format: a caller that refilled the buffer in between —
+ * any ring-backed receiver — silently got the old samples' spectra).
+ *   ready_stream: a HIP stream (or NULL).  Non-NULL: the samples are complete once the work queued on that stream SO FAR has run
+ *     (an asynchronous copy, a front-end kernel): the library records an event there and stage F waits for it.  NULL: d_samples
+ *     already holds the samples when the call is made (host-time contract, e.g. a published part of a device ring).
+ *   Either way d_samples must stay unchanged until stage F has read it: until the search that consumes the token has been
+ *     synchronised, or gm_acq_synchronize after gm_acq_drop_prepared.
+ *   One preparation is outstanding at a time: a second gm_acq_prepare_dev replaces the first (its token becomes stale),
+ *     gm_acq_drop_prepared forgets it; a stale / consumed / unknown token makes gm_acq_search_prepared_dev return
+ *     GM_ERR_INVALID_ARG and launch nothing.  Plain searches in between leave the preparation intact.
+ * Call order for dwell after dwell: search_prepared(k), prepare(k + 1), decide(k).  Pays where stage C leaves CUs idle in its last
+ * round — N = 16368: 32 PRN x 29 bins are 3.6 rounds of one workgroup per CU and stage F fits into the rest; not at N = 8000, whose
+ * last round is already filled.  Same metric words as the plain search.  The first call allocates the second spectrum buffer
+ * (n_bins * n_integrations * fft_size * 8 bytes), the stream and three events — all of them or, on failure, none;
+ * gm_acq_destroy releases them.  Composite sizes prepare nothing: they issue a token all the same and run the whole search at
+ * gm_acq_search_prepared_dev from d_samples as it is THEN. */
+int gm_acq_prepare_dev(gm_acq *a, const void *d_samples, int fmt, void *ready_stream, uint64_t *token);
+int gm_acq_search_prepared_dev(gm_acq *a, uint64_t token, void *d_metrics);
+int gm_acq_drop_prepared(gm_acq *a);
 /* Use an existing HIP stream (e.g. torch's current stream) instead of the handle's own. */
 int gm_acq_set_stream(gm_acq *a, void *hip_stream);
 

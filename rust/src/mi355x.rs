@@ -130,7 +130,9 @@ extern "C" {
     /// back-to-back dwells: the decision rides inside the next search's first kernel
     pub fn gm_acq_set_deferred_decision(a: *mut GmAcq, on: c_int) -> c_int;
     /// back-to-back dwells: stage F of the next dwell beside the current stage C (pays at N = 16368)
-    pub fn gm_acq_prepare_dev(a: *mut GmAcq, d_samples: *const c_void, fmt: c_int) -> c_int;
+    pub fn gm_acq_prepare_dev(a: *mut GmAcq, d_samples: *const c_void, fmt: c_int, ready_stream: *mut c_void, token: *mut u64) -> c_int;
+    pub fn gm_acq_search_prepared_dev(a: *mut GmAcq, token: u64, d_metrics: *mut c_void) -> c_int;
+    pub fn gm_acq_drop_prepared(a: *mut GmAcq) -> c_int;
 }
 
 /// status -> the last error text of the library (for panics that mirror the reference's)

@@ -23,7 +23,7 @@ def test_header_symbols_all_exported(gm):
     exported = set(re.findall(r" T (gm_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
     assert not [s for s in re.findall(r" [TDB] (\S+)", nm) if not s.startswith("gm_")]   # nothing else leaks
-    assert gm.lib().gm_abi_version() == 5
+    assert gm.lib().gm_abi_version() == 6
 
 
 def test_library_links_no_oracle_and_no_torch(gm):
@@ -65,7 +65,8 @@ def test_null_handles_are_refused_not_dereferenced(gm):
     L = gm.lib()
     assert L.gm_acq_set_deferred_decision(None, 1) == -1
     assert b"null handle" in L.gm_last_error()
-    assert L.gm_acq_prepare_dev(None, C.c_void_p(16), 0) == -1
+    assert L.gm_acq_prepare_dev(None, C.c_void_p(16), 0, None, C.byref(C.c_uint64(0))) == -1
+    assert L.gm_acq_search_prepared_dev(None, 1, None) == -1 and L.gm_acq_drop_prepared(None) == -1
     assert L.gm_acq_synchronize(None) == -1
 
 

@@ -89,3 +89,23 @@ def test_plain_invocation_without_gpus_exits_nonzero_with_a_message():
     if torch.cuda.device_count() >= 2:
         return      # a real multi-GPU host: the launcher would run the bench; not this test's business
     assert r.returncode == 2 and "GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+
+
+def test_visible_gpus_counts_from_sysfs_without_hip(tmp_path):
+    """The launcher counts its devices from the KFD topology (a node with simd_count > 0 is a GPU) and the *_VISIBLE_DEVICES
+    variables — no HIP call, no torch import in the parent: a made-up topology of one CPU node and three GPU nodes."""
+    b = _bench()
+    for i, simd in enumerate((0, 1024, 1024, 1024)):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    nodes = str(tmp_path)
+    assert b.visible_gpus(nodes, env={}) == 3
+    assert b.visible_gpus(nodes, env={"HIP_VISIBLE_DEVICES": "0,2"}) == 2
+    assert b.visible_gpus(nodes, env={"HIP_VISIBLE_DEVICES": ""}) == 0
+    assert b.visible_gpus(nodes, env={"ROCR_VISIBLE_DEVICES": "1", "HIP_VISIBLE_DEVICES": "0"}) == 1
+    assert b.visible_gpus(nodes, env={"HIP_VISIBLE_DEVICES": "0,7,1"}) == 1          # the runtime stops at the first invalid index
+    assert b.visible_gpus(nodes, env={"CUDA_VISIBLE_DEVICES": "2,1,0"}) == 3
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def visible_gpus"):src.index("def launch_ranks")]
+    assert "import torch" not in body.replace('"import torch; print(torch.cuda.device_count())"', "")   # only inside the child's -c string

@@ -176,6 +176,7 @@ def test_five_arm_boc_persistent_kernel_first_epoch(gpu, oracle):
                                                        (25.0e6, 1023, 1.023e6, 25000, 5),     # GPS C/A at configs[2]'s rate
                                                        (32.736e6, 1023, 1.023e6, 32736, 2),        # 2 x 16368, the reference capture geometry doubled (8-byte loads)
                                                        (32.768e6, 1023, 1.023e6, 32768, 2),       # 2 x 16384
+                                                       (24.552e6, 1023, 1.023e6, 24552, 3),       # 3 x 8184 (24 * 11 * 31: half the reference's size as a base)
                                                        (12.0e6, 4092, 1.023e6, 48000, 3),         # 3 x 16000: the wave-specialised kernel (acq_comp_ws.h) at another Q
                                                        (20.0e6, 4092, 1.023e6, 80000, 5),         # 5 x 16000: from Q = 5 its load units are single row pairs
                                                        (32.0e6, 4092, 1.023e6, 128000, 8)])       # 8 x 16000 (its most register-hungry instantiation)

@@ -10,12 +10,14 @@ def leg(name, fs, N, M, dop, fmt, n_per, prns=32):
     xs = [torch.randint(-100, 100, (M * N * n_per,), dtype=torch.int8, device="cuda") for _ in range(2)]
     met = torch.empty(3 * prns * dop.size, dtype=torch.int32, device="cuda")
     def run(k, ahead):
-        if ahead:
-            eng.prepare_dev(xs[0].data_ptr(), fmt)
+        tok = eng.prepare_dev(xs[0].data_ptr(), fmt) if ahead else 0
         for i in range(k):
-            eng.search_dev(xs[i & 1].data_ptr(), fmt, met.data_ptr())
+            if ahead:
+                eng.search_prepared_dev(tok, met.data_ptr())
+            else:
+                eng.search_dev(xs[i & 1].data_ptr(), fmt, met.data_ptr())
             if ahead and i + 1 < k:
-                eng.prepare_dev(xs[(i + 1) & 1].data_ptr(), fmt)
+                tok = eng.prepare_dev(xs[(i + 1) & 1].data_ptr(), fmt)
             eng.decide_dev(met.data_ptr())
         eng.synchronize()
     for rep in range(3):
