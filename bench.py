@@ -1067,7 +1067,7 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
     TrackingChannel::start -> TrackingManager::process_channels on the same ring (15 channels, the reference's constants, FIXED
     code index) -> bit sync / nav bits / preamble on every channel's prompt I.  3.2 s of int8 IQ at the reference capture's
     16.3676 Msps / 4.1304 MHz IF (N = 16368), eight satellites with 50 bit/s data; n_ms = 3200 by default (frame sync needs ~3 s).  One host thread drives it block by block
-    (16 ms blocks; the front-end runs asynchronously on the ring's copy stream, the stages behind the ring one block behind it); reported: sustained Msps and x real time over the whole chain, when the first satellite was handed to
+    (32 ms blocks; the front-end runs asynchronously on the ring's copy and front-end streams, tracking ordered behind it on the device); reported: sustained Msps and x real time over the whole chain, when the first satellite was handed to
     tracking / bit-synchronised / frame-synchronised (signal time and wall clock), and the wall clock per stage.  Informative,
     never `value`.  The same chain is parity-tested in tests/test_gpu_pipeline.py::test_full_chain_frontend_to_nav_bits."""
     from gnss_sdr_rs_amd import decoding as Dm, frontend as F
@@ -1087,12 +1087,12 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
     xi8 = synth.to_i8_iq(np.clip(x.real, -127, 127) + 1j * np.clip(x.imag, -127, 127))
     del x
     t_gen = time.perf_counter() - t_gen
-    BLK = 1 << 18                                                   # 16 ms per block
+    BLK = 1 << 19                                                   # 32 ms per block (one staging slot of the ring's asynchronous writer)
     dop = np.arange(-7000.0, 7000.1, 500.0, dtype=np.float32)       # do_acquisition.rs:248-255
     ring = T.MulticastRingBuffer(1 << 23)                           # 0.5 s of samples (the reference: 2^20)
     fe = F.DigitalFrontend(f_if, fs, fs)
     eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, n_integrations=M, decision_mode=A.DECIDE_BEST_BIN)
-    mgr = T.TrackingManager(fs, n_channels=15, code_index_mode=T.CODE_INDEX_FIXED)
+    mgr = T.TrackingManager(fs, n_channels=15, code_index_mode=T.CODE_INDEX_FIXED, share_device=True)
     amgr = A.AcquisitionManager()
     navs = [Dm.NavSyncStatus(Dm.NAV_FIXED) for _ in range(15)]
     nav_old, nav_cnt, nav_st = [0.0] * 15, [0] * 15, [None] * 15
@@ -1105,6 +1105,10 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
     wm = T.TrackingManager(fs, n_channels=15, code_index_mode=T.CODE_INDEX_FIXED)
     wm.channels[0].start(dict(prn=1, code_phase_samples=0, code_phase_chips=0.0, carrier_freq=0.0, fs=fs, mag_relative=1.0, sample_global_index=0, doppler_bin=0))
     wm.update_all(wring, 2); wm.close(); wfe.close(); wring.close()
+    # ... and the receiver's own tracking handle: result buffers for the loop's pass count and one empty asynchronous call (no channel
+    # is active yet), so that the first real call finds its buffers, its copy path and its result slots in place
+    E_TRK = 2 * (BLK // N) + 3
+    mgr.collect(mgr.update_all_async(ring, E_TRK), wait=True)
 
     # start-up, not throughput: the first write of a ring creates its pinned staging slots, its copy stream and its publisher
     # thread (~0.12 s, once per ring).  The first 64 samples of the stream (4 us of signal) go in before the clock starts.
@@ -1114,9 +1118,10 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
     events = {}
     next_acq_ms, dwells, epochs_run, fe_blocks = 10.0, 0, 0, []
     t_start = time.perf_counter()
-    def consume(head):
-        """everything downstream of the ring for the samples published so far: acquisition when due, tracking to the head, nav bits"""
-        nonlocal next_acq_ms, dwells, epochs_run
+    tickets = []
+    def consume(head, final=False):
+        """everything downstream of the ring: acquisition (on the samples PUBLISHED so far) when due, tracking to the enqueued head, nav bits"""
+        nonlocal next_acq_ms, dwells
         t1 = time.perf_counter()
         sig_ms = head / fs * 1e3
         # ---- do_acquisition::run's loop body, paced in signal time (:287-295: interval from the manager, then a snapshot ending at head)
@@ -1141,10 +1146,24 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
                 stage["fine_doppler"] += time.perf_counter() - t2
                 next_acq_ms = sig_ms + interval_ms
             t1 = time.perf_counter()
-        # ---- TrackingManager::process_channels until the ring's head (do_tracking.rs:407-413)
+        # ---- TrackingManager::process_channels to the ring's head (do_tracking.rs:407-413) — WITHOUT a host wait: the passes are
+        # ordered on the device behind the blocks the feeder has enqueued (gm_trk_update_all_async: the Condvar wait of :392-406 as an
+        # event on the ring's copy stream); their results are collected when they are there, a block or two later
         if chan_prn:
-            outs, proc, lost, done = mgr.update_all(ring, 2 * (BLK // N) + 3)
+            tickets.append((mgr.update_all_async(ring, E_TRK), sig_ms))
+        stage["tracking"] += time.perf_counter() - t1
+        drain(final)
+
+    def drain(everything):
+        nonlocal epochs_run
+        while tickets:
+            t1 = time.perf_counter()
+            res = mgr.collect(tickets[0][0], wait=everything or len(tickets) >= 7)
             t3 = time.perf_counter(); stage["tracking"] += t3 - t1
+            if res is None:
+                return
+            sig_ms = tickets.pop(0)[1]
+            outs, proc, lost, done = res
             epochs_run += int(proc.sum())
             for ch in chan_prn:                 # nav_decoding's per-epoch step on the prompt I (decoding.rs:102-145), one call per channel and block
                 sel = np.nonzero(proc[:, ch])[0]
@@ -1174,7 +1193,7 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
     ring.flush()
     stage["frontend"] += time.perf_counter() - t0
     consume(ring.get_head())
-    consume(ring.get_head())          # (a second pass: a channel's last whole code periods once every other channel has caught up)
+    consume(ring.get_head(), final=True)          # (a second pass: a channel's last whole code periods once every other channel has caught up)
     wall = time.perf_counter() - t_start
     sig_s = n_ms * 1e-3
     truth = {s_["prn"]: s_ for s_ in sats}
@@ -1184,7 +1203,7 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
         if st.active and prn in truth and abs(st.carrier_freq - truth[prn]["doppler_hz"]) < 25.0:
             locked += 1
     out = {"workload": "feeder -> digital front-end -> device ring -> acquisition (32 PRN x 29 bins x 16368, 10 ms) + fine Doppler -> 15-channel "
-                       "tracking -> bit sync / nav bits; %.1f s of int8 IQ at 16.3676 Msps, IF 4.1304 MHz, 8 satellites, 16 ms blocks, one host thread" % sig_s,
+                       "tracking -> bit sync / nav bits; %.1f s of int8 IQ at 16.3676 Msps, IF 4.1304 MHz, 8 satellites, 32 ms blocks, one host thread" % sig_s,
            "signal_seconds": sig_s, "wall_seconds": wall, "x_real_time": sig_s / wall, "sustained_msps": n_ms * N / wall / 1e6,
            "dwells": dwells, "channel_epochs": epochs_run, "satellites_in_scene": len(sats), "channels_started": len(chan_prn),
            "channels_on_true_doppler": locked,
@@ -1193,9 +1212,9 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
            "events_signal_ms_and_wall_s": {k: {"signal_ms": v[0], "wall_s": v[1]} for k, v in events.items()},
            "wall_seconds_per_stage": stage, "frontend_block_seconds": {"first": fe_blocks[0], "median": float(np.median(fe_blocks)), "max_after_first": float(max(fe_blocks[1:]))},
            "scene_generation_seconds": t_gen,
-           "bound": "the host thread: %d blocks, each one front-end enqueue (asynchronous: copy + kernel run on the ring's copy stream), one "
-                    "tracking launch with a synchronisation and a device-to-host copy of the sums, one nav-bit call per channel; the front-end's "
-                    "sequential recurrences cap one stream at ~0.9 Gsps = 55 x real time (DESIGN 5)" % (-(-n_ms * N // BLK))}
+           "bound": "the front-end kernel (its sequential recurrences cap one stream at ~0.9 Gsps = 55 x real time, DESIGN 5); the host thread "
+                    "only enqueues: %d blocks, each one front-end enqueue (copy + kernel on the ring's copy stream) and one tracking enqueue ordered "
+                    "behind it ON THE DEVICE (gm_trk_update_all_async: no host wait per block), results collected a block or two later" % (-(-n_ms * N // BLK))}
     for o in navs:
         o.close()
     mgr.close(); eng.close(); fe.close(); ring.close()

@@ -58,7 +58,8 @@ class TrkCfg(C.Structure):
                 ("n_codes", C.c_uint32), ("code_len", C.c_uint32), ("nominal_code_rate", C.c_float),
                 ("pll_bw", C.c_float), ("pll_zeta", C.c_float), ("pll_gain", C.c_float), ("dll_bw", C.c_float),
                 ("dll_zeta", C.c_float), ("dll_gain", C.c_float), ("pll_dt", C.c_float), ("dll_dt", C.c_float),
-                ("lock_threshold", C.c_float), ("max_lost_epochs", C.c_uint32), ("strict_libm", C.c_int32), ("strict_sum_order", C.c_int32)]
+                ("lock_threshold", C.c_float), ("max_lost_epochs", C.c_uint32), ("strict_libm", C.c_int32), ("strict_sum_order", C.c_int32),
+                ("share_device", C.c_int32)]
 
 
 FMT_C32, FMT_I8_IQ, FMT_I8_REAL = 0, 1, 2
@@ -156,6 +157,8 @@ SIGNATURES = {
     "gm_trk_do_work": (_i, [_vp, _u32, _vp, _sz, C.POINTER(TrkOut), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
     "gm_trk_update_all": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "gm_trk_update_all_dev": (_i, [_vp, _vp, _u32]),
+    "gm_trk_update_all_async": (_i, [_vp, _vp, _u32, C.POINTER(C.c_uint64)]),
+    "gm_trk_collect": (_i, [_vp, C.c_uint64, _i, _vp, _vp, _vp, C.POINTER(_u32), C.POINTER(_i)]),
     "gm_trk_synchronize": (_i, [_vp]),
     "gm_trk_set_stream": (_i, [_vp, _vp]),
     "gm_trk_debug_stamps": (_i, [_vp, _u32, _vp]),

@@ -168,29 +168,78 @@ struct gm_ring {
     // `notifier` + `condvar` of the reference ring (multicast_ring_buffer.rs:42-43,95-98): gm_ring_wait_head sleeps here
     std::mutex notifier;
     std::condition_variable condvar;
-    // asynchronous writer (gm_ring_write_samples_async): pinned staging slots, a copy stream, and `head` published
-    // by a host callback that the stream runs after the copy has landed
+    // asynchronous writer (gm_ring_write_samples_async): pinned staging slots, a copy stream, and `head` published once the copy
+    // has landed.  Published by PULL: every chunk leaves an entry {event, head after it} in `pending`; whoever looks at the head
+    // (gm_ring_get_head / _wait_head / the stage entries that snapshot the ring) first retires the entries whose events have
+    // completed (ring_refresh_head).  Round 4 published from a hipLaunchHostFunc callback on the copy stream: the runtime's
+    // callback thread wakes up milliseconds late now and then, and the stream — hence the next block's copy and front-end kernel
+    // — waits behind the callback (7-9 ms stalls every five or six blocks of the receiver loop, tools/trk_async_probe.py).
     static constexpr int SLOTS = 4;
-    static constexpr size_t SLOT_SAMPLES_MAX = size_t(1) << 18;      // 16 ms at 16.4 Msps: one copy + one front-end launch per block of that size
+    static constexpr size_t SLOT_SAMPLES_MAX = size_t(1) << 19;      // 32 ms at 16.4 Msps: one copy + one front-end launch per block of that size (the
+                                                                     // front-end kernel's fixed ~45 us weigh 15 % on a 2^18 block, 8 % on this one)
     size_t slot_samples = 0;                                        // min(ring size, SLOT_SAMPLES_MAX), set at create
     cf* staging[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t slot_done[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     bool slot_used[SLOTS] = {false, false, false, false};
     hipStream_t copy_stream = nullptr;
+    // gm_frontend_write_ring: the front-end kernels run on a stream of their own behind the copies (event per slot), so the copy
+    // of block k + 1 travels while the kernel of block k runs
+    hipStream_t fe_stream = nullptr;
+    hipEvent_t h2d_done[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t last_enq_stream = nullptr;       // the stream ev_enq was last recorded on (see ring_enqueue_publish)
     uint64_t write_pos = 0;       // writer-private: samples enqueued so far (>= head)
     uint64_t slot_seq = 0;
-    struct Publish { gm_ring* r; uint64_t new_head; };
-    std::vector<Publish*> publish_pool;
+    struct Pending { int slot; uint64_t new_head; };
+    std::mutex pend_mu;
+    std::vector<Pending> pending;           // FIFO, at most SLOTS entries (a slot is re-used only after its entry has been retired)
+    // what the writer has ENQUEUED on copy_stream so far, and an event recorded there behind it: a consumer that must not wait on
+    // the host (gm_trk_update_all_async) orders its own stream behind `ev_enq` on the DEVICE and may then use `enqueued` as its head
+    // — the device-side counterpart of the Condvar wait of do_tracking::run (do_tracking.rs:392-406).  enq_mu: writer and
+    // consumer may be different host threads; the pair (enqueued, ev_enq) is read and written under it.
+    std::mutex enq_mu;
+    hipEvent_t ev_enq = nullptr;
+    uint64_t enqueued = 0;
+    bool ev_enq_armed = false;
 };
+
+// Wait for an event the way a latency path wants it: poll (hipEventQuery) for up to ~2 ms before handing over to the runtime's blocking
+// wait.  hipEventSynchronize's wake-up through the interrupt path costs milliseconds on this platform when the event is already (or
+// almost) complete — measured 7-9 ms per wait in the receiver loop, against the ~0.3 ms the awaited front-end block takes
+// (tools/trk_async_probe.py) — and the device idles meanwhile, because the host is what feeds it.
+static hipError_t wait_event_polling(hipEvent_t ev) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+        (void)hipGetLastError();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipEventSynchronize(ev);
+    }
+}
 
 static void ring_publish(gm_ring* r, uint64_t new_head) {
     r->head.store(new_head, std::memory_order_release);
     std::lock_guard<std::mutex> g(r->notifier);     // "Wake up Tracking after writing new samples" (:94-98)
     r->condvar.notify_all();
 }
-static void ring_publish_cb(void* p) {              // runs on a HIP runtime thread after the copy; no HIP calls here
-    auto* pub = static_cast<gm_ring::Publish*>(p);
-    ring_publish(pub->r, pub->new_head);
+// retire the chunks whose copies (and front-end kernels) have run: head := the newest completed one.  Any host thread; the
+// ring's device must be current.  `all`: the copy stream has just been synchronised — everything is complete.
+static void ring_refresh_head(gm_ring* r, bool all = false) {
+    if (!r->copy_stream) return;
+    uint64_t newest = 0;
+    bool any = false;
+    {
+        std::lock_guard<std::mutex> g(r->pend_mu);
+        size_t done = 0;
+        while (done < r->pending.size()) {
+            if (!all) {
+                const hipError_t q = hipEventQuery(r->slot_done[r->pending[done].slot]);
+                if (q != hipSuccess) { (void)hipGetLastError(); break; }
+            }
+            newest = r->pending[done].new_head; any = true; ++done;
+        }
+        if (done) r->pending.erase(r->pending.begin(), r->pending.begin() + done);
+    }
+    if (any && int64_t(newest - r->head.load(std::memory_order_relaxed)) > 0) ring_publish(r, newest);
 }
 static int ring_async_init(gm_ring* r) {
     if (r->copy_stream) return GM_OK;
@@ -202,16 +251,29 @@ static int ring_async_init(gm_ring* r) {
     r->write_pos = r->head.load(std::memory_order_relaxed);
     return GM_OK;
 }
-// after the work of one chunk has been enqueued on copy_stream: publish head = write_pos once it has run
-static int ring_enqueue_publish(gm_ring* r) {
-    if (r->publish_pool.size() > 4096) {     // bound the bookkeeping: everything enqueued before this sync has run
-        HIPC(hipStreamSynchronize(r->copy_stream));
-        for (auto* p : r->publish_pool) delete p;
-        r->publish_pool.clear();
+// after the work of one chunk (staging slot `slot`, its event recorded) has been enqueued on `st` (copy_stream or fe_stream)
+static int ring_enqueue_publish(gm_ring* r, int slot, hipStream_t st) {
+    {
+        std::lock_guard<std::mutex> g(r->pend_mu);
+        r->pending.push_back(gm_ring::Pending{slot, r->write_pos});
     }
-    auto* pub = new gm_ring::Publish{r, r->write_pos};
-    r->publish_pool.push_back(pub);
-    HIPC(hipLaunchHostFunc(r->copy_stream, ring_publish_cb, pub));
+    {   // the enqueued head and its event (see struct gm_ring): "everything enqueued so far" — when the writer changes streams
+        // (plain copies and front-end blocks on one ring), the new stream first waits for what the event covered before
+        std::lock_guard<std::mutex> g(r->enq_mu);
+        if (!r->ev_enq) HIPC(hipEventCreateWithFlags(&r->ev_enq, hipEventDisableTiming));
+        if (r->ev_enq_armed && r->last_enq_stream != st) HIPC(hipStreamWaitEvent(st, r->ev_enq, 0));
+        r->last_enq_stream = st;
+        HIPC(hipEventRecord(r->ev_enq, st));
+        r->enqueued = r->write_pos;
+        r->ev_enq_armed = true;
+    }
+    return GM_OK;
+}
+// a staging slot is about to be re-used: its previous chunk must have run — and is retired first (its entry names the slot's event)
+static int ring_reclaim_slot(gm_ring* r, int slot) {
+    if (!r->slot_used[slot]) return GM_OK;
+    HIPC(wait_event_polling(r->slot_done[slot]));
+    ring_refresh_head(r);
     return GM_OK;
 }
 
@@ -1002,6 +1064,8 @@ int gm_acq_search_ring(gm_acq* a, gm_ring* ring, uint64_t prn_mask, gm_acq_resul
     if (a->device != ring->device) return set_err(GM_ERR_INVALID_ARG, "ring lives on another device");
     const size_t need = size_t(a->M) * a->N;
     if (need > ring->size) return set_err(GM_ERR_OUT_OF_RANGE, "ring smaller than num_integrations*fft_size");
+    if (int rc = ensure_device(ring->device)) return rc;
+    ring_refresh_head(ring);
     const uint64_t head = ring->head.load(std::memory_order_acquire);
     if ((int64_t)(head - need) < 0) return set_err(GM_ERR_OUT_OF_RANGE, "not enough samples yet (head < M*N)");   // :299
     if (int rc = ensure_device(a->device)) return rc;
@@ -1302,11 +1366,13 @@ int gm_ring_destroy(gm_ring* r) {
     if (!r) return GM_OK;
     hipSetDevice(r->device);
     if (r->copy_stream) { hipStreamSynchronize(r->copy_stream); hipStreamDestroy(r->copy_stream); }
+    if (r->fe_stream) { hipStreamSynchronize(r->fe_stream); hipStreamDestroy(r->fe_stream); }
+    for (hipEvent_t e : r->h2d_done) if (e) hipEventDestroy(e);
+    if (r->ev_enq) hipEventDestroy(r->ev_enq);
     for (int i = 0; i < gm_ring::SLOTS; ++i) {
         if (r->staging[i]) hipHostFree(r->staging[i]);
         if (r->slot_done[i]) hipEventDestroy(r->slot_done[i]);
     }
-    for (auto* p : r->publish_pool) delete p;
     hipFree(r->d_buf);
     delete r;
     return GM_OK;
@@ -1325,7 +1391,7 @@ int gm_ring_write_samples_async(gm_ring* r, const gm_c32* s, size_t n) {
     while (n) {
         const size_t chunk = n < r->slot_samples ? n : r->slot_samples;
         const int slot = int(r->slot_seq++ % gm_ring::SLOTS);
-        if (r->slot_used[slot]) HIPC(hipEventSynchronize(r->slot_done[slot]));
+        if (int rc = ring_reclaim_slot(r, slot)) return rc;
         memcpy(r->staging[slot], src, chunk * 8);
         const size_t start = size_t(r->write_pos & r->mask);
         const size_t first = start + chunk <= r->size ? chunk : r->size - start;
@@ -1335,7 +1401,7 @@ int gm_ring_write_samples_async(gm_ring* r, const gm_c32* s, size_t n) {
         HIPC(hipEventRecord(r->slot_done[slot], r->copy_stream));
         r->slot_used[slot] = true;
         r->write_pos += chunk;
-        if (int rc = ring_enqueue_publish(r)) return rc;
+        if (int rc = ring_enqueue_publish(r, slot, r->copy_stream)) return rc;
         src += chunk; n -= chunk;
     }
     return GM_OK;
@@ -1346,8 +1412,8 @@ int gm_ring_flush(gm_ring* r) {
     if (!r->copy_stream) return GM_OK;
     if (int rc = ensure_device(r->device)) return rc;
     HIPC(hipStreamSynchronize(r->copy_stream));
-    for (auto* p : r->publish_pool) delete p;
-    r->publish_pool.clear();
+    if (r->fe_stream) HIPC(hipStreamSynchronize(r->fe_stream));
+    ring_refresh_head(r, true);
     return GM_OK;
 }
 
@@ -1356,8 +1422,21 @@ int gm_ring_flush(gm_ring* r) {
 int gm_ring_wait_head(gm_ring* r, uint64_t required_idx, uint32_t timeout_ms, int* reached) {
     if (!r) return set_err(GM_ERR_INVALID_ARG, "null ring");
     auto ok = [&] { return int64_t(r->head.load(std::memory_order_acquire) - required_idx) >= 0; };
-    std::unique_lock<std::mutex> g(r->notifier);
-    const bool got = r->condvar.wait_for(g, std::chrono::milliseconds(timeout_ms), ok);
+    if (r->copy_stream) { if (int rc = ensure_device(r->device)) return rc; }
+    // the asynchronous writer's chunks are retired by whoever looks (ring_refresh_head): look, then sleep on the Condvar in short
+    // slices (a synchronous writer, or another reader's refresh, notifies it) until the head is there or the time is up
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+    bool got = false;
+    for (;;) {
+        ring_refresh_head(r);
+        if ((got = ok())) break;
+        const auto now = std::chrono::steady_clock::now();
+        if (now >= deadline) break;
+        std::unique_lock<std::mutex> g(r->notifier);
+        auto slice = std::chrono::microseconds(100);
+        if (deadline - now < slice) slice = std::chrono::duration_cast<std::chrono::microseconds>(deadline - now);
+        if ((got = r->condvar.wait_for(g, slice, ok))) break;
+    }
     if (reached) *reached = got ? 1 : 0;
     return GM_OK;
 }
@@ -1382,6 +1461,7 @@ int gm_ring_write_samples(gm_ring* r, const gm_c32* s, size_t n) {
 
 int gm_ring_get_head(gm_ring* r, uint64_t* head) {
     if (!r || !head) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (r->copy_stream) { if (int rc = ensure_device(r->device)) return rc; ring_refresh_head(r); }
     *head = r->head.load(std::memory_order_acquire);
     return GM_OK;
 }
@@ -1431,9 +1511,17 @@ struct gm_trk {
     int* d_error_dev = nullptr;         // its device-memory twin, read by every later launch (trk_persistent_kernel)
     uint32_t launch_seq = 0;
     long long* d_stamps = nullptr; uint32_t stamps_cap = 0;   // diagnostic phase stamps (gm_trk_debug_stamps)
+    // gm_trk_update_all_async: results of call k land in pinned slot k % TICKETS ([outs | processed | lost] of that call's epochs),
+    // `done` recorded behind the copies; gm_trk_collect hands them over and frees the slot
+    static constexpr int TICKETS = 8;
+    struct Ticket { uint8_t* h = nullptr; hipEvent_t done = nullptr; bool in_flight = false; uint32_t epochs = 0; uint64_t id = 0; } tk[TICKETS];
+    uint8_t* tk_block = nullptr;          // ONE pinned allocation cut into the TICKETS slots (a pinned allocation costs ~1 ms: not per slot, not in a receiver's loop)
+    size_t tk_cap = 0;                    // bytes per slot
+    uint64_t next_ticket = 1;
 };
 
 static int trk_check_error(gm_trk* t);
+static int trk_reserve_tickets(gm_trk* t, size_t bytes);
 // strict_sum_order: room for `samples` per-sample products per sum and channel
 static int trk_reserve_terms(gm_trk* t, size_t samples) {
     samples = (samples + 3) & ~size_t(3);       // rows of the streams stay 16-byte aligned
@@ -1478,6 +1566,8 @@ int gm_trk_destroy(gm_trk* t) {
     hipFree(t->d_codes); hipFree(t->d_states); hipFree(t->d_partials); hipFree(t->d_ready); hipFree(t->d_scratch); hipFree(t->d_terms);
     hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
     if (t->h_res) hipHostFree(t->h_res);
+    for (auto& k : t->tk) if (k.done) hipEventDestroy(k.done);
+    if (t->tk_block) hipHostFree(t->tk_block);
     hipFree(t->d_xchg); if (t->d_error) hipHostFree(t->d_error); hipFree(t->d_error_dev); hipFree(t->d_stamps);
     if (t->ev0) hipEventDestroy(t->ev0);
     if (t->ev1) hipEventDestroy(t->ev1);
@@ -1576,7 +1666,8 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
         // 480 of the 512 places, where 8 left a third of the chip idle and two-workgroup CUs beside one-workgroup CUs);
         // 17..31 fall back to 16, the width of the DPP totals path
         {
-            const size_t fit = (size_t(cus) * per_cu) / slots;
+            // share_device: a quarter of the places (gm_trk_cfg: the other stages' kernels run beside a tracking launch)
+            const size_t fit = (size_t(cus) * per_cu) / (cfg->share_device ? 4 : 1) / slots;
             g = int(fit < 1 ? 1 : fit > 32 ? 32 : fit);
             while (g > 1 && g * nv > 256) --g;
             if (g > 16 && g < 32) g = 16;
@@ -1595,6 +1686,7 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
         HIPT(hipMemsetAsync(t->d_error_dev, 0, sizeof(int), t->stream));
     }
     if (int rc = trk_reserve_epochs(t, 1)) return fail(rc);
+    if (int rc = trk_reserve_tickets(t, size_t(128) * t->C * (sizeof(gm_trk_out) + 2))) return fail(rc);     // gm_trk_update_all_async's result slots
     HIPT(hipStreamSynchronize(t->stream));      // the clears above have landed before any caller-supplied stream (gm_trk_set_stream) can run a kernel
 #undef HIPT
     *out = t;
@@ -1733,10 +1825,8 @@ struct PersistChain { std::mutex mu; hipEvent_t ev = nullptr; bool armed = false
 PersistChain g_persist_chain[16];
 }
 
-int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
-    if (!t || !ring || !epochs) return set_err(GM_ERR_INVALID_ARG, "bad argument");
-    if (t->device != ring->device) return set_err(GM_ERR_INVALID_ARG, "ring lives on another device");
-    if (int rc = ensure_device(t->device)) return rc;
+// `epochs` passes of process_channels on the handle's stream; the data gate of every pass (:170-172) uses `head`
+static int trk_launch_all(gm_trk* t, gm_ring* ring, uint32_t epochs, uint64_t head) {
     if (int rc = trk_reserve_epochs(t, epochs)) return rc;
     if (t->dc.strict_sum_order) {
         // the reference's sequential sums: three launches per pass (products, one serial wave per channel, scalar epilogue)
@@ -1751,7 +1841,7 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
         if (schain.armed) HIPC(hipStreamWaitEvent(t->stream, schain.ev, 0));
         if (t->timing) HIPC(hipEventRecord(t->ev0, t->stream));
         gm::TrkSrc src;
-        src.base = ring->d_buf; src.mask = ring->mask; src.head = ring->head.load(std::memory_order_acquire); src.linear = 0; src.only_channel = -1;
+        src.base = ring->d_buf; src.mask = ring->mask; src.head = head; src.linear = 0; src.only_channel = -1;
         for (uint32_t e = 0; e < epochs; ++e) {
             const size_t o = size_t(e) * t->C;
             gm::launch_trk_epoch(t->stream, t->dc, t->d_codes, t->d_states, src, t->slices, t->d_partials, t->d_ready, gm::TRK_MODE_DO_WORK,
@@ -1774,7 +1864,7 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
         const size_t o = size_t(e0) * t->C;
         t->launch_seq = (t->launch_seq + 1) & 0xfffffu;
         if (t->launch_seq == 0) t->launch_seq = 1;
-        gm::launch_trk_persistent(t->stream, t->dc, t->d_codes, t->d_states, ring->d_buf, ring->mask, ring->head.load(std::memory_order_acquire), t->G,
+        gm::launch_trk_persistent(t->stream, t->dc, t->d_codes, t->d_states, ring->d_buf, ring->mask, head, t->G,
                                   int(ne), t->launch_seq << 12, t->d_xchg, t->d_outs + o, t->d_proc + o, t->d_lost + o,
                                   t->d_lostprn + o, t->d_error, t->d_error_dev, (t->d_stamps && e0 == 0 && ne <= t->stamps_cap) ? t->d_stamps : nullptr);
     }
@@ -1782,6 +1872,94 @@ int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
     HIPC(hipEventRecord(chain.ev, t->stream));
     chain.armed = true;
     HIPC(hipGetLastError());
+    return GM_OK;
+}
+
+int gm_trk_update_all_dev(gm_trk* t, gm_ring* ring, uint32_t epochs) {
+    if (!t || !ring || !epochs) return set_err(GM_ERR_INVALID_ARG, "bad argument");
+    if (t->device != ring->device) return set_err(GM_ERR_INVALID_ARG, "ring lives on another device");
+    if (int rc = ensure_device(t->device)) return rc;
+    ring_refresh_head(ring);
+    return trk_launch_all(t, ring, epochs, ring->head.load(std::memory_order_acquire));      // the PUBLISHED head: the samples are in HBM
+}
+
+// the pinned result slots of gm_trk_update_all_async: one block, at least `bytes` per slot (grown only while no ticket is in flight)
+static int trk_reserve_tickets(gm_trk* t, size_t bytes) {
+    if (bytes <= t->tk_cap) return GM_OK;
+    for (const auto& k : t->tk)
+        if (k.in_flight) return set_err(GM_ERR_OUT_OF_RANGE, "a larger max_epochs than the result slots hold: collect the tickets in flight first");
+    if (t->tk_block) { hipHostFree(t->tk_block); t->tk_block = nullptr; t->tk_cap = 0; }
+    const size_t per = (bytes + 255) & ~size_t(255);
+    HIPC(hipHostMalloc(reinterpret_cast<void**>(&t->tk_block), per * gm_trk::TICKETS, hipHostMallocDefault));
+    t->tk_cap = per;
+    for (int i = 0; i < gm_trk::TICKETS; ++i) {
+        t->tk[i].h = t->tk_block + size_t(i) * per;
+        if (!t->tk[i].done) HIPC(hipEventCreateWithFlags(&t->tk[i].done, hipEventDisableTiming));
+    }
+    return GM_OK;
+}
+
+static uint32_t trk_epochs_done(const uint8_t* proc, uint32_t max_epochs, uint32_t C) {
+    uint32_t done = 0;
+    for (uint32_t e = 0; e < max_epochs; ++e) {
+        bool any = false;
+        for (uint32_t c = 0; c < C; ++c) any |= proc[size_t(e) * C + c] != 0;
+        if (any) done = e + 1;
+    }
+    return done;
+}
+
+// The same passes without a host wait: ordered on the DEVICE behind whatever the ring's writer has enqueued so far
+// — an event on the ring's copy stream, the counterpart of the Condvar wait at do_tracking.rs:392-406 — with the data gate on that
+// enqueued head; results into a pinned slot, handed over by gm_trk_collect.
+int gm_trk_update_all_async(gm_trk* t, gm_ring* ring, uint32_t max_epochs, uint64_t* ticket) {
+    if (!t || !ring || !max_epochs || !ticket) return set_err(GM_ERR_INVALID_ARG, "bad argument");
+    if (t->device != ring->device) return set_err(GM_ERR_INVALID_ARG, "ring lives on another device");
+    *ticket = 0;
+    gm_trk::Ticket& k = t->tk[t->next_ticket % gm_trk::TICKETS];
+    if (k.in_flight) return set_err(GM_ERR_OUT_OF_RANGE, "all result slots are in flight: gm_trk_collect the oldest ticket first");
+    if (int rc = ensure_device(t->device)) return rc;
+    const size_t n = size_t(max_epochs) * t->C, bytes = n * (sizeof(gm_trk_out) + 2);
+    if (int rc = trk_reserve_tickets(t, bytes)) return rc;
+    ring_refresh_head(ring);
+    uint64_t head = ring->head.load(std::memory_order_acquire);
+    {
+        std::lock_guard<std::mutex> g(ring->enq_mu);
+        if (ring->ev_enq_armed) {
+            HIPC(hipStreamWaitEvent(t->stream, ring->ev_enq, 0));
+            if (int64_t(ring->enqueued - head) > 0) head = ring->enqueued;
+        }
+    }
+    if (int rc = trk_launch_all(t, ring, max_epochs, head)) return rc;
+    HIPC(hipMemcpyAsync(k.h, t->d_outs, n * sizeof(gm_trk_out), hipMemcpyDeviceToHost, t->stream));
+    HIPC(hipMemcpyAsync(k.h + n * sizeof(gm_trk_out), t->d_proc, n, hipMemcpyDeviceToHost, t->stream));
+    HIPC(hipMemcpyAsync(k.h + n * sizeof(gm_trk_out) + n, t->d_lost, n, hipMemcpyDeviceToHost, t->stream));
+    HIPC(hipEventRecord(k.done, t->stream));
+    k.in_flight = true; k.epochs = max_epochs; k.id = *ticket = t->next_ticket++;
+    return GM_OK;
+}
+
+int gm_trk_collect(gm_trk* t, uint64_t ticket, int wait, gm_trk_out* outs, uint8_t* processed, uint8_t* lost, uint32_t* epochs_done,
+                   int* ready) {
+    if (!t || !ticket || !ready) return set_err(GM_ERR_INVALID_ARG, "bad argument");
+    gm_trk::Ticket& k = t->tk[ticket % gm_trk::TICKETS];
+    if (!k.in_flight || k.id != ticket) return set_err(GM_ERR_INVALID_ARG, "no such ticket (collected already, or never issued)");
+    if (int rc = ensure_device(t->device)) return rc;
+    *ready = 0;
+    if (wait) HIPC(wait_event_polling(k.done));
+    else {
+        const hipError_t q = hipEventQuery(k.done);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return GM_OK; }
+        if (q != hipSuccess) return hip_fail(q, "hipEventQuery(ticket)");
+    }
+    k.in_flight = false;
+    if (int rc = trk_check_error(t)) return rc;
+    const size_t n = size_t(k.epochs) * t->C;
+    if (outs) memcpy(outs, k.h, n * sizeof(gm_trk_out));
+    if (processed) memcpy(processed, k.h + n * sizeof(gm_trk_out), n);
+    if (lost) memcpy(lost, k.h + n * sizeof(gm_trk_out) + n, n);
+    if (epochs_done) *epochs_done = trk_epochs_done(k.h + n * sizeof(gm_trk_out), k.epochs, t->C);
+    *ready = 1;
     return GM_OK;
 }
 
@@ -1803,15 +1981,7 @@ int gm_trk_update_all(gm_trk* t, gm_ring* ring, uint32_t max_epochs, gm_trk_out*
     if (outs) memcpy(outs, h_outs, n * sizeof(gm_trk_out));
     if (processed) memcpy(processed, h_proc, n);
     if (lost) memcpy(lost, h_lost, n);
-    if (epochs_done) {
-        uint32_t done = 0;
-        for (uint32_t e = 0; e < max_epochs; ++e) {
-            bool any = false;
-            for (uint32_t c = 0; c < t->C; ++c) any |= proc[size_t(e) * t->C + c] != 0;
-            if (any) done = e + 1;
-        }
-        *epochs_done = done;
-    }
+    if (epochs_done) *epochs_done = trk_epochs_done(proc, max_epochs, t->C);
     return GM_OK;
 }
 
@@ -2124,20 +2294,26 @@ int gm_frontend_write_ring(gm_frontend* f, gm_ring* r, const void* samples, size
     if (n_samples > r->size) return set_err(GM_ERR_OUT_OF_RANGE, "write larger than the ring");
     if (int rc = ensure_device(r->device)) return rc;
     if (int rc = ring_async_init(r)) return rc;
+    if (!r->fe_stream) {
+        HIPC(hipStreamCreateWithFlags(&r->fe_stream, hipStreamNonBlocking));
+        for (int i = 0; i < gm_ring::SLOTS; ++i) HIPC(hipEventCreateWithFlags(&r->h2d_done[i], hipEventDisableTiming));
+    }
     const size_t bps = fmt == GM_FMT_C32 ? 8 : 2;
     const uint8_t* src = static_cast<const uint8_t*>(samples);
     while (n_samples) {
         const size_t chunk = n_samples < r->slot_samples ? n_samples : r->slot_samples;
         const int slot = int(r->slot_seq++ % gm_ring::SLOTS);
-        if (r->slot_used[slot]) HIPC(hipEventSynchronize(r->slot_done[slot]));
+        if (int rc = ring_reclaim_slot(r, slot)) return rc;
         if (!f->d_raw[slot]) HIPC(hipMalloc(&f->d_raw[slot], gm_ring::SLOT_SAMPLES_MAX * 8));
         memcpy(r->staging[slot], src, chunk * bps);
         HIPC(hipMemcpyAsync(f->d_raw[slot], r->staging[slot], chunk * bps, hipMemcpyHostToDevice, r->copy_stream));
-        if (int rc = frontend_launch(f, r->copy_stream, f->d_raw[slot], fmt, r->d_buf, r->write_pos, r->mask, chunk)) return rc;
-        HIPC(hipEventRecord(r->slot_done[slot], r->copy_stream));
+        HIPC(hipEventRecord(r->h2d_done[slot], r->copy_stream));
+        HIPC(hipStreamWaitEvent(r->fe_stream, r->h2d_done[slot], 0));
+        if (int rc = frontend_launch(f, r->fe_stream, f->d_raw[slot], fmt, r->d_buf, r->write_pos, r->mask, chunk)) return rc;
+        HIPC(hipEventRecord(r->slot_done[slot], r->fe_stream));
         r->slot_used[slot] = true;
         r->write_pos += chunk;
-        if (int rc = ring_enqueue_publish(r)) return rc;
+        if (int rc = ring_enqueue_publish(r, slot, r->fe_stream)) return rc;
         src += chunk * bps; n_samples -= chunk;
     }
     return GM_OK;

@@ -274,9 +274,9 @@ class TrackingManager {
 public:
     std::vector<TrackingChannel> channels;
     TrackingManager(float fs, uint32_t n_channels = 15, int code_index_mode = GM_CODE_INDEX_FAITHFUL, uint32_t n_arms = 3,
-                    bool strict_libm = false, bool strict_sum_order = false) : n_(n_channels) {
+                    bool strict_libm = false, bool strict_sum_order = false, bool share_device = false) : n_(n_channels) {
         gm_trk_cfg c{}; c.fs = fs; c.n_channels = n_channels; c.n_arms = n_arms; c.code_index_mode = code_index_mode;
-        c.strict_libm = strict_libm ? 1 : 0; c.strict_sum_order = strict_sum_order ? 1 : 0;
+        c.strict_libm = strict_libm ? 1 : 0; c.strict_sum_order = strict_sum_order ? 1 : 0; c.share_device = share_device ? 1 : 0;
         check(gm_trk_create(&c, &h_), "TrackingManager::new");
         for (uint32_t i = 0; i < n_channels; ++i) channels.push_back(TrackingChannel(h_, i));
     }

@@ -91,10 +91,11 @@ class TrackingManager:
 
     def __init__(self, fs, n_channels=NUM_OF_CHANNELS, n_arms=3, code_index_mode=CODE_INDEX_FAITHFUL,
                  early_late_space=0.5, very_early_late_space=1.0, boc11=False, codes=None, nominal_code_rate=0.0,
-                 device=None, strict_libm=False, strict_sum_order=False):
+                 device=None, strict_libm=False, strict_sum_order=False, share_device=False):
         _lib.init(device if device is not None else (_lib._initialised or 0))
         cfg = TrkCfg()
         cfg.strict_libm = int(strict_libm)     # the carrier's cos / sin as glibc's cosf / sinf, bit for bit (gm_trk_cfg.strict_libm)
+        cfg.share_device = int(share_device)          # a receiver: leave room for the other stages' kernels beside a tracking launch
         cfg.strict_sum_order = int(strict_sum_order)   # the sums in the reference's sample order (with strict_libm: bit-identical state)
         cfg.fs, cfg.n_channels, cfg.n_arms = fs, n_channels, n_arms
         cfg.early_late_space, cfg.very_early_late_space = early_late_space, very_early_late_space
@@ -129,6 +130,33 @@ class TrackingManager:
         done = C.c_uint32(0)
         check(lib().gm_trk_update_all(self._h, ring._h, E, C.cast(outs, C.c_void_p), _p(proc), _p(lost),
                                       C.byref(done)), "gm_trk_update_all")
+        o = np.frombuffer(outs, np.float32).reshape(E, Cn, 10)[:, :, :2 * self.n_arms].copy()
+        return o, proc, lost, done.value
+
+    def update_all_async(self, ring, max_epochs=1):
+        """update_all without a host wait: ordered on the device behind what the ring's writer has enqueued; -> ticket"""
+        tok = C.c_uint64(0)
+        check(lib().gm_trk_update_all_async(self._h, ring._h, int(max_epochs), C.byref(tok)), "gm_trk_update_all_async")
+        self._ticket_epochs = getattr(self, "_ticket_epochs", {})
+        self._ticket_epochs[tok.value] = int(max_epochs)
+        return tok.value
+
+    def collect(self, ticket, wait=False):
+        """-> None while the call is still running (wait = False), else update_all's (outs, processed, lost, epochs_done)"""
+        if ticket not in getattr(self, "_ticket_epochs", {}):      # let the library say so (GM_ERR_INVALID_ARG)
+            ready = C.c_int(0)
+            check(lib().gm_trk_collect(self._h, int(ticket), int(bool(wait)), None, None, None, None, C.byref(ready)), "gm_trk_collect")
+            raise KeyError(ticket)
+        E, Cn = self._ticket_epochs[ticket], self.n_channels
+        outs = (TrkOut * (E * Cn))()
+        proc = np.zeros((E, Cn), np.uint8)
+        lost = np.zeros((E, Cn), np.uint8)
+        done, ready = C.c_uint32(0), C.c_int(0)
+        check(lib().gm_trk_collect(self._h, int(ticket), int(bool(wait)), C.cast(outs, C.c_void_p), _p(proc), _p(lost), C.byref(done),
+                                   C.byref(ready)), "gm_trk_collect")
+        if not ready.value:
+            return None
+        del self._ticket_epochs[ticket]
         o = np.frombuffer(outs, np.float32).reshape(E, Cn, 10)[:, :, :2 * self.n_arms].copy()
         return o, proc, lost, done.value
 

@@ -387,6 +387,13 @@ typedef struct {
                                   strict_libm as well, every correlator sum and every word of the channel state equal the
                                   reference's bit for bit, free-running.  0 (default): tree sums, within 1e-5 of the
                                   envelope and closer to the exact sum.  ABI version 4. */
+    int32_t share_device;      /* 1: a receiver — the persistent tracking kernel takes at most a QUARTER of the device's resident
+                                  workgroup places (workgroups per channel chosen accordingly), so that the other stages' kernels
+                                  (the digital front-end writing the ring needs a whole CU per stream, an acquisition dwell every
+                                  CU it can get) run BESIDE a tracking launch instead of queueing behind its all-resident grid.
+                                  0 (default): every place, the fastest epoch (a tracking-only load).  The split of a code period
+                                  over a channel's workgroups follows the count: sums differ in the last bits between the two
+                                  settings, inside the default mode's tolerance.  ABI version 6. */
 } gm_trk_cfg;
 
 typedef struct gm_trk gm_trk;
@@ -423,6 +430,19 @@ int gm_trk_update_all(gm_trk *t, gm_ring *ring, uint32_t max_epochs, gm_trk_out 
                       uint8_t *lost, uint32_t *epochs_done);
 /* Asynchronous device-resident form for benchmarking: enqueues `epochs` passes, no host readback. */
 int gm_trk_update_all_dev(gm_trk *t, gm_ring *ring, uint32_t epochs);
+/* gm_trk_update_all without a host wait per block (ABI 6) — for a receiver loop that feeds block after block.  The reference's
+ * tracking thread sleeps on the ring's Condvar until the head has passed what it needs (do_tracking.rs:392-406); here that wait
+ * happens ON THE DEVICE: the passes are ordered behind everything the ring's asynchronous writer (gm_ring_write_samples_async /
+ * gm_frontend_write_ring) has ENQUEUED so far, by an event on the ring's copy stream, and their data gate uses that enqueued
+ * head — the host neither waits for the samples to land nor for the passes to run.  Results ([outs | processed | lost] as in
+ * gm_trk_update_all) land in one of 8 pinned slots; *ticket (never 0) names the call.
+ * gm_trk_collect(ticket, wait, ...): wait = 0 -> *ready = 0 and nothing else when the call has not finished; otherwise the results
+ * are handed over (any of outs / processed / lost / epochs_done may be NULL), *ready = 1 and the slot is free again.  Tickets are
+ * collected in any order; with 8 uncollected tickets gm_trk_update_all_async returns GM_ERR_OUT_OF_RANGE and launches nothing.
+ * Same channel states and sums as the synchronous entry, bit for bit (tests/test_gpu_pipeline.py). */
+int gm_trk_update_all_async(gm_trk *t, gm_ring *ring, uint32_t max_epochs, uint64_t *ticket);
+int gm_trk_collect(gm_trk *t, uint64_t ticket, int wait, gm_trk_out *outs, uint8_t *processed, uint8_t *lost,
+                   uint32_t *epochs_done, int *ready);
 int gm_trk_synchronize(gm_trk *t);
 /* The handle's own stream is created at the device's HIGHEST priority: the tracking loop is the receiver's latency path (one short
  * launch per block of samples) and must not queue behind a front-end block or an acquisition dwell in flight on another stream.

@@ -67,6 +67,7 @@ pub struct GmTrkCfg {               // gm_trk_cfg (zero = reference default)
     pub max_lost_epochs: u32,
     pub strict_libm: i32,           // 1 = the carrier's cos / sin are glibc's cosf / sinf restated on the device (bit-identical products)
     pub strict_sum_order: i32,      // 1 = the correlator sums added sample by sample like do_tracking.rs:256-262 (with strict_libm: bit-identical state)
+    pub share_device: i32,          // 1 = a receiver: the tracking kernel leaves room for the front-end's and the acquisition's kernels beside it (ABI 6)
 }
 pub enum GmAcq {} pub enum GmTrk {} pub enum GmRing {} pub enum GmComm {}
 
@@ -106,6 +107,10 @@ extern "C" {
                           lost: *mut u8, lost_prn: *mut u8) -> c_int;
     pub fn gm_trk_update_all(t: *mut GmTrk, ring: *mut GmRing, max_epochs: u32, outs: *mut GmTrkOut,
                              processed: *mut u8, lost: *mut u8, epochs_done: *mut u32) -> c_int;
+    /// the same passes ordered on the DEVICE behind what the ring's writer has enqueued (the Condvar wait of :392-406 without a host wait)
+    pub fn gm_trk_update_all_async(t: *mut GmTrk, ring: *mut GmRing, max_epochs: u32, ticket: *mut u64) -> c_int;
+    pub fn gm_trk_collect(t: *mut GmTrk, ticket: u64, wait: c_int, outs: *mut GmTrkOut, processed: *mut u8, lost: *mut u8,
+                          epochs_done: *mut u32, ready: *mut c_int) -> c_int;
     // fft.rs:5-56
     pub fn gm_fft_c2c_f32(n: usize, dir: c_int, inout: *mut Complex32, batch: usize) -> c_int;
     pub fn gm_fft_power_spectrum_f32(n: usize, inout: *mut Complex32, power: *mut f32) -> c_int;

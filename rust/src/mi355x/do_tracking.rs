@@ -36,7 +36,7 @@ fn trk_cfg(fs: f32, n_channels: u32) -> GmTrkCfg {  // zero = the reference's co
     GmTrkCfg { fs, n_channels, n_arms: 3, early_late_space: 0.5, very_early_late_space: 0.0, code_index_mode: CODE_INDEX_FAITHFUL,
                boc11: 0, codes: std::ptr::null(), n_codes: 0, code_len: 0, nominal_code_rate: 0.0, pll_bw: 0.0, pll_zeta: 0.0,
                pll_gain: 0.0, dll_bw: 0.0, dll_zeta: 0.0, dll_gain: 0.0, pll_dt: 0.0, dll_dt: 0.0, lock_threshold: 0.0,
-               max_lost_epochs: 0, strict_libm: 0, strict_sum_order: 0 }
+               max_lost_epochs: 0, strict_libm: 0, strict_sum_order: 0, share_device: 1 }
 }
 fn to_raw(r: &AcquisitionResult) -> GmAcqResult {
     GmAcqResult { prn: r.prn, code_phase_samples: r.code_phase_samples as u64, code_phase_chips: r.code_phase_chips,

@@ -182,3 +182,77 @@ def test_decision_over_more_than_64_doppler_bins(gpu, oracle):
                 trips.add(got["doppler_bin"] // 64)
         assert res[3] is None and trips == {0, 1, 2}, (mode, trips)
         eng.close()
+
+
+def test_tracking_async_tickets_equal_the_per_block_path(gpu, oracle):
+    """gm_trk_update_all_async + gm_trk_collect: a feeder writes block after block through the ring's
+    asynchronous writer and enqueues the tracking passes behind each block WITHOUT waiting — ordered on the device by the ring's
+    enqueue event, data gate on the enqueued head — and drains the tickets when they are ready.  Channel states and every
+    correlator sum equal the synchronous per-block path (write, flush, gm_trk_update_all), bit for bit; ticket misuse is refused."""
+    from gnss_sdr_rs_amd import tracking as T, synth, _lib
+    t = oracle.ca_code_table()
+    fs, N, n_ms, BLK = 4_096_000.0, 4096, 96, 6 * 4096 + 1000       # blocks that do NOT end on code-period boundaries
+    truth = {4: (-1730.0, 1111), 11: (640.0, 4000), 23: (2210.0, 77)}
+    sats = [dict(prn=p, prn_row=p - 1, cn0_dbhz=49.0, doppler_hz=d, code_start=c, phase=0.1 * p) for p, (d, c) in truth.items()]
+    x = synth.to_c32(synth.make_scene(t, fs, 0.0, n_ms * N, sats, config_id=62))
+    starts = [dict(prn=p, code_phase_samples=c, code_phase_chips=0.0, carrier_freq=d + 20.0, fs=fs, mag_relative=1.0,
+                   sample_global_index=c, doppler_bin=0) for p, (d, c) in sorted(truth.items())]
+    E = BLK // N + 3
+
+    def run(asynchronous):
+        ring = T.MulticastRingBuffer(1 << 19)
+        mgr = T.TrackingManager(fs, n_channels=5, code_index_mode=T.CODE_INDEX_FIXED)
+        for i, r in enumerate(starts):
+            mgr.channels[i].start(r)
+        got = [[] for _ in starts]
+
+        def take(res):
+            outs, proc, lost, done = res
+            assert not lost.any()
+            for i in range(len(starts)):
+                got[i].append(outs[proc[:, i] != 0, i, :])
+        tickets = []
+        for off in range(0, x.size, BLK):
+            ring.write_samples_async(x[off:off + BLK])
+            if asynchronous:
+                tickets.append(mgr.update_all_async(ring, E))
+                while tickets:
+                    res = mgr.collect(tickets[0], wait=len(tickets) >= 7)
+                    if res is None:
+                        break
+                    tickets.pop(0); take(res)
+            else:
+                ring.flush()
+                take(mgr.update_all(ring, E))
+        ring.flush()
+        if asynchronous:
+            tickets.append(mgr.update_all_async(ring, E))
+            for tk in tickets:
+                take(mgr.collect(tk, wait=True))
+            with pytest.raises(_lib.GmError):                # collected already
+                mgr.collect(tickets[-1], wait=True)
+        else:
+            take(mgr.update_all(ring, E))
+        states = [bytes(mgr.channels[i].state) for i in range(len(starts))]
+        sums = [np.concatenate(g, axis=0) for g in got]
+        mgr.close(); ring.close()
+        return states, sums
+    s_sync, o_sync = run(False)
+    s_async, o_async = run(True)
+    for i, r in enumerate(starts):
+        assert o_sync[i].shape[0] == (n_ms * N - r["sample_global_index"]) // N      # every whole code period
+        assert o_async[i].shape == o_sync[i].shape
+        assert (o_async[i].view(np.uint32) == o_sync[i].view(np.uint32)).all(), i
+        assert s_async[i] == s_sync[i], i
+    # nine calls without a collect: the ninth is refused (eight result slots), nothing is launched for it
+    ring = T.MulticastRingBuffer(1 << 16)
+    mgr = T.TrackingManager(fs, n_channels=2, code_index_mode=T.CODE_INDEX_FIXED)
+    ring.write_samples_async(x[:8 * N])
+    tks = [mgr.update_all_async(ring, 2) for _ in range(8)]
+    assert len(set(tks)) == 8 and 0 not in tks
+    with pytest.raises(_lib.GmError) as e:
+        mgr.update_all_async(ring, 2)
+    assert e.value.status == -5                              # GM_ERR_OUT_OF_RANGE
+    for tk in reversed(tks):                                 # any order
+        assert mgr.collect(tk, wait=True) is not None
+    mgr.close(); ring.close()
