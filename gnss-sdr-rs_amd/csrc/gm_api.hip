@@ -1366,7 +1366,7 @@ int gm_ring_destroy(gm_ring* r) {
     if (!r) return GM_OK;
     hipSetDevice(r->device);
     if (r->copy_stream) { hipStreamSynchronize(r->copy_stream); hipStreamDestroy(r->copy_stream); }
-    if (r->fe_stream) { hipStreamSynchronize(r->fe_stream); hipStreamDestroy(r->fe_stream); }
+    if (r->fe_stream && r->fe_stream != r->copy_stream) { hipStreamSynchronize(r->fe_stream); hipStreamDestroy(r->fe_stream); }
     for (hipEvent_t e : r->h2d_done) if (e) hipEventDestroy(e);
     if (r->ev_enq) hipEventDestroy(r->ev_enq);
     for (int i = 0; i < gm_ring::SLOTS; ++i) {
@@ -1499,8 +1499,11 @@ struct gm_trk {
     uint8_t* d_ready = nullptr;
     cf* d_scratch = nullptr; size_t scratch_cap = 0;
     float* d_terms = nullptr; size_t terms_cap = 0;   // strict_sum_order: [C][2 * arms][terms_cap] per-sample products of one epoch
+    // results of a call of e passes, n = e * C entries: ONE device block laid out for that n as [outs n | processed n | lost n |
+    // lost_prn n] (trk_reserve_epochs), so that outs + processed + lost leave in ONE device-to-host copy; d_outs .. d_lostprn point into it
+    uint8_t* d_res = nullptr; size_t res_cap = 0, res_n = 0;
     gm_trk_out* d_outs = nullptr; uint8_t *d_proc = nullptr, *d_lost = nullptr, *d_lostprn = nullptr;
-    uint8_t* h_res = nullptr;                      // pinned landing area of gm_trk_update_all: [outs | processed | lost] of epochs_cap epochs
+    uint8_t* h_res = nullptr; size_t h_cap = 0;    // pinned landing area of gm_trk_update_all: [outs | processed | lost] of the call's passes
     uint32_t epochs_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false; uint32_t timed_launches = 0;
@@ -1533,19 +1536,31 @@ static int trk_reserve_terms(gm_trk* t, size_t samples) {
     return GM_OK;
 }
 static int trk_reserve_epochs(gm_trk* t, uint32_t e) {
-    if (e <= t->epochs_cap) return GM_OK;
-    HIPC(hipStreamSynchronize(t->stream));      // nothing in flight still writes the buffers about to be replaced
-    hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
-    t->d_outs = nullptr; t->d_proc = t->d_lost = t->d_lostprn = nullptr; t->epochs_cap = 0;
-    const size_t n = size_t(e) * t->C;
-    HIPC(hipMalloc(&t->d_outs, n * sizeof(gm_trk_out)));
-    // with three arms the persistent kernel writes the six live sums only: ive..qvl stay 0.  Ordered on the handle's stream
-    // (a non-blocking stream does not synchronise with the NULL stream a plain hipMemset runs on)
-    HIPC(hipMemsetAsync(t->d_outs, 0, n * sizeof(gm_trk_out), t->stream));
-    HIPC(hipMalloc(&t->d_proc, n)); HIPC(hipMalloc(&t->d_lost, n)); HIPC(hipMalloc(&t->d_lostprn, n));
-    if (t->h_res) { hipHostFree(t->h_res); t->h_res = nullptr; }
-    HIPC(hipHostMalloc(reinterpret_cast<void**>(&t->h_res), n * (sizeof(gm_trk_out) + 2), hipHostMallocDefault));
-    t->epochs_cap = e;
+    const size_t n = size_t(e) * t->C, bytes = (n * (sizeof(gm_trk_out) + 3) + 3) & ~size_t(3);
+    if (bytes > t->res_cap) {
+        HIPC(hipStreamSynchronize(t->stream));      // nothing in flight still writes the block about to be replaced
+        hipFree(t->d_res); t->d_res = nullptr; t->res_cap = 0; t->res_n = 0;
+        HIPC(hipMalloc(&t->d_res, bytes));
+        t->res_cap = bytes;
+    }
+    if (n * (sizeof(gm_trk_out) + 2) > t->h_cap) {
+        HIPC(hipStreamSynchronize(t->stream));
+        if (t->h_res) { hipHostFree(t->h_res); t->h_res = nullptr; t->h_cap = 0; }
+        HIPC(hipHostMalloc(reinterpret_cast<void**>(&t->h_res), n * (sizeof(gm_trk_out) + 2), hipHostMallocDefault));
+        t->h_cap = n * (sizeof(gm_trk_out) + 2);
+    }
+    if (n != t->res_n) {
+        // a new layout: with three arms the persistent kernel writes the six live sums only, ive..qvl must read 0 — and bytes that were
+        // flags under the previous layout may now lie inside `outs`.  Ordered on the handle's stream (a non-blocking stream does not
+        // synchronise with the NULL stream a plain hipMemset runs on).  A loop that keeps its pass count pays this once.
+        HIPC(hipMemsetAsync(t->d_res, 0, bytes, t->stream));
+        t->res_n = n;
+    }
+    t->d_outs = reinterpret_cast<gm_trk_out*>(t->d_res);
+    t->d_proc = t->d_res + n * sizeof(gm_trk_out);
+    t->d_lost = t->d_proc + n;
+    t->d_lostprn = t->d_lost + n;
+    if (e > t->epochs_cap) t->epochs_cap = e;
     return GM_OK;
 }
 
@@ -1564,7 +1579,7 @@ int gm_trk_destroy(gm_trk* t) {
     if (!t) return GM_OK;
     if (t->device >= 0) hipSetDevice(t->device);
     hipFree(t->d_codes); hipFree(t->d_states); hipFree(t->d_partials); hipFree(t->d_ready); hipFree(t->d_scratch); hipFree(t->d_terms);
-    hipFree(t->d_outs); hipFree(t->d_proc); hipFree(t->d_lost); hipFree(t->d_lostprn);
+    hipFree(t->d_res);
     if (t->h_res) hipHostFree(t->h_res);
     for (auto& k : t->tk) if (k.done) hipEventDestroy(k.done);
     if (t->tk_block) hipHostFree(t->tk_block);
@@ -1784,6 +1799,7 @@ static int trk_unit(gm_trk* t, uint32_t ch, const gm_c32* samples, size_t n, int
         t->scratch_cap = need * 2;
     }
     if (int rc = trk_reserve_terms(t, need)) return rc;
+    if (int rc = trk_reserve_epochs(t, 1)) return rc;          // the result block laid out for one pass
     HIPC(hipMemcpyAsync(t->d_scratch, samples, need * 8, hipMemcpyHostToDevice, t->stream));
     // the unit entries run regardless of ChannelState (the reference's early_late_correlation/do_work do not test it)
     const uint8_t was_active = s.active;
@@ -1921,7 +1937,12 @@ int gm_trk_update_all_async(gm_trk* t, gm_ring* ring, uint32_t max_epochs, uint6
     if (int rc = ensure_device(t->device)) return rc;
     const size_t n = size_t(max_epochs) * t->C, bytes = n * (sizeof(gm_trk_out) + 2);
     if (int rc = trk_reserve_tickets(t, bytes)) return rc;
+    static const int trace_slow = gm::diag_int("GM_TRK_TRACE_SLOW", 0);      // diagnostic: which runtime call of this entry takes milliseconds
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    const auto t0 = now();
     ring_refresh_head(ring);
+    const auto t1 = now();
     uint64_t head = ring->head.load(std::memory_order_acquire);
     {
         std::lock_guard<std::mutex> g(ring->enq_mu);
@@ -1930,11 +1951,15 @@ int gm_trk_update_all_async(gm_trk* t, gm_ring* ring, uint32_t max_epochs, uint6
             if (int64_t(ring->enqueued - head) > 0) head = ring->enqueued;
         }
     }
+    const auto t2 = now();
     if (int rc = trk_launch_all(t, ring, max_epochs, head)) return rc;
-    HIPC(hipMemcpyAsync(k.h, t->d_outs, n * sizeof(gm_trk_out), hipMemcpyDeviceToHost, t->stream));
-    HIPC(hipMemcpyAsync(k.h + n * sizeof(gm_trk_out), t->d_proc, n, hipMemcpyDeviceToHost, t->stream));
-    HIPC(hipMemcpyAsync(k.h + n * sizeof(gm_trk_out) + n, t->d_lost, n, hipMemcpyDeviceToHost, t->stream));
+    const auto t3 = now();
+    gm::launch_trk_results_to_host(t->stream, t->d_res, k.h, bytes);      // [outs | processed | lost] -> the pinned slot (trk_kernels.hip)
+    const auto t4 = now();
     HIPC(hipEventRecord(k.done, t->stream));
+    const auto t5 = now();
+    if (trace_slow && us(t0, t5) > 1000)
+        fprintf(stderr, "gm_trk_update_all_async slow: refresh %ld us, wait-event %ld, launch %ld, copy %ld, record %ld\n", us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, t5));
     k.in_flight = true; k.epochs = max_epochs; k.id = *ticket = t->next_ticket++;
     return GM_OK;
 }
@@ -1972,9 +1997,8 @@ int gm_trk_update_all(gm_trk* t, gm_ring* ring, uint32_t max_epochs, gm_trk_out*
     uint8_t* h_outs = t->h_res;
     uint8_t* h_proc = h_outs + n * sizeof(gm_trk_out);
     uint8_t* h_lost = h_proc + n;
-    HIPC(hipMemcpyAsync(h_proc, t->d_proc, n, hipMemcpyDeviceToHost, t->stream));
-    if (outs) HIPC(hipMemcpyAsync(h_outs, t->d_outs, n * sizeof(gm_trk_out), hipMemcpyDeviceToHost, t->stream));
-    if (lost) HIPC(hipMemcpyAsync(h_lost, t->d_lost, n, hipMemcpyDeviceToHost, t->stream));
+    if (outs) HIPC(hipMemcpyAsync(h_outs, t->d_res, n * (sizeof(gm_trk_out) + 2), hipMemcpyDeviceToHost, t->stream));      // [outs | processed | lost]: one copy
+    else HIPC(hipMemcpyAsync(h_proc, t->d_proc, 2 * n, hipMemcpyDeviceToHost, t->stream));
     HIPC(hipStreamSynchronize(t->stream));
     if (int rc = trk_check_error(t)) return rc;
     const uint8_t* proc = h_proc;
@@ -2295,7 +2319,8 @@ int gm_frontend_write_ring(gm_frontend* f, gm_ring* r, const void* samples, size
     if (int rc = ensure_device(r->device)) return rc;
     if (int rc = ring_async_init(r)) return rc;
     if (!r->fe_stream) {
-        HIPC(hipStreamCreateWithFlags(&r->fe_stream, hipStreamNonBlocking));
+        if (gm::diag_int("GM_RING_FE_STREAM", 1) == 0) r->fe_stream = r->copy_stream;      // diagnostic: kernels on the copy stream (round 4's form)
+        else HIPC(hipStreamCreateWithFlags(&r->fe_stream, hipStreamNonBlocking));
         for (int i = 0; i < gm_ring::SLOTS; ++i) HIPC(hipEventCreateWithFlags(&r->h2d_done[i], hipEventDisableTiming));
     }
     const size_t bps = fmt == GM_FMT_C32 ? 8 : 2;

@@ -1434,4 +1434,20 @@ void launch_trk_epoch(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_code
     }
 }
 
+// Results of a tracking call (a few KB) from the device block to PINNED HOST memory by a kernel of the library's own: gfx950 stores to
+// host-mapped memory straight over the fabric, one launch, a fixed cost.  (The runtime's hipMemcpyAsync of the same bytes stalled the
+// calling thread ~7 ms five times in a 100-block receiver loop on the ROCm 7.0 runtime a PyTorch process brings along —
+// tools/receiver_time.py GM_TRK_TRACE_SLOW — and took three submissions where this takes one.)
+__global__ __launch_bounds__(256) void trk_results_to_host_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t words) {
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < words; i += size_t(gridDim.x) * 256)
+        __builtin_nontemporal_store(src[i], dst + i);
+}
+void launch_trk_results_to_host(hipStream_t st, const void* d_src, void* h_dst_pinned, size_t bytes) {
+    const size_t words = (bytes + 3) / 4;                      // (both blocks are allocated in multiples of 4 bytes)
+    if (!words) return;
+    const int blocks = int((words + 255) / 256 < 64 ? (words + 255) / 256 : 64);
+    hipLaunchKernelGGL(trk_results_to_host_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint32_t*>(d_src),
+                       static_cast<uint32_t*>(h_dst_pinned), words);
+}
+
 }  // namespace gm
