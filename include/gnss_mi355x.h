@@ -303,7 +303,10 @@ int gm_ring_write_samples(gm_ring *r, const gm_c32 *samples, size_t n);  /* :66-
 int gm_ring_get_head(gm_ring *r, uint64_t *head);                        /* :103-105 */
 int gm_ring_copy_to_slice(gm_ring *r, uint64_t start, gm_c32 *dest, size_t n); /* :107-129 */
 /* write_samples that does not block the producer on the H2D copy: pinned staging + the ring's own copy stream; `head`
- * advances (and the Condvar fires) only after the samples have landed in HBM.  gm_ring_flush waits for all of it. */
+ * advances only after the samples have landed in HBM.  gm_ring_flush waits for all of it.  The head is published by PULL
+ * (ABI 6): gm_ring_get_head, gm_ring_wait_head and every stage entry that snapshots the ring first retire the blocks whose copies
+ * (and front-end kernels) have completed; nothing runs on the copy stream but copies and kernels (a host callback there — round 4 —
+ * held the stream, i.e. the next block, until the runtime's callback thread woke up: milliseconds, now and then). */
 int gm_ring_write_samples_async(gm_ring *r, const gm_c32 *samples, size_t n);
 int gm_ring_flush(gm_ring *r);
 /* The notifier/Condvar of the reference ring (:42-43, :94-98) as used by do_tracking::run (do_tracking.rs:392-406):
@@ -335,7 +338,8 @@ int gm_frontend_process_dev_batch(gm_frontend *const *fes, uint32_t n_streams, c
 int gm_frontend_synchronize(gm_frontend *f);
 /* rf_thread's block step (src/rf/rf_thread.rs:43-48: process_block, then shared_ring_buffer.write_samples) fused and
  * non-blocking: host samples (c32, or int8 IQ: 2 B/sample over PCIe, converted on the GPU) -> pinned staging -> front-end
- * kernel writing straight into the ring mirror; head advances when the block is in HBM (gm_ring_flush to wait). */
+ * kernel writing straight into the ring mirror; head advances when the block is in HBM (gm_ring_flush to wait).  Blocks of up
+ * to 2^19 samples per copy + launch; the kernels run on a stream of the ring's own behind the copies (an event per staging slot). */
 int gm_frontend_write_ring(gm_frontend *f, gm_ring *ring, const void *samples, size_t n_samples, int fmt);
 
 /* ------------------------------------------------------------------ Tracking
