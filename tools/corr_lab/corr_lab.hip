@@ -1,8 +1,10 @@
-// tools/corr_lab/corr_lab.hip — timing laboratory for acq_corr_kernel at BASELINE configs[1] geometry (32 workers x 41
-// bins x N = 8000 x 10 integrations) on random data: the product kernel source is included as is, restricted to one plan,
-// optionally with ONE ablation macro defined on the command line (-DGM_LAB_NOLOAD, -DGM_LAB_NOCODE,
-// -DGM_XFORM_SYNC\(\)=) so that the cost of loads / barriers can be read off as time differences.  Timing only: an ablated
-// build computes garbage.  Not product code, not a test.
+// tools/corr_lab/corr_lab.hip — timing laboratory for stage C at BASELINE configs[1] geometry (32 workers x 41 bins x N = 8000 x 10
+// integrations; arguments: workers, bins, integrations) on random data: the PRODUCT kernel source is included as is, restricted to one
+// plan (-DLAB_PLAN=...), so that a variant (a macro on the command line, an older source through -DLAB_SRC, a lab header such as
+// mfma16_8000/ or wsh_8000/) can be timed beside the shipped kernel on one box.  The timing-ablation macros of rounds 2-3 (no loads,
+// no barriers, no twiddles) are no longer in the product sources: their results are in profiles/r03_lab_ablations.txt, and they can be
+// repeated with -DLAB_SRC pointing at commit 5af55ed's kernels (tools/README.md).  Prints the median / minimum launch time and a
+// checksum of the maxima (equal checksums = same results to seven digits).  Not product code, not a test.
 #ifndef LAB_PLAN
 #define LAB_PLAN gm::Plan8000
 #endif
