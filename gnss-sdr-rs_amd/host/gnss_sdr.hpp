@@ -8,6 +8,7 @@
 #include <complex>
 #include <deque>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <cstdint>
@@ -294,6 +295,33 @@ public:
                                 lost ? lost->data() : nullptr, &done), "process_channels");
         return done;
     }
+    // the same passes WITHOUT a host wait (ABI 6): ordered on the device behind everything the ring's asynchronous writer has enqueued
+    // (the Condvar wait of do_tracking.rs:392-406 as an event on the ring's stream); the results are collected later, by ticket
+    uint64_t process_channels_async(MulticastRingBuffer& ring, uint32_t max_epochs) {
+        uint64_t ticket = 0;
+        check(gm_trk_update_all_async(h_, ring.handle(), max_epochs, &ticket), "process_channels_async");
+        pending_[ticket] = max_epochs;
+        return ticket;
+    }
+    // false while the call is still running (wait = false); else the passes in which a channel ran through *done
+    bool collect(uint64_t ticket, bool wait, uint32_t* done = nullptr, std::vector<CorrelatorOut>* outs = nullptr,
+                 std::vector<uint8_t>* processed = nullptr, std::vector<uint8_t>* lost = nullptr) {
+        const auto it = pending_.find(ticket);
+        if (it == pending_.end()) throw Panic(GM_ERR_INVALID_ARG, "collect: no such ticket");
+        const size_t n = size_t(it->second) * n_;
+        if (outs) outs->resize(n);
+        if (processed) processed->resize(n);
+        if (lost) lost->resize(n);
+        int ready = 0; uint32_t d = 0;
+        check(gm_trk_collect(h_, ticket, wait ? 1 : 0, outs ? outs->data() : nullptr, processed ? processed->data() : nullptr,
+                             lost ? lost->data() : nullptr, &d, &ready), "collect");
+        if (!ready) return false;
+        pending_.erase(it);
+        if (done) *done = d;
+        return true;
+    }
+private:
+    std::map<uint64_t, uint32_t> pending_;      // ticket -> its pass count
 };
 
 // ---- the two stage drivers: do_acquisition::run (do_acquisition.rs:241-327) and

@@ -97,6 +97,27 @@ static int test_pll_frequency_pull_in() {
     s = mgr.channels[0].state();
     CHECK(s.next_sample_index == before + 2 * 4096);
     CHECK(std::fabs(s.carrier_freq - true_doppler) < 50.0f);
+    // the asynchronous form (ABI 6): the same passes by ticket — an identical second manager fed the same way ends in the same state
+    {
+        MulticastRingBuffer buf2(32768);
+        TrackingManager m2(f_sampling, 1, GM_CODE_INDEX_FIXED);
+        m2.channels[0].start(r);
+        buf2.write_samples(std::vector<Complex32>(signal.begin(), signal.begin() + 4096));
+        const uint64_t t1 = m2.process_channels_async(buf2, 1);
+        buf2.write_samples(std::vector<Complex32>(signal.begin() + 4096, signal.begin() + 3 * 4096));
+        const uint64_t t2 = m2.process_channels_async(buf2, 4);
+        CHECK(t1 != 0 && t2 != 0 && t1 != t2);
+        uint32_t d1 = 0, d2 = 0;
+        std::vector<uint8_t> proc;
+        CHECK(m2.collect(t2, true, &d2, nullptr, &proc));        // any order
+        CHECK(m2.collect(t1, true, &d1));
+        CHECK(d1 == 1 && d2 == 2 && proc.size() == 4 && proc[0] == 1 && proc[1] == 1 && proc[2] == 0);
+        const auto s2 = m2.channels[0].state();
+        CHECK(s2.next_sample_index == s.next_sample_index && s2.carrier_freq == s.carrier_freq && s2.code_rate == s.code_rate);
+        bool threw = false;
+        try { m2.collect(t1, true); } catch (const Panic&) { threw = true; }
+        CHECK(threw);
+    }
     return 0;
 }
 
