@@ -68,6 +68,11 @@ def test_null_handles_are_refused_not_dereferenced(gm):
     assert L.gm_acq_prepare_dev(None, C.c_void_p(16), 0, None, C.byref(C.c_uint64(0))) == -1
     assert L.gm_acq_search_prepared_dev(None, 1, None) == -1 and L.gm_acq_drop_prepared(None) == -1
     assert L.gm_acq_synchronize(None) == -1
+    # the asynchronous tracking entries (ABI 6): null handle / ring / ticket pointer, ticket 0, null `ready`
+    tok, ready = C.c_uint64(7), C.c_int(5)
+    assert L.gm_trk_update_all_async(None, None, 4, C.byref(tok)) == -1 and tok.value == 7
+    assert L.gm_trk_collect(None, 1, 1, None, None, None, None, C.byref(ready)) == -1 and ready.value == 5
+    assert b"bad argument" in L.gm_last_error()
 
 
 def test_ca_table_and_resampler_host(gm, oracle):
