@@ -442,7 +442,8 @@ int gm_trk_update_all_dev(gm_trk *t, gm_ring *ring, uint32_t epochs);
  * gm_trk_update_all) land in one of 8 pinned slots; *ticket (never 0) names the call.
  * gm_trk_collect(ticket, wait, ...): wait = 0 -> *ready = 0 and nothing else when the call has not finished; otherwise the results
  * are handed over (any of outs / processed / lost / epochs_done may be NULL), *ready = 1 and the slot is free again.  Tickets are
- * collected in any order; with 8 uncollected tickets gm_trk_update_all_async returns GM_ERR_OUT_OF_RANGE and launches nothing.
+ * collected in any order; a call is refused (GM_ERR_OUT_OF_RANGE, nothing launched) while the ticket issued eight calls earlier —
+ * whose slot it would take — has not been collected.
  * Same channel states and sums as the synchronous entry, bit for bit (tests/test_gpu_pipeline.py). */
 int gm_trk_update_all_async(gm_trk *t, gm_ring *ring, uint32_t max_epochs, uint64_t *ticket);
 int gm_trk_collect(gm_trk *t, uint64_t ticket, int wait, gm_trk_out *outs, uint8_t *processed, uint8_t *lost,
