@@ -256,3 +256,54 @@ def test_tracking_async_tickets_equal_the_per_block_path(gpu, oracle):
     for tk in reversed(tks):                                 # any order
         assert mgr.collect(tk, wait=True) is not None
     mgr.close(); ring.close()
+
+
+def test_ring_head_by_pull_with_concurrent_readers(gpu):
+    """The asynchronous writer's head is published by PULL (ABI 6: no host callback on the copy stream): whoever looks retires the
+    blocks whose copies have completed.  A writer thread and two reader threads on one ring — the single-writer / many-readers
+    use of the reference ring (multicast_ring_buffer.rs:36-130) — : every head a reader sees is monotonic, never ahead of what the
+    writer has enqueued, and the samples below it HAVE landed (copy_to_slice returns exactly what was written); wait_head returns
+    at the head it was asked for (the Condvar wait of do_tracking.rs:392-406), and times out when nothing comes."""
+    import threading
+    from gnss_sdr_rs_amd import tracking as T
+    rng = np.random.default_rng(5)
+    BLK, NB = 3000, 160                                           # blocks that do not divide the ring or the staging slots
+    x = (rng.standard_normal(BLK * NB) + 1j * rng.standard_normal(BLK * NB)).astype(np.complex64)
+    ring = T.MulticastRingBuffer(1 << 20)
+    written = [0]
+    errors = []
+
+    def writer():
+        try:
+            for b in range(NB):
+                ring.write_samples_async(x[b * BLK:(b + 1) * BLK])
+                written[0] = (b + 1) * BLK
+            ring.flush()
+        except Exception as e:                                    # pragma: no cover
+            errors.append(repr(e))
+
+    def reader(step):
+        try:
+            last, want = 0, step
+            while last < BLK * NB:
+                assert ring.wait_head(want, 5000), ("timed out waiting for", want)
+                h = ring.get_head()
+                assert h >= want and h >= last, (h, want, last)
+                # (the writer's counter is bumped after its call returns: the head may run at most one call ahead of it)
+                assert h <= written[0] + BLK, (h, written[0])
+                lo = max(last, h - 4096)
+                got = ring.copy_to_slice(lo, h - lo)
+                assert (got.view(np.uint32) == x[lo:h].view(np.uint32)).all(), (lo, h)
+                last = h
+                want = min(h + step, BLK * NB)
+        except Exception as e:
+            errors.append(repr(e))
+    th = [threading.Thread(target=writer), threading.Thread(target=reader, args=(7001,)), threading.Thread(target=reader, args=(20011,))]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(120)
+    assert not errors, errors
+    assert ring.get_head() == BLK * NB
+    assert not ring.wait_head(BLK * NB + 1, 20)                   # nothing more is coming: the wait times out
+    ring.close()
