@@ -183,6 +183,39 @@ def test_channel_count_sweep_covers_every_G(gpu, oracle, C):
     mgr.close(); ring.close()
 
 
+@pytest.mark.parametrize("C", [1, 8, 15, 32, 100])
+def test_share_device_grid_same_parity(gpu, oracle, C):
+    """gm_trk_cfg.share_device (ABI 6: a receiver's setting — a quarter of the device's resident places, so that the front-end's and
+    the acquisition's kernels run beside a tracking launch): other workgroups-per-channel counts than the default for the same C
+    (8 instead of 32 at 15 channels), same parity bars — teacher-forced sums within 1e-5 of the oracle's and 5e-7 of an f64
+    accumulation, loop state 0 ulps — and the asynchronous entry gives the same words as the synchronous one on this grid too."""
+    from gnss_sdr_rs_amd import tracking as T, synth
+    fs, n, E = 8.0e6, 8000, 11
+    t = oracle.ca_code_table()
+    prns = [2, 5, 9, 13, 17, 22, 26, 30]
+    sc = synth.tracking_scene(t, fs, 0.0, prns, E + 2, config_id=63, cn0=50.0)
+    x = synth.to_c32(sc["x"])
+    ring, oring = T.MulticastRingBuffer(1 << 17), oracle.MulticastRingBuffer(1 << 17)
+    ring.write_samples(x[:(E + 1) * n])
+    oring.write_samples(x[:(E + 1) * n])
+    starts = []
+    for i in range(C):
+        s = sc["sats"][i % 8]
+        starts.append(_acq_result(s["prn"], s["doppler_hz"] + 25.0 - 0.17 * (i // 8), fs, s["code_start"]))
+    mgr = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED, share_device=True)
+    w = _compare(mgr, ring, oring, starts, lambda i: oracle.TrackingChannel(i, fs, code_index_mode=1), 3, E, E)
+    print("share_device C", C, w)
+    states = [bytes(mgr.channels[i].state) for i in range(C)]
+    mgr.close()
+    m2 = T.TrackingManager(fs, n_channels=C, code_index_mode=T.CODE_INDEX_FIXED, share_device=True)
+    for i, r in enumerate(starts):
+        m2.channels[i].start(r)
+    outs, proc, lost, done = m2.collect(m2.update_all_async(ring, E), wait=True)
+    assert done == E and not lost.any() and proc.all()
+    assert [bytes(m2.channels[i].state) for i in range(C)] == states
+    m2.close(); ring.close()
+
+
 def test_two_managers_on_two_streams_do_not_strand_each_other(gpu, oracle):
     """The persistent kernel needs its whole grid resident; two handles (two streams) launched back to back used to be able
     to hold half of each other's workgroups until the 0.2 s exchange time-out (GM_ERR_HIP).  Persistent launches are now
