@@ -60,6 +60,10 @@ class HipBuffers:
         p = self.C.c_void_p()
         assert self.hip.hipMalloc(self.C.byref(p), nbytes) == 0
         assert self.hip.hipMemset(p, fill, nbytes) == 0
+        # hipMemset of device memory is asynchronous to the host and ordered on the NULL stream only: the library's streams are
+        # non-blocking, so a kernel of theirs could otherwise write this buffer BEFORE the fill runs (seen once the suite's order
+        # changed: a metrics block zeroed after the search that filled it)
+        assert self.hip.hipDeviceSynchronize() == 0
         self.ptrs.append(p)
         return p.value
 
