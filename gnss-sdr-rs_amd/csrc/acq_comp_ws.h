@@ -171,11 +171,11 @@ __device__ __forceinline__ void comp_ws_wave_group_barrier(unsigned* word, unsig
 }
 
 // (the kernel's body is a function that receives the image as a pointer, for the same reason)
-template <class CP, uint32_t Q, bool STAMPS>
+template <class CP, uint32_t Q, bool STAMPS, bool PLANES>
 __device__ __forceinline__ void comp_corr_ws_body(
     cf* lds, const cf* __restrict__ spectra, const cf* __restrict__ code_fft,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
-    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int cb, int rows_max) {
+    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int cb, int rows_max, float* __restrict__ planes) {
     using PL = CP;
     using F = Fft<PL, true>;
     using PR = PairRows<PL>;
@@ -307,6 +307,17 @@ __device__ __forceinline__ void comp_corr_ws_body(
                 constexpr int STEP = Nb / RL;
                 static_assert(STEP == PL::A * PL::B1 && STEP * RL == Nb, "slot q2 of a lane is element e0 + A B1 q2 (mod Nb): HybridPlan::out_index");
                 const int e0 = PL::out_index(tid, 0), rw = (Nb - e0 + STEP - 1) / STEP;      // slots rw .. RL - 1 have wrapped
+                if constexpr (PLANES) {                       // gm_acq_cfg.strict_sum_order: the finished sums at their natural indices
+                    if (PL::last_active(tid)) {
+                        float* dst = planes + (size_t(p) * n_bins + d) * N + n1;
+#pragma unroll
+                        for (int r = 0; r < RL; ++r) {
+                            int e = e0 + STEP * r;
+                            e = e >= Nb ? e - Nb : e;
+                            dst[size_t(Q) * e] = acc[r];
+                        }
+                    }
+                }
                 float m1 = 0.0f, ps = 0.0f;                  // (from 0.0 like the reference's scan, :195-202: a NaN never becomes the maximum)
 #pragma unroll
                 for (int r = 0; r < RL; ++r) m1 = acc[r] > m1 ? acc[r] : m1;
@@ -361,16 +372,17 @@ __device__ __forceinline__ void comp_corr_ws_body(
     }
 }
 
-template <class CP, uint32_t Q, bool STAMPS = false>
+// PLANES (gm_acq_cfg.strict_sum_order): an instantiation of its own that also stores the accumulated power planes (acq_composite.hip)
+template <class CP, uint32_t Q, bool STAMPS = false, bool PLANES = false>
 __global__ __launch_bounds__(1024, 1) void comp_corr_ws_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
-    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int cb, int rows_max) {
+    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int cb, int rows_max, float* __restrict__ planes) {
     __shared__ cf image[CP::LDS_ELEMS];
     if constexpr (STAMPS) {
         if (g_comp_ws_wg && threadIdx.x == 0) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); g_comp_ws_wg[2 * blockIdx.x] = (long long)t; }
     }
-    comp_corr_ws_body<CP, Q, STAMPS>(image, spectra, code_fft, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, cb, rows_max);
+    comp_corr_ws_body<CP, Q, STAMPS, PLANES>(image, spectra, code_fft, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, cb, rows_max, planes);
     if constexpr (STAMPS) {
         if (g_comp_ws_wg && threadIdx.x == 0) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); g_comp_ws_wg[2 * blockIdx.x + 1] = (long long)t; }
     }

@@ -170,11 +170,13 @@ __global__ __launch_bounds__(256) void comp_fold_post_kernel(const cf* __restric
 // ------------------------------------------------------------------------------------ inverse, fused
 // One workgroup per (worker, bin).  spectra [d][m][k1][paired k2], code [p][k1][paired k2], twn [n1][paired k2] =
 // W_N^{-n1 k2} (e^{+...}: inverse).
-template <class PLX, uint32_t Q>
+// PLANES (gm_acq_cfg.strict_sum_order): every accumulated power value also goes to planes[(p * n_bins + d) * N + its natural index]
+// (an instantiation of its own: the shipped kernel carries nothing of it)
+template <class PLX, uint32_t Q, bool PLANES = false>
 __global__ __launch_bounds__(CompPlanOf<PLX>::type::T, CompPlanOf<PLX>::type::WAVES_PER_EU) void comp_corr_kernel(
     const cf* __restrict__ spectra, const cf* __restrict__ code_fft, const cf* __restrict__ twn, const cf* __restrict__ tw_inv,
     float* __restrict__ mmax, uint32_t* __restrict__ margmax, float* __restrict__ msum,
-    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int cb, int rows_max) {
+    const uint32_t* __restrict__ worker_list, int n_workers, int n_bins, int n_int, int cb, int rows_max, float* __restrict__ planes = nullptr) {
     using PL = typename CompPlanOf<PLX>::type;      // the base size's plan for this path (acq_device.h): plain or hybrid
     constexpr bool HYB = CorrMode<PL>::HYBRID;
     static_assert(!CorrMode<PL>::PFA, "composite bases: plain or hybrid correlation plans");
@@ -282,6 +284,7 @@ __global__ __launch_bounds__(CompPlanOf<PLX>::type::T, CompPlanOf<PLX>::type::WA
                     if constexpr (HYB) e = uint32_t(PL::out_index(tid, r)); else e = uint32_t((tid + it * PL::T) + r * NBL);
                     take_better(bv, bi, acc[it][r], Q * e + n1);
                     sum += acc[it][r];
+                    if constexpr (PLANES) planes[(size_t(p) * n_bins + d) * N + (Q * e + n1)] = acc[it][r];
                 }
             }
         }
@@ -327,7 +330,7 @@ template <class PL, uint32_t Q> struct CompLaunch {
         hipLaunchKernelGGL((comp_fwd_post_kernel<PL, Q>), dim3((PL::N + CT - 1) / CT, n_items), dim3(CT), 0, st, A, X, paired, order);
     }
     static void corr(hipStream_t st, const cf* spectra, const cf* code_paired, const cf* twn, const cf* tw_inv, float* mmax,
-                     uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int) {
+                     uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int, float* planes) {
         if (n_workers <= 0) return;
         static const int cb_env = diag_int("GM_COMP_CB", -1);   // diagnostic: workers per block (0: plain order)
         const int items = n_workers * n_bins, share = (items + 7) / 8;
@@ -337,12 +340,21 @@ template <class PL, uint32_t Q> struct CompLaunch {
         // bins a strip can touch: a share of `share` items starting anywhere in a row
         const int rows_max = (share + n_workers - 2) / n_workers + 1;
         const int slots = cb > 0 ? ((n_workers + cb - 1) / cb) * rows_max * cb : share;
+        if (planes) {                       // strict_sum_order: the variants that also store the power planes (launch_plane_strict_sum follows)
+            if constexpr (CompWs<CP>::USE)
+                hipLaunchKernelGGL((comp_corr_ws_kernel<CP, Q, false, true>), dim3(8 * slots), dim3(1024), 0, st, spectra, code_paired, mmax, margmax, msum,
+                                   worker_list, n_workers, n_bins, n_int, cb, rows_max, planes);
+            else
+                hipLaunchKernelGGL((comp_corr_kernel<PL, Q, true>), dim3(8 * slots), dim3(PL::T), 0, st, spectra, code_paired, twn, tw_inv,
+                                   mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, cb, rows_max, planes);
+            return;
+        }
         if constexpr (CompWs<CP>::USE)      // base 16000: the wave-specialised kernel (acq_comp_ws.h)
             hipLaunchKernelGGL((comp_corr_ws_kernel<CP, Q>), dim3(8 * slots), dim3(1024), 0, st, spectra, code_paired, mmax, margmax, msum,
-                               worker_list, n_workers, n_bins, n_int, cb, rows_max);
+                               worker_list, n_workers, n_bins, n_int, cb, rows_max, static_cast<float*>(nullptr));
         else
             hipLaunchKernelGGL((comp_corr_kernel<PL, Q>), dim3(8 * slots), dim3(PL::T), 0, st, spectra, code_paired, twn, tw_inv,
-                               mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, cb, rows_max);
+                               mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, cb, rows_max, static_cast<float*>(nullptr));
     }
     // W_N^{-n1 k2} (inverse sign) for n1 < Q, in the paired position of k2: built in double on the host
     static void fill_twn(cf* out) {
@@ -377,6 +389,41 @@ namespace gm {
         CompLaunch<PL, 6>::ops(), CompLaunch<PL, 8>::ops(),
 static const CompOps g_comp[] = {GM_COMP_ENTRY(Plan16384) GM_COMP_ENTRY(Plan16368) GM_COMP_ENTRY(Plan16000) GM_COMP_ENTRY(Plan8000) GM_COMP_ENTRY(Plan8192) GM_COMP_ENTRY(Plan8184)
                                      GM_COMP_ENTRY(Plan6000) GM_COMP_ENTRY(Plan5000) GM_COMP_ENTRY(Plan4000)};
+
+// strict_sum_order on the composite path.  is_good_satellite's plane sum in the reference's own order (do_acquisition.rs:229-235): eight
+// running f32 sums over chunks_exact(8) — lane l adds power[8c + l] for c = 0, 1, ... — then reduce_sum, an ordered add of the eight
+// lanes starting from -0.0.  One workgroup per plane; the plane travels through LDS in chunks of 8192 values (coalesced loads), eight
+// lanes of wave 0 walk each chunk sequentially and carry their sums from chunk to chunk.
+__global__ __launch_bounds__(256) void plane_strict_sum_kernel(const float* __restrict__ planes, float* __restrict__ msum,
+                                                                const uint32_t* __restrict__ worker_list, int n_bins, uint32_t N) {
+    constexpr uint32_t CH = 8192;
+    __shared__ float pl[CH];
+    const int tid = threadIdx.x;
+    const size_t o = size_t(worker_list[blockIdx.y]) * n_bins + blockIdx.x;
+    const float* src = planes + o * N;
+    const uint32_t n8 = N & ~7u;                                    // chunks_exact(8) drops a tail
+    float ls = 0.0f;                                                // f32x8::splat(0.0): lane tid < 8 holds lane tid of it
+    for (uint32_t c0 = 0; c0 < n8; c0 += CH) {
+        const uint32_t len = n8 - c0 < CH ? n8 - c0 : CH;
+        for (uint32_t i = tid; i < len; i += 256) pl[i] = src[c0 + i];
+        __syncthreads();
+        if (tid < 8) {
+#pragma unroll 8
+            for (uint32_t c = 0; c < len / 8; ++c) ls = ls + pl[c * 8 + tid];
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
+        float t = -0.0f;                                            // simd_reduce_add_ordered(v, -0.0)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) t = t + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ls), l));
+        if (tid == 0) msum[o] = t;
+    }
+}
+void launch_plane_strict_sum(hipStream_t st, const float* planes, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, uint32_t N) {
+    if (n_workers <= 0 || n_bins <= 0) return;
+    hipLaunchKernelGGL(plane_strict_sum_kernel, dim3(n_bins, n_workers), dim3(256), 0, st, planes, msum, worker_list, n_bins, N);
+}
 
 // N = Q * Nb: the largest base plan first (fewest sub-transform passes over the spectra)
 const CompOps* find_comp(uint32_t n) {

@@ -314,6 +314,7 @@ struct gm_acq {
     const gm::CompOps* comp = nullptr;     // Q > 1: the (Q, base plan) kernels
     cf* d_comp_tmp = nullptr;              // [max(D*M, P)][Q][Nb]: forward sub-transforms before the Q-point DFTs
     cf* d_comp_twn = nullptr;              // [Q][Nb] inverse twiddles W_N^{-n1 k2}, paired positions
+    float* d_planes = nullptr;             // composite sizes with strict_sum_order: the accumulated power planes [P * D][N] (launch_plane_strict_sum)
     cf* d_code_comb = nullptr;             // Q > 1: [P][Q][Q][Nb] conj(code) x W_Q^{-n1 k1} x W_N^{-n1 k2}, what comp corr multiplies the spectra by
     // gm_acq_decide_dev on the metrics of the last search, on a handle of an in-LDS size: the decision is NOT launched but kept here
     // and rides along with the next search's stage F (PlanOps::mix_fft: trailing workgroups) — anything else that consumes or
@@ -651,6 +652,7 @@ int gm_rfft_f32(size_t n, const float* in, gm_c32* out) {
 int gm_acq_destroy(gm_acq* a) {
     if (!a) return GM_OK;
     if (a->device >= 0) hipSetDevice(a->device);
+    hipFree(a->d_planes);
     hipFree(a->d_comp_tmp); hipFree(a->d_comp_twn); hipFree(a->d_code_comb); hipFree(a->d_split_scratch); hipFree(a->d_split_counter);
     hipFree(a->fine.d_chips); hipFree(a->fine.d_tw1); hipFree(a->fine.d_tw2); hipFree(a->fine.d_B); hipFree(a->fine.d_mean);
     hipFree(a->fine.d_rowmax); hipFree(a->fine.d_rowarg); hipFree(a->fine.d_sat_worker); hipFree(a->fine.d_sat_cp);
@@ -692,8 +694,8 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
         if (comp) { pl = gm::find_plan(comp->nb); comp_q = uint32_t(comp->q); }
     }
     if (!pl) return set_err(GM_ERR_UNSUPPORTED_N, "no in-LDS FFT plan for this fft_size, nor Q x {16384, 16368, 16000, 8192, 8184, 8000, 6000, 5000, 4000} with Q in {2,3,4,5,6,8}");
-    if (cfg->strict_sum_order && comp_q > 1)
-        return set_err(GM_ERR_INVALID_ARG, "strict_sum_order needs an fft_size with an in-LDS plan (gm_fft_supported_sizes)");
+    // (strict_sum_order on a composite size: the kernels also store the power planes and a second kernel sums them in the reference's
+    //  order — P * D * N * 4 bytes of planes: 189 MB at the configs[3] Galileo geometry)
     if (cfg->reference_products && comp_q > 1)
         return set_err(GM_ERR_INVALID_ARG, "reference_products needs an fft_size with an in-LDS plan (gm_fft_supported_sizes)");
     if (int rc = ensure_device(g_device)) return rc;
@@ -805,6 +807,7 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
     } else {     // the signal's two forward steps on the chips: natural order (the API's view), then every block paired
         const size_t tmp_items = D * M > P ? D * M : P;
         HIPA(hipMalloc(&a->d_comp_tmp, tmp_items * N * 8));
+        if (cfg->strict_sum_order) HIPA(hipMalloc(&a->d_planes, P * D * N * sizeof(float)));
         HIPA(hipMalloc(&a->d_comp_twn, N * 8));
         HIPA(hipMalloc(&a->d_code_fft_paired, P * N * 8));
         std::vector<gm::cf> twn(N);
@@ -892,7 +895,9 @@ static int acq_search_common(gm_acq* a, const void* d_samples, int fmt, void* d_
                       a->cfg.reference_products ? 1 : 0);
     } else if (a->n_workers) {
         a->comp->corr(a->stream, a->d_spectra, a->d_code_comb, a->d_comp_twn, a->d_tw_inv, reinterpret_cast<float*>(met),
-                      met + PD, reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M));
+                      met + PD, reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), int(a->M), a->d_planes);
+        if (a->d_planes)      // strict_sum_order: the plane sums once more, in is_good_satellite's own order (:229-235)
+            gm::launch_plane_strict_sum(a->stream, a->d_planes, reinterpret_cast<float*>(met + 2 * PD), a->d_worker_list, int(a->n_workers), int(a->D), uint32_t(a->N));
     }
     if (t) { HIPC(hipEventRecord(ev[2], a->stream)); a->tm.count++; a->tm.decide_valid = false; }
     HIPC(hipGetLastError());

@@ -98,8 +98,10 @@ struct CompOps {
     // forward step 2: twiddle + Q-point DFTs -> natural block order; paired != 0 stores each block in the paired layout
     void (*fwd_post)(hipStream_t, const cf* A, cf* X, uint32_t n_items, int paired, const uint16_t* order);
     // inverse, fused: {max, first argmax, sum} per (worker, bin) straight from the spectra
+    // planes (null normally; gm_acq_cfg.strict_sum_order): [n_workers_total * n_bins][N] floats — the kernel also stores every accumulated
+    // power value at its natural index, for launch_plane_strict_sum
     void (*corr)(hipStream_t, const cf* spectra, const cf* code_paired, const cf* twn, const cf* tw_inv, float* mmax,
-                 uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int);
+                 uint32_t* margmax, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, int n_int, float* planes);
     void (*fill_twn)(cf* out);   // host: [q][nb] inverse twiddles W_N^{-n1 k2} in the paired position of k2
     // once per handle: comb[p][n1][k1][pos] = conj(code_paired[p][k1][pos]) * W_Q^{-n1 k1} * twn[n1][pos], the whole code-side
     // factor of sub-transform n1 (the codes are static, so corr multiplies a spectrum value by ONE table entry)
@@ -113,6 +115,9 @@ struct CompOps {
     void (*fold_post)(hipStream_t, const cf* comb, const uint16_t* order, cf* comb2, uint32_t n_codes);
 };
 const CompOps* find_comp(uint32_t n);
+// strict_sum_order on the composite path: msum[o] = is_good_satellite's eight-lane ordered sum (do_acquisition.rs:229-235) of plane o,
+// for the planes of the listed workers (o = worker * n_bins + bin)
+void launch_plane_strict_sum(hipStream_t, const float* planes, float* msum, const uint32_t* worker_list, int n_workers, int n_bins, uint32_t N);
 
 // elementwise apply_doppler_shift (doppler_shift.rs:25-58)
 void launch_apply_doppler(hipStream_t, const cf* s, const cf* t, cf* out, size_t n);

@@ -130,7 +130,9 @@ typedef struct {
                                   ~2e-6 of the reference's, FFT rounding aside).  1: summed in the reference's own order —
                                   eight running f32 sums over chunks_exact(8), then reduce_sum from -0.0 — and the
                                   integrations accumulated strictly in sequence (no grid-tail split); costs ~4 us per
-                                  (worker, bin) workgroup.  In-LDS sizes only (fft_size one of gm_fft_supported_sizes()). */
+                                  (worker, bin) workgroup.  Composite sizes (Q x a base plan) as well since ABI 6: their kernels
+                                  then also store the accumulated power planes (n_prn * n_bins * fft_size * 4 bytes of device
+                                  memory) and a second kernel sums each plane in that order. */
     int32_t reference_products; /* 0: `result_buf[i] *= conj(code_fft[i])` (:184-186) and `norm_sqr()` (:190-192) use two fused
                                   multiply-adds each (one rounding fewer per component; 4 instead of 6 instructions per
                                   element).  1: formed as num-complex forms them — every product and every sum rounded on its

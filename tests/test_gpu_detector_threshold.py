@@ -85,8 +85,49 @@ def test_near_threshold_decisions_match_the_oracle(gpu, oracle, side):
     print(side, "ratio0 =", sc["ratio0"], "tree (sum, max, ratio) =", report[False], "strict =", report[True])
 
 
-def test_strict_sum_order_rejected_on_the_composite_path(gpu):
-    from gnss_sdr_rs_amd import acquisition as A
-    with pytest.raises(Exception):
-        A.AcquisitionEngine(8.0e6, 0.0, 32000, doppler_hz=np.array([0.0], np.float32), prn_ids=[1], n_integrations=2,
-                            strict_sum_order=True)
+@pytest.mark.parametrize("fs,N,code_len,what", [(8.0e6, 32000, 4092, "2 x 16000: the wave-specialised composite kernel"),
+                                                  (25.0e6, 25000, 1023, "5 x 5000: the generic composite kernel")])
+def test_strict_sum_order_on_the_composite_path(gpu, oracle, fs, N, code_len, what):
+    """ABI 6 ("missing" 6): strict_sum_order is accepted on sizes beyond one LDS buffer — the composite kernels store
+    the accumulated power planes and a second kernel adds each plane in is_good_satellite's eight-lane order (:229-235).  As at the
+    in-LDS sizes: strict sums within 5e-7 of the oracle's ordered sums (only the transform's rounding is left), tree sums within
+    1e-5; maxima, indices and decisions are those of the default mode."""
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    M = 2
+    dop = np.array([-500.0, 0.0, 500.0], np.float32)
+    rng = np.random.default_rng(N)
+    code_rate = 1.023e6
+    if code_len == 1023:
+        codes, prn_ids, table, rows = None, [3, 9, 21], oracle.ca_code_table(), [2, 8, 20]
+    else:
+        codes = np.where(rng.integers(0, 2, (3, code_len)) > 0, 1, -1).astype(np.int8)
+        prn_ids, table, rows = [1, 2, 3], codes, [0, 1, 2]
+    sats = [dict(prn_row=rows[0], cn0_dbhz=50.0, doppler_hz=180.0, code_start=N - 77),
+            dict(prn_row=rows[2], cn0_dbhz=48.0, doppler_hz=-390.0, code_start=12345)]
+    x = synth.to_i8_iq(synth.make_scene(table, fs, 0.0, M * N, sats, config_id=77, code_rate=code_rate))
+    xc = (x[:, 0] + 1j * x[:, 1]).astype(np.complex64)
+    tables = [oracle.DopplerShiftTable(0.0, float(d), fs, N) for d in dop]
+    want = []
+    for w in range(3):
+        ow = oracle.AcquisitionWorker(prn_ids[w], N, fs, code=(codes[w] if codes is not None else None), code_rate=code_rate)
+        want.append(ow.search_satellite(xc, tables, 0, M, want_planes=True, no_early_exit=True))
+    got = {}
+    for strict in (False, True):
+        eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=prn_ids, n_integrations=M, codes=codes, code_rate=code_rate,
+                                  strict_sum_order=strict)
+        res = eng.search(x)
+        got[strict] = (res,) + eng.metrics()
+        # a PRN mask: the strict sums of the searched workers only, the others' words untouched by the second kernel
+        res_m = eng.search(x, prn_mask=0b101)
+        assert [r is None for r in res_m] == [res[0] is None, True, res[2] is None]
+        eng.close()
+        for w in range(3):
+            exp, (bmax, barg, bsum, _) = want[w]
+            mx, am, sm = got[strict][1:]
+            assert (am[w] == barg).all() and np.allclose(mx[w], bmax, rtol=1e-5)
+            rel = float(np.max(np.abs(sm[w] - bsum) / bsum))
+            assert rel <= (5e-7 if strict else 1e-5), (what, strict, w, rel)
+            assert (res[w] is None) == (exp is None)
+    assert (got[True][1].view(np.uint32) == got[False][1].view(np.uint32)).all()      # the maxima do not depend on the mode
+    assert (got[True][2] == got[False][2]).all()
+    assert not (got[True][3].view(np.uint32) == got[False][3].view(np.uint32)).all()  # ... the sums do (another order of additions)

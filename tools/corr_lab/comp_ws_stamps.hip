@@ -28,8 +28,8 @@ int main() {
     hipMalloc(&wg, NWG * 16); hipMemset(wg, 0, NWG * 16);
     hipMemcpyToSymbol(HIP_SYMBOL(g_comp_ws_wg), &wg, sizeof(wg));
     const int items = P * D, share = (items + 7) / 8, cb = 4, rows_max = (share + P - 2) / P + 1, slots = ((P + cb - 1) / cb) * rows_max * cb;
-    auto launch_st = [&]() { hipLaunchKernelGGL((comp_corr_ws_kernel<CP, Q, true>), dim3(8 * slots), dim3(1024), 0, 0, dx, dc, met, reinterpret_cast<uint32_t*>(met) + P * D, met + 2 * P * D, wl, P, D, M, cb, rows_max); };
-    auto launch = [&]() { hipLaunchKernelGGL((comp_corr_ws_kernel<CP, Q, false>), dim3(8 * slots), dim3(1024), 0, 0, dx, dc, met, reinterpret_cast<uint32_t*>(met) + P * D, met + 2 * P * D, wl, P, D, M, cb, rows_max); };
+    auto launch_st = [&]() { hipLaunchKernelGGL((comp_corr_ws_kernel<CP, Q, true>), dim3(8 * slots), dim3(1024), 0, 0, dx, dc, met, reinterpret_cast<uint32_t*>(met) + P * D, met + 2 * P * D, wl, P, D, M, cb, rows_max, static_cast<float*>(nullptr)); };
+    auto launch = [&]() { hipLaunchKernelGGL((comp_corr_ws_kernel<CP, Q, false>), dim3(8 * slots), dim3(1024), 0, 0, dx, dc, met, reinterpret_cast<uint32_t*>(met) + P * D, met + 2 * P * D, wl, P, D, M, cb, rows_max, static_cast<float*>(nullptr)); };
     for (int rep = 0; rep < 3; ++rep) launch_st();
     hipDeviceSynchronize();
     std::vector<long long> hall(4 * S * 3 * 8);
