@@ -5,6 +5,11 @@
 //   kind 1  16 independent v_fma_f32 per round
 //   kind 2  16 v_mfma_f32_16x16x4_f32 per round on 4 accumulators (dependence distance 4 instructions = 128 cycles > 40)
 //   kind 3  16 matrix instructions with `fill` independent v_fma_f32 behind each (one wave feeding both pipes)
+//   kind 4  16 v_mfma_f32_32x32x2_f32 per round (the other f32-input shape)
+//   kind 5  16 v_mfma_f32_32x32x16_bf16 per round (for contrast: a low-precision matrix instruction beside vector code)
+//   kind 6  16 v_mfma_f32_16x16x4_f32 per round with FILL x `s_nop 7` (8 wait states each) behind every one: does a matrix wave that
+//           does NOT present its next matrix instruction at once leave the vector issue port to the other waves?
+//   kind 7  the same with v_mfma_f32_32x32x16_bf16
 // Prints shader-clock ticks per instruction for one wave of every role.  The question behind it: a radix-16
 // butterfly is ~340 vector instructions per 64 butterflies = 10.7 issue cycles per butterfly at 2 cycles per instruction; as four
 // real 16 x 16 products it is 16 matrix instructions per 16 butterflies — if each of them holds the vector issue port for 8 cycles
@@ -13,6 +18,8 @@
 #include <cstdio>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Roles { int kind[4]; int fill; };
 
@@ -45,6 +52,58 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, Roles r, long l
                 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, d3, 0, 0, 0);
             }
         }
+    } else if (kind == 6) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, d0, 0, 0, 0);
+                _Pragma("unroll") for (int f = 0; f < FILL; ++f) asm volatile("s_nop 7");
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, d1, 0, 0, 0);
+                _Pragma("unroll") for (int f = 0; f < FILL; ++f) asm volatile("s_nop 7");
+                d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, d2, 0, 0, 0);
+                _Pragma("unroll") for (int f = 0; f < FILL; ++f) asm volatile("s_nop 7");
+                d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, d3, 0, 0, 0);
+                _Pragma("unroll") for (int f = 0; f < FILL; ++f) asm volatile("s_nop 7");
+            }
+        }
+    } else if (kind == 7) {
+        f32x16 e0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, e1 = e0;
+        bf16x8 ab, bb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ab[i] = (__bf16)(am + float(i)); bb[i] = (__bf16)(bm - float(i)); }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, e0, 0, 0, 0);
+                _Pragma("unroll") for (int f = 0; f < FILL; ++f) asm volatile("s_nop 7");
+                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, e1, 0, 0, 0);
+                _Pragma("unroll") for (int f = 0; f < FILL; ++f) asm volatile("s_nop 7");
+            }
+        }
+        d0[0] += e0[0] + e1[5];
+    } else if (kind == 4) {
+        f32x16 e0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, e1 = e0;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                e0 = __builtin_amdgcn_mfma_f32_32x32x2f32(am, bm, e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_32x32x2f32(am, bm, e1, 0, 0, 0);
+            }
+        }
+        d0[0] += e0[0] + e1[5];
+    } else if (kind == 5) {
+        f32x16 e0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, e1 = e0;
+        bf16x8 ab, bb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ab[i] = (__bf16)(am + float(i)); bb[i] = (__bf16)(bm - float(i)); }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, e1, 0, 0, 0);
+            }
+        }
+        d0[0] += e0[0] + e1[5];
     } else {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -95,6 +154,24 @@ int main() {
         {"1 wave/SIMD: matrix with 6 vector behind each", 256, {{3, 0, 0, 0}, 6}},
         {"1 wave/SIMD: matrix with 8 vector behind each", 256, {{3, 0, 0, 0}, 8}},
         {"2 waves/SIMD: (matrix with 4 vector) + vector", 512, {{3, 1, 0, 0}, 4}},
+        {"matrix + 2 x s_nop 7 each, alone", 256, {{6, 0, 0, 0}, 2}},
+        {"(matrix + 2 x s_nop 7) + vector", 512, {{6, 1, 0, 0}, 2}},
+        {"(matrix + 2 x s_nop 7) + 3 x vector", 1024, {{6, 1, 1, 1}, 2}},
+        {"matrix + 4 x s_nop 7 each, alone", 256, {{6, 0, 0, 0}, 4}},
+        {"(matrix + 4 x s_nop 7) + vector", 512, {{6, 1, 0, 0}, 4}},
+        {"(matrix + 4 x s_nop 7) + 2 x vector", 768, {{6, 1, 1, 0}, 4}},
+        {"(matrix + 4 x s_nop 7) + 3 x vector", 1024, {{6, 1, 1, 1}, 4}},
+        {"(matrix + 6 x s_nop 7) + 3 x vector", 1024, {{6, 1, 1, 1}, 6}},
+        {"2 x (matrix + 4 x s_nop 7) + 2 x vector", 1024, {{6, 6, 1, 1}, 4}},
+        {"bf16 matrix + 4 x s_nop 7 each, alone", 256, {{7, 0, 0, 0}, 4}},
+        {"(bf16 matrix + 4 x s_nop 7) + 3 x vector", 1024, {{7, 1, 1, 1}, 4}},
+        {"1 wave/SIMD: f32 32x32x2", 256, {{4, 0, 0, 0}, 0}},
+        {"2 waves/SIMD: f32 32x32x2 + vector", 512, {{4, 1, 0, 0}, 0}},
+        {"3 waves/SIMD: f32 32x32x2 + 2 x vector", 768, {{4, 1, 1, 0}, 0}},
+        {"1 wave/SIMD: bf16 32x32x16", 256, {{5, 0, 0, 0}, 0}},
+        {"2 waves/SIMD: bf16 32x32x16 + vector", 512, {{5, 1, 0, 0}, 0}},
+        {"3 waves/SIMD: bf16 32x32x16 + 2 x vector", 768, {{5, 1, 1, 0}, 0}},
+        {"4 waves/SIMD: bf16 32x32x16 + 3 x vector", 1024, {{5, 1, 1, 1}, 0}},
     };
     for (int nblk : {1, 256}) {
         printf("---- %d workgroup(s)\n", nblk);
@@ -124,7 +201,7 @@ int main() {
                 const int w = role * 4;      // the role's wave on the SIMD of wave 0
                 const double per_round = double(c[w]) / iters;
                 if (kind == 1) printf("  vector %.2f ticks/instr", per_round / 16);
-                else if (kind == 2) printf("  matrix %.2f ticks/instr", per_round / 16);
+                else if (kind == 2 || kind == 4 || kind == 5 || kind == 6 || kind == 7) printf("  matrix %.2f ticks/instr", per_round / 16);
                 else printf("  mixed %.1f ticks per (matrix + %d vector)", per_round / 16, cs.r.fill);
                 printf(" [simd %u]", (id[w] >> 4) & 3u);
             }
