@@ -2336,6 +2336,8 @@ int gm_frontend_write_ring(gm_frontend* f, gm_ring* r, const void* samples, size
         if (int rc = ring_reclaim_slot(r, slot)) return rc;
         if (!f->d_raw[slot]) HIPC(hipMalloc(&f->d_raw[slot], gm_ring::SLOT_SAMPLES_MAX * 8));
         memcpy(r->staging[slot], src, chunk * bps);
+        // (the kernel reading the pinned staging slot itself instead of a device copy of it — no copy, no event — was measured:
+        //  30 x real time against 52: the front-end's loads then wait on host memory)
         HIPC(hipMemcpyAsync(f->d_raw[slot], r->staging[slot], chunk * bps, hipMemcpyHostToDevice, r->copy_stream));
         HIPC(hipEventRecord(r->h2d_done[slot], r->copy_stream));
         HIPC(hipStreamWaitEvent(r->fe_stream, r->h2d_done[slot], 0));
