@@ -23,7 +23,18 @@ def test_header_symbols_all_exported(gm):
     exported = set(re.findall(r" T (gm_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
     assert not [s for s in re.findall(r" [TDB] (\S+)", nm) if not s.startswith("gm_")]   # nothing else leaks
-    assert gm.lib().gm_abi_version() == 6
+    import __graft_entry__ as entry
+    assert gm.lib().gm_abi_version() == entry.header_abi_version() >= 6
+
+
+def test_graft_entry_build_runs_and_imports_the_package():
+    """The driver's "does it build" call: `__graft_entry__.build()` in a process of its own (hipcc cross-compiles without a GPU;
+    an up-to-date tree is an incremental no-op) must exit 0, having loaded the library and compared its ABI number with the
+    header's (a stale literal made this the one entry point that failed while every test was green)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "build"], cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "built " in out.stdout and "libgnss_mi355x.so" in out.stdout, out.stdout[-1000:]
 
 
 def test_library_links_no_oracle_and_no_torch(gm):
