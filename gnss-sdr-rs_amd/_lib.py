@@ -126,6 +126,7 @@ SIGNATURES = {
     "gm_ring_copy_to_slice": (_i, [_vp, _u64, _vp, _sz]),
     "gm_ring_write_samples_async": (_i, [_vp, _vp, _sz]),
     "gm_ring_flush": (_i, [_vp]),
+    "gm_ring_get_enqueued_head": (_i, [_vp, C.POINTER(_u64)]),
     "gm_ring_wait_head": (_i, [_vp, _u64, _u32, _vp]),
     "gm_nav_sync_create": (_i, [_i, _vp]),
     "gm_nav_sync_destroy": (_i, [_vp]),
@@ -158,7 +159,9 @@ SIGNATURES = {
     "gm_trk_update_all": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "gm_trk_update_all_dev": (_i, [_vp, _vp, _u32]),
     "gm_trk_update_all_async": (_i, [_vp, _vp, _u32, C.POINTER(C.c_uint64)]),
-    "gm_trk_collect": (_i, [_vp, C.c_uint64, _i, _vp, _vp, _vp, C.POINTER(_u32), C.POINTER(_i)]),
+    "gm_trk_collect": (_i, [_vp, C.c_uint64, _i, _vp, _vp, _vp, _vp, C.POINTER(_u32), C.POINTER(_i)]),
+    "gm_trk_get_states": (_i, [_vp, _vp]),
+    "gm_trk_set_states": (_i, [_vp, _vp, _vp]),
     "gm_trk_synchronize": (_i, [_vp]),
     "gm_trk_set_stream": (_i, [_vp, _vp]),
     "gm_trk_debug_stamps": (_i, [_vp, _u32, _vp]),

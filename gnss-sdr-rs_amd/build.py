@@ -59,7 +59,25 @@ def build(force=False, verbose=False):
         run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
              "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")])
     build_synth(force)
+    build_receiver_harness(force)
     return LIB
+
+
+def build_receiver_harness(force=False):
+    """host/receiver_harness.cpp: the receiver chain built from the C++ stage drivers of host/gnss_sdr.hpp behind an extern "C"
+    surface (g++, host code only, links the product library through the C ABI) — what bench.py's `receiver` leg and the
+    stage-driver tests call.  Linked against the plain product library even in a suffixed diagnostic build."""
+    src = os.path.join(HERE, "host", "receiver_harness.cpp")
+    lib = os.path.join(LIBDIR, "libgm_receiver.so")
+    deps = [src, os.path.join(HERE, "host", "gnss_sdr.hpp"), os.path.join(HERE, "..", "include", "gnss_mi355x.h")]
+    product = os.path.join(LIBDIR, "libgnss_mi355x.so")
+    if force or _stale(lib, deps) or (os.path.exists(product) and os.path.getmtime(product) > os.path.getmtime(lib)):
+        r = subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-o", lib, src,
+                            "-L", LIBDIR, "-lgnss_mi355x", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-pthread"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            raise RuntimeError("g++ failed:\n" + r.stdout)
+    return lib
 
 
 def build_synth(force=False):

@@ -216,8 +216,15 @@ static hipError_t wait_event_polling(hipEvent_t ev) {
     }
 }
 
+// head := max(head, new_head), never backwards: readers and the writer may retire chunks concurrently (head by pull), and a
+// plain store after a stale load would let the older of two retirements land last.  compare-exchange max loop, then the wake-up.
 static void ring_publish(gm_ring* r, uint64_t new_head) {
-    r->head.store(new_head, std::memory_order_release);
+    uint64_t cur = r->head.load(std::memory_order_relaxed);
+    bool moved = false;
+    while (int64_t(new_head - cur) > 0) {
+        if (r->head.compare_exchange_weak(cur, new_head, std::memory_order_release, std::memory_order_relaxed)) { moved = true; break; }
+    }
+    if (!moved) return;
     std::lock_guard<std::mutex> g(r->notifier);     // "Wake up Tracking after writing new samples" (:94-98)
     r->condvar.notify_all();
 }
@@ -239,7 +246,7 @@ static void ring_refresh_head(gm_ring* r, bool all = false) {
         }
         if (done) r->pending.erase(r->pending.begin(), r->pending.begin() + done);
     }
-    if (any && int64_t(newest - r->head.load(std::memory_order_relaxed)) > 0) ring_publish(r, newest);
+    if (any) ring_publish(r, newest);               // monotonic by construction (two readers retiring at once: ADVICE round 5)
 }
 static int ring_async_init(gm_ring* r) {
     if (r->copy_stream) return GM_OK;
@@ -335,6 +342,7 @@ struct gm_acq {
         uint64_t token = 0, next_token = 1;
         const void* samples = nullptr;      // composite sizes only (nothing is prepared: the search runs from these at search_prepared)
         int fmt = 0;
+        bool comp_wait = false;             // composite sizes: ev_in was recorded on the caller's ready_stream, the search waits for it
     } ahead;
     bool defer_decisions = false;   // gm_acq_set_deferred_decision
     bool dec_deferred = false;
@@ -920,8 +928,9 @@ int gm_acq_search_prepared_dev(gm_acq* a, uint64_t token, void* d_metrics) {
     if (!token || !ah.valid || ah.token != token)
         return set_err(GM_ERR_INVALID_ARG, "no such preparation (token stale, consumed, replaced or dropped)");
     if (int rc = ensure_device(a->device)) return rc;
-    if (a->Q != 1) {                        // composite sizes prepare nothing: the whole search runs now, from the samples named then
-        ah.valid = false;
+    if (a->Q != 1) {                        // composite sizes prepare nothing: the whole search runs now, from the samples named then,
+        ah.valid = false;                   // behind what `ready_stream` held at the time of gm_acq_prepare_dev
+        if (ah.comp_wait) { HIPC(hipStreamWaitEvent(a->stream, ah.ev_in, 0)); ah.comp_wait = false; }
         return acq_search_common(a, ah.samples, ah.fmt, d_metrics, false);
     }
     return acq_search_common(a, ah.samples, ah.fmt, d_metrics, true);
@@ -938,11 +947,20 @@ int gm_acq_prepare_dev(gm_acq* a, const void* d_samples, int fmt, void* ready_st
     if (fmt < GM_FMT_C32 || fmt > GM_FMT_I8_REAL) return set_err(GM_ERR_INVALID_ARG, "bad sample format");
     *token = 0;
     gm_acq::Ahead& ah = a->ahead;
-    if (a->Q != 1) {                        // composite sizes: nothing is prepared, gm_acq_search_prepared_dev does all of it
+    if (int rc = ensure_device(a->device)) return rc;
+    if (a->Q != 1) {                        // composite sizes: nothing is prepared, gm_acq_search_prepared_dev does all of it —
+        // but the ordering promise is the same: the samples are complete once the work queued on `ready_stream` so far has run, so
+        // the event is recorded NOW and the search waits for it on the handle's stream (the token used to be handed
+        // out before `ready_stream` was looked at)
+        ah.valid = false; ah.comp_wait = false;
+        if (ready_stream) {
+            if (!ah.ev_in) HIPC(hipEventCreateWithFlags(&ah.ev_in, hipEventDisableTiming));
+            HIPC(hipEventRecord(ah.ev_in, reinterpret_cast<hipStream_t>(ready_stream)));
+            ah.comp_wait = true;
+        }
         ah.valid = true; ah.samples = d_samples; ah.fmt = fmt; ah.token = *token = ah.next_token++;
         return GM_OK;
     }
-    if (int rc = ensure_device(a->device)) return rc;
     if (!ah.side) {
         // all four resources or none: a failure half-way must leave the handle as it was (a later call starts over)
         cf* buf = nullptr; hipStream_t side = nullptr; hipEvent_t e[3] = {nullptr, nullptr, nullptr};
@@ -1450,6 +1468,11 @@ int gm_ring_write_samples(gm_ring* r, const gm_c32* s, size_t n) {
     if (!r || (!s && n)) return set_err(GM_ERR_INVALID_ARG, "null pointer");
     if (n > r->size) return set_err(GM_ERR_OUT_OF_RANGE, "write larger than the ring");
     if (int rc = ensure_device(r->device)) return rc;
+    if (r->copy_stream) {       // chunks of the asynchronous writer still in flight: land and retire them first, so that `head` is the
+        HIPC(hipStreamSynchronize(r->copy_stream));      // writer's position (a synchronous write placed at a stale head would overwrite them)
+        if (r->fe_stream) HIPC(hipStreamSynchronize(r->fe_stream));
+        ring_refresh_head(r, true);
+    }
     const uint64_t cur = r->head.load(std::memory_order_relaxed);
     const size_t start = size_t(cur & r->mask);
     if (start + n <= r->size) {
@@ -1468,6 +1491,17 @@ int gm_ring_get_head(gm_ring* r, uint64_t* head) {
     if (!r || !head) return set_err(GM_ERR_INVALID_ARG, "null pointer");
     if (r->copy_stream) { if (int rc = ensure_device(r->device)) return rc; ring_refresh_head(r); }
     *head = r->head.load(std::memory_order_acquire);
+    return GM_OK;
+}
+
+int gm_ring_get_enqueued_head(gm_ring* r, uint64_t* head) {
+    if (!r || !head) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    uint64_t h = r->head.load(std::memory_order_acquire);
+    {
+        std::lock_guard<std::mutex> g(r->enq_mu);
+        if (r->ev_enq_armed && int64_t(r->enqueued - h) > 0) h = r->enqueued;
+    }
+    *head = h;
     return GM_OK;
 }
 
@@ -1737,6 +1771,32 @@ int gm_trk_set_state(gm_trk* t, uint32_t ch, const gm_trk_state* in) {
     return GM_OK;
 }
 
+int gm_trk_get_states(gm_trk* t, gm_trk_state* out) {
+    if (!t || !out) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (int rc = ensure_device(t->device)) return rc;
+    HIPC(hipStreamSynchronize(t->stream));
+    HIPC(hipMemcpy(out, t->d_states, size_t(t->C) * sizeof(*out), hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+int gm_trk_set_states(gm_trk* t, const gm_trk_state* in, const uint8_t* which) {
+    if (!t || !in) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    if (int rc = ensure_device(t->device)) return rc;
+    HIPC(hipStreamSynchronize(t->stream));
+    if (!which) {
+        HIPC(hipMemcpy(t->d_states, in, size_t(t->C) * sizeof(*in), hipMemcpyHostToDevice));
+        return GM_OK;
+    }
+    for (uint32_t c = 0; c < t->C; ) {          // runs of flagged channels, one copy each
+        if (!which[c]) { ++c; continue; }
+        uint32_t e = c;
+        while (e < t->C && which[e]) ++e;
+        HIPC(hipMemcpy(t->d_states + c, in + c, size_t(e - c) * sizeof(*in), hipMemcpyHostToDevice));
+        c = e;
+    }
+    return GM_OK;
+}
+
 int gm_trk_start(gm_trk* t, uint32_t ch, const gm_acq_result* r) {   // :148-154
     if (!t || !r || ch >= t->C) return set_err(GM_ERR_INVALID_ARG, "bad channel");
     gm_trk_state s;
@@ -1940,8 +2000,10 @@ int gm_trk_update_all_async(gm_trk* t, gm_ring* ring, uint32_t max_epochs, uint6
     gm_trk::Ticket& k = t->tk[t->next_ticket % gm_trk::TICKETS];
     if (k.in_flight) return set_err(GM_ERR_OUT_OF_RANGE, "all result slots are in flight: gm_trk_collect the oldest ticket first");
     if (int rc = ensure_device(t->device)) return rc;
+    // slot: [outs n | processed n | lost n | pad to 8 | states C] — the states as they stand behind THIS call's passes
     const size_t n = size_t(max_epochs) * t->C, bytes = n * (sizeof(gm_trk_out) + 2);
-    if (int rc = trk_reserve_tickets(t, bytes)) return rc;
+    const size_t st_off = (bytes + 7) & ~size_t(7), st_bytes = size_t(t->C) * sizeof(gm_trk_state);
+    if (int rc = trk_reserve_tickets(t, st_off + st_bytes)) return rc;
     static const int trace_slow = gm::diag_int("GM_TRK_TRACE_SLOW", 0);      // diagnostic: which runtime call of this entry takes milliseconds
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
@@ -1959,7 +2021,7 @@ int gm_trk_update_all_async(gm_trk* t, gm_ring* ring, uint32_t max_epochs, uint6
     const auto t2 = now();
     if (int rc = trk_launch_all(t, ring, max_epochs, head)) return rc;
     const auto t3 = now();
-    gm::launch_trk_results_to_host(t->stream, t->d_res, k.h, bytes);      // [outs | processed | lost] -> the pinned slot (trk_kernels.hip)
+    gm::launch_trk_results_to_host(t->stream, t->d_res, k.h, bytes, t->d_states, k.h + st_off, st_bytes);   // -> the pinned slot (trk_kernels.hip)
     const auto t4 = now();
     HIPC(hipEventRecord(k.done, t->stream));
     const auto t5 = now();
@@ -1969,18 +2031,22 @@ int gm_trk_update_all_async(gm_trk* t, gm_ring* ring, uint32_t max_epochs, uint6
     return GM_OK;
 }
 
-int gm_trk_collect(gm_trk* t, uint64_t ticket, int wait, gm_trk_out* outs, uint8_t* processed, uint8_t* lost, uint32_t* epochs_done,
-                   int* ready) {
+int gm_trk_collect(gm_trk* t, uint64_t ticket, int wait, gm_trk_out* outs, uint8_t* processed, uint8_t* lost, gm_trk_state* states,
+                   uint32_t* epochs_done, int* ready) {
     if (!t || !ticket || !ready) return set_err(GM_ERR_INVALID_ARG, "bad argument");
     gm_trk::Ticket& k = t->tk[ticket % gm_trk::TICKETS];
     if (!k.in_flight || k.id != ticket) return set_err(GM_ERR_INVALID_ARG, "no such ticket (collected already, or never issued)");
     if (int rc = ensure_device(t->device)) return rc;
     *ready = 0;
-    if (wait) HIPC(wait_event_polling(k.done));
-    else {
+    // contract (include/gnss_mi355x.h): a collect that returns an ERROR has consumed the ticket — the slot is released on hard HIP
+    // errors too, or it would be lost for good and every TICKETS-th asynchronous call refused from then on
+    if (wait) {
+        const hipError_t w = wait_event_polling(k.done);
+        if (w != hipSuccess) { k.in_flight = false; return hip_fail(w, "wait(ticket)"); }
+    } else {
         const hipError_t q = hipEventQuery(k.done);
         if (q == hipErrorNotReady) { (void)hipGetLastError(); return GM_OK; }
-        if (q != hipSuccess) return hip_fail(q, "hipEventQuery(ticket)");
+        if (q != hipSuccess) { k.in_flight = false; return hip_fail(q, "hipEventQuery(ticket)"); }
     }
     k.in_flight = false;
     if (int rc = trk_check_error(t)) return rc;
@@ -1988,6 +2054,7 @@ int gm_trk_collect(gm_trk* t, uint64_t ticket, int wait, gm_trk_out* outs, uint8
     if (outs) memcpy(outs, k.h, n * sizeof(gm_trk_out));
     if (processed) memcpy(processed, k.h + n * sizeof(gm_trk_out), n);
     if (lost) memcpy(lost, k.h + n * sizeof(gm_trk_out) + n, n);
+    if (states) memcpy(states, k.h + ((n * (sizeof(gm_trk_out) + 2) + 7) & ~size_t(7)), size_t(t->C) * sizeof(gm_trk_state));
     if (epochs_done) *epochs_done = trk_epochs_done(k.h + n * sizeof(gm_trk_out), k.epochs, t->C);
     *ready = 1;
     return GM_OK;

@@ -1438,16 +1438,22 @@ void launch_trk_epoch(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_code
 // host-mapped memory straight over the fabric, one launch, a fixed cost.  (The runtime's hipMemcpyAsync of the same bytes stalled the
 // calling thread ~7 ms five times in a 100-block receiver loop on the ROCm 7.0 runtime a PyTorch process brings along —
 // tools/receiver_time.py GM_TRK_TRACE_SLOW — and took three submissions where this takes one.)
-__global__ __launch_bounds__(256) void trk_results_to_host_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t words) {
-    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < words; i += size_t(gridDim.x) * 256)
-        __builtin_nontemporal_store(src[i], dst + i);
+__global__ __launch_bounds__(256) void trk_results_to_host_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t words,
+                                                                  const uint32_t* __restrict__ src2, uint32_t* __restrict__ dst2, size_t words2) {
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < words + words2; i += size_t(gridDim.x) * 256) {
+        if (i < words) __builtin_nontemporal_store(src[i], dst + i);
+        else __builtin_nontemporal_store(src2[i - words], dst2 + (i - words));
+    }
 }
-void launch_trk_results_to_host(hipStream_t st, const void* d_src, void* h_dst_pinned, size_t bytes) {
-    const size_t words = (bytes + 3) / 4;                      // (both blocks are allocated in multiples of 4 bytes)
-    if (!words) return;
-    const int blocks = int((words + 255) / 256 < 64 ? (words + 255) / 256 : 64);
+// a second range (the channel states behind the call's passes, ABI 7) travels in the same launch; d_src2 may be NULL
+void launch_trk_results_to_host(hipStream_t st, const void* d_src, void* h_dst_pinned, size_t bytes, const void* d_src2, void* h_dst2_pinned, size_t bytes2) {
+    const size_t words = (bytes + 3) / 4;                      // (the blocks are allocated in multiples of 4 bytes)
+    const size_t words2 = d_src2 ? (bytes2 + 3) / 4 : 0;
+    if (!(words + words2)) return;
+    const size_t wg = (words + words2 + 255) / 256;
+    const int blocks = int(wg < 64 ? wg : 64);
     hipLaunchKernelGGL(trk_results_to_host_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint32_t*>(d_src),
-                       static_cast<uint32_t*>(h_dst_pinned), words);
+                       static_cast<uint32_t*>(h_dst_pinned), words, static_cast<const uint32_t*>(d_src2), static_cast<uint32_t*>(h_dst2_pinned), words2);
 }
 
 }  // namespace gm

@@ -6,7 +6,9 @@
 #include <atomic>
 #include <chrono>
 #include <complex>
+#include <algorithm>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <map>
 #include <mutex>
@@ -197,6 +199,8 @@ public:
     // notifier / condvar (:42-43): true once head >= required_idx
     bool wait_head(uint64_t required_idx, uint32_t timeout_ms) const { int r = 0; check(gm_ring_wait_head(h_, required_idx, timeout_ms, &r), "wait_head"); return r != 0; }
     uint64_t get_head() const { uint64_t h = 0; check(gm_ring_get_head(h_, &h), "get_head"); return h; }
+    // what the asynchronous writer has ENQUEUED (>= get_head()): the head process_channels_async's passes are gated on
+    uint64_t get_enqueued_head() const { uint64_t h = 0; check(gm_ring_get_enqueued_head(h_, &h), "get_enqueued_head"); return h; }
     void copy_to_slice(uint64_t start, std::vector<Complex32>& dest) const {
         check(gm_ring_copy_to_slice(h_, start, reinterpret_cast<gm_c32*>(dest.data()), dest.size()), "copy_to_slice");
     }
@@ -222,6 +226,7 @@ public:
     explicit NavSyncStatus(int mode = GM_NAV_FAITHFUL) { check(gm_nav_sync_create(mode, &h_), "NavSyncStatus::new"); }
     ~NavSyncStatus() { gm_nav_sync_destroy(h_); }
     NavSyncStatus(const NavSyncStatus&) = delete;
+    gm_nav_sync* handle() const { return h_; }
     gm_nav_status update(float old_i_prompt, float i_prompt, uint64_t cnt, uint64_t buff_loc = 0) {
         gm_nav_status st{};
         check(gm_nav_sync_update(h_, old_i_prompt, i_prompt, cnt, buff_loc, &st), "nav_decoding");
@@ -304,22 +309,31 @@ public:
         return ticket;
     }
     // false while the call is still running (wait = false); else the passes in which a channel ran through *done
+    // states: the channel records as they stood behind THAT call's passes (a device-side snapshot in stream order)
     bool collect(uint64_t ticket, bool wait, uint32_t* done = nullptr, std::vector<CorrelatorOut>* outs = nullptr,
-                 std::vector<uint8_t>* processed = nullptr, std::vector<uint8_t>* lost = nullptr) {
+                 std::vector<uint8_t>* processed = nullptr, std::vector<uint8_t>* lost = nullptr,
+                 std::vector<gm_trk_state>* states = nullptr) {
         const auto it = pending_.find(ticket);
         if (it == pending_.end()) throw Panic(GM_ERR_INVALID_ARG, "collect: no such ticket");
         const size_t n = size_t(it->second) * n_;
         if (outs) outs->resize(n);
         if (processed) processed->resize(n);
         if (lost) lost->resize(n);
+        if (states) states->resize(n_);
         int ready = 0; uint32_t d = 0;
-        check(gm_trk_collect(h_, ticket, wait ? 1 : 0, outs ? outs->data() : nullptr, processed ? processed->data() : nullptr,
-                             lost ? lost->data() : nullptr, &d, &ready), "collect");
+        const int rc = gm_trk_collect(h_, ticket, wait ? 1 : 0, outs ? outs->data() : nullptr, processed ? processed->data() : nullptr,
+                                      lost ? lost->data() : nullptr, states ? states->data() : nullptr, &d, &ready);
+        if (rc != GM_OK) { pending_.erase(it); check(rc, "collect"); }      // a failed collect has consumed the ticket (header)
         if (!ready) return false;
         pending_.erase(it);
         if (done) *done = d;
         return true;
     }
+    size_t tickets_in_flight() const { return pending_.size(); }
+    uint32_t n_channels() const { return n_; }
+    uint32_t pass_count(uint64_t ticket) const { const auto it = pending_.find(ticket); return it == pending_.end() ? 0 : it->second; }
+    // every channel's record in one synchronisation + one copy (ABI 7)
+    std::vector<gm_trk_state> states() const { std::vector<gm_trk_state> s(n_); check(gm_trk_get_states(h_, s.data()), "states"); return s; }
 private:
     std::map<uint64_t, uint32_t> pending_;      // ticket -> its pass count
 };
@@ -345,13 +359,32 @@ struct StageControl {
     std::atomic<bool> stop{false};
     double pacing_scale = 1.0;            // 1.0 = the reference's 500 / 1000 / 2000 ms search intervals (:59-63)
     std::atomic<uint64_t> acq_rounds{0}, trk_passes{0};
+    // round 6: what a feeder that replays faster than real time needs for flow control, and what a harness reports
+    std::atomic<uint64_t> trk_collected_head{0};   // ring head up to which the tracking stage's passes have run AND been collected
+    std::atomic<uint64_t> channel_epochs{0};       // channel x code-period updates collected so far
+    std::atomic<uint64_t> acq_ns{0}, fine_ns{0}, trk_ns{0}, hook_ns{0};   // wall clock spent inside the stages' calls
+    std::atomic<bool> trk_finished{false};         // the tracking stage has collected its last call (its handles are torn down after this)
+    std::atomic<int> stages_ready{0};              // + 1 by each stage once its handles exist (tables, code spectra, result slots): a
+                                                   // replay that outruns real time starts its feeder when both stages are listening
 };
+inline uint64_t stage_ns(std::chrono::steady_clock::time_point t0) {
+    return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+}
 
 struct AcquisitionRunOptions {            // the reference's compile-time constants (:20-23) as run-time values
     float freq_search_hz = 14e3f;         // FREQ_SEARCH_ACQUISITION_HZ
     float freq_step_hz = 500.0f;          // FREQ_SEARCH_STEP_HZ
     uint32_t long_samples_length = 10;    // LONG_SAMPLES_LENGTH (ms)
     int decision_mode = GM_DECIDE_REFERENCE;
+    // The reference paces its rounds on the wall clock (:292-295), which IS signal time for a live source.  A replay that runs
+    // faster (or slower) than real time keeps the reference's cadence per second of SIGNAL with this switch: the interval is
+    // counted in samples of the ring's head.  first_round_signal_ms < 0: the reference's behaviour (the first round after one
+    // interval, `last_run = Instant::now()` at :274); >= 0: the first round once that much signal is in the ring.
+    bool pace_on_signal_time = false;
+    double first_round_signal_ms = -1.0;
+    // refine every hit's carrier (finer_doppler, acquisition_bk.rs:215-302) before it goes to tracking
+    bool fine_doppler = false;
+    std::function<void(uint64_t head, const std::vector<std::optional<AcquisitionResult>>&)> on_round;   // after every round (may be empty)
 };
 
 inline void run_acquisition(MulticastRingBuffer& multi_buffer, float freq_sampling_hz, float f_if,
@@ -367,8 +400,13 @@ inline void run_acquisition(MulticastRingBuffer& multi_buffer, float freq_sampli
                               opt.decision_mode);                                                            // :252-271
     std::set<uint8_t> active_prns;
     AcquisitionManager acq_manager;
+    ctl.stages_ready++;
     auto last_run = std::chrono::steady_clock::now();
     const auto ms = [&](double v) { return std::chrono::duration<double, std::milli>(v * ctl.pacing_scale); };
+    // signal-time pacing: the head (in samples) at which the next round is due
+    const double samples_per_ms = double(freq_sampling_hz) * 1e-3;
+    uint64_t next_due = opt.first_round_signal_ms >= 0.0 ? uint64_t(opt.first_round_signal_ms * samples_per_ms) : 0;
+    bool first = true;
     while (!ctl.stop.load()) {
         while (auto msg = from_tracking.try_recv()) {                                                       // :278-287
             if (msg->kind == TrackingMessageKind::SatelliteLost) active_prns.erase(msg->prn);
@@ -376,66 +414,249 @@ inline void run_acquisition(MulticastRingBuffer& multi_buffer, float freq_sampli
         }
         acq_manager.update_mode(active_prns.size());                                                        // :289
         auto [interval_ms, mask] = acq_manager.get_pacing_and_list(active_prns);                            // :290
-        if (std::chrono::steady_clock::now() - last_run < ms(double(interval_ms))) {                        // :292-295
+        if (opt.pace_on_signal_time) {
+            if (first && opt.first_round_signal_ms < 0.0) next_due = uint64_t(double(interval_ms) * ctl.pacing_scale * samples_per_ms);
+            first = false;
+            if (int64_t(multi_buffer.get_head() - next_due) < 0) {                                          // :292-295 in samples
+                multi_buffer.wait_head(next_due, 2);         // the ring's Condvar, bounded so that `stop` is seen
+                continue;
+            }
+        } else if (std::chrono::steady_clock::now() - last_run < ms(double(interval_ms))) {                 // :292-295
             std::this_thread::sleep_for(ms(50.0));
             continue;
         }
         uint64_t local_tail = 0;
+        auto t0 = std::chrono::steady_clock::now();
         auto results = workers.search_ring(multi_buffer.handle(), uint64_t(mask), &local_tail);             // :297-313
+        ctl.acq_ns += stage_ns(t0);
         if (!results) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }              // :324-326
+        const uint64_t head_of_round = local_tail + uint64_t(opt.long_samples_length) * fft_size;
+        if (opt.fine_doppler) {
+            // hits on satellites that are tracked already go nowhere (:315-320 would hand them over again; the mask
+            // normally excludes them) — refine only what is about to start a channel
+            bool any = false;
+            for (auto& r : *results) { if (r && active_prns.count(r->prn)) r.reset(); any = any || bool(r); }
+            if (any) {
+                t0 = std::chrono::steady_clock::now();
+                const std::vector<float> fine = workers.finer_doppler(*results);
+                for (size_t i = 0; i < results->size(); ++i)
+                    if ((*results)[i] && std::isfinite(fine[i])) (*results)[i]->carrier_freq = fine[i];
+                ctl.fine_ns += stage_ns(t0);
+            }
+        }
         for (auto& r : *results)                                                                            // :315-320
             if (r && to_tracking.send(*r)) active_prns.insert(r->prn);
+        if (opt.on_round) opt.on_round(head_of_round, *results);
         last_run = std::chrono::steady_clock::now();                                                        // :322
+        // the NEXT interval is the one the manager gives for the satellites just handed over (as the loop head would compute it)
+        acq_manager.update_mode(active_prns.size());
+        next_due = head_of_round + uint64_t(double(acq_manager.get_pacing_and_list(active_prns).first) * ctl.pacing_scale * samples_per_ms);
         ctl.acq_rounds++;
     }
 }
 
+// What one collected call of the tracking stage hands to a consumer behind it (nav-bit accumulation, logging): the passes'
+// correlator outputs and flags, [passes][n_channels], and the ring head the call was gated on.
+struct EpochBlock {
+    uint32_t passes = 0, n_channels = 0;
+    uint64_t head = 0;
+    const CorrelatorOut* outs = nullptr;
+    const uint8_t* processed = nullptr;
+    const uint8_t* lost = nullptr;
+    const gm_trk_state* states = nullptr;       // [n_channels], as they stood behind this call's passes (NULL on the synchronous path)
+    const uint8_t* channel_prn = nullptr;       // [n_channels] the PRN each channel was started with (0: never started)
+};
+
+struct TrackingRunOptions {
+    int code_index_mode = GM_CODE_INDEX_FIXED;
+    uint32_t n_channels = 15;                   // NUM_OF_CHANNELS (:18)
+    // true (default): no host wait per block — process_channels is ENQUEUED behind whatever the ring's writer has enqueued
+    // (gm_trk_update_all_async: the Condvar wait of :392-406 as an event on the ring's stream) and collected a block or two later;
+    // false: the synchronous pass per loop turn (rounds 3-5)
+    bool async_tickets = true;
+    uint32_t max_in_flight = 6;                 // tickets not yet collected (the library holds 8 result slots)
+    uint32_t max_passes_per_call = 256;         // the result slots are sized for this once, before the loop (they cannot grow under tickets in flight)
+    bool share_device = true;                   // a receiver: leave CUs to the front-end and the acquisition dwell (gm_trk_cfg.share_device)
+    bool drain_on_stop = true;                  // after `stop`: hand over pending acquisitions and run every whole code period the ring still holds
+    std::function<void(const EpochBlock&)> on_epochs;      // every collected call (may be empty)
+    std::vector<gm_trk_state>* final_states = nullptr;
+};
+
+namespace detail {
+// passes needed so that every active channel reaches `head`: channels advance one code period per pass
+inline uint32_t passes_to_head(const std::vector<gm_trk_state>& st, const std::vector<uint8_t>& busy, uint64_t head,
+                               const std::vector<uint64_t>& covered) {
+    uint64_t worst = 0;
+    for (size_t c = 0; c < st.size(); ++c) {
+        if (!busy[c] || !st[c].num_samples_per_code) continue;
+        const uint64_t n = st[c].num_samples_per_code;
+        uint64_t idx = st[c].next_sample_index;
+        // passes already enqueued for this channel (not yet collected) take it to the last whole period before covered[c]
+        if (int64_t(covered[c] - idx) > 0) idx += ((covered[c] - idx) / n) * n;
+        if (int64_t(head - idx) > 0) worst = std::max<uint64_t>(worst, (head - idx) / n);
+    }
+    return uint32_t(std::min<uint64_t>(worst + 2, 4095));    // + 2: the period length moves by a sample now and then (code_rate)
+}
+}  // namespace detail
+
 inline void run_tracking(MulticastRingBuffer& multi_ring_buf, Channel<AcquisitionResult>& acq_to_trk,
-                         Channel<TrackingMessage>& trk_to_acq, float fs, StageControl& ctl,
-                         int code_index_mode = GM_CODE_INDEX_FIXED, uint32_t n_channels = 15,
-                         std::vector<gm_trk_state>* final_states = nullptr) {
-    TrackingManager manager(fs, n_channels, code_index_mode);                                               // :390
-    std::vector<uint8_t> channel_prn(n_channels, 0), lost;
+                         Channel<TrackingMessage>& trk_to_acq, float fs, StageControl& ctl, const TrackingRunOptions& opt) {
+    const uint32_t n_channels = opt.n_channels;
+    TrackingManager manager(fs, n_channels, opt.code_index_mode, 3, false, false, opt.share_device);        // :390
+    std::vector<uint8_t> channel_prn(n_channels, 0), busy(n_channels, 0), lost, processed;
+    std::vector<CorrelatorOut> outs;
+    std::vector<gm_trk_state> states = manager.states(), snap;       // host view of the channels: exact whenever nothing is in flight
+    struct Pending { uint64_t ticket, head, seq; };
+    std::deque<Pending> tickets;
+    uint64_t issued = 0;                                             // calls enqueued so far
+    std::vector<uint64_t> start_seq(n_channels, 0);                  // `issued` when the channel was started: older snapshots predate it
+    std::vector<uint64_t> covered(n_channels, 0);                    // the head up to which passes for this channel have been enqueued
+    uint64_t planned_head = multi_ring_buf.get_enqueued_head();      // the head the most recent enqueued call was gated on
+    ctl.trk_collected_head = planned_head;
     constexpr uint32_t LOOP_MS = 10;                                                                        // :29
-    while (!ctl.stop.load()) {
-        // process_channels (:351-371): hand new acquisitions to idle channels ...
+    const bool want_outs = bool(opt.on_epochs);
+    const uint32_t max_passes = std::max<uint32_t>(opt.max_passes_per_call, 3);
+    if (opt.async_tickets)      // one empty call of the largest size: pinned result slots, copy path and events exist before the first block
+        manager.collect(manager.process_channels_async(multi_ring_buf, max_passes), true);
+    ctl.stages_ready++;
+
+    // process_channels' first half (:352-362): hand new acquisitions to idle channels
+    const auto take_acquisitions = [&] {
         while (auto msg = acq_to_trk.try_recv()) {
             for (uint32_t c = 0; c < n_channels; ++c) {
-                if (!manager.channels[c].is_active()) {
-                    trk_to_acq.send(TrackingMessage{TrackingMessageKind::SatelliteLocked, msg->prn});
-                    manager.channels[c].start(*msg);
-                    channel_prn[c] = msg->prn;
-                    break;
-                }
+                if (busy[c]) continue;
+                trk_to_acq.send(TrackingMessage{TrackingMessageKind::SatelliteLocked, msg->prn});
+                manager.channels[c].start(*msg);       // (waits for the passes in flight: a hand-over, a few per minute)
+                states[c] = manager.channels[c].state();
+                busy[c] = 1; channel_prn[c] = msg->prn;
+                start_seq[c] = issued; covered[c] = states[c].next_sample_index;
+                break;
             }
         }
-        // ... then every active channel with a whole code period available runs update(), up to LOOP_MS passes
-        const uint32_t done = manager.process_channels(multi_ring_buf, LOOP_MS, nullptr, nullptr, &lost);
-        for (uint32_t e = 0; e < LOOP_MS; ++e)
-            for (uint32_t c = 0; c < n_channels; ++c)
+    };
+    const auto report = [&](uint32_t passes, uint32_t done, uint64_t head, const gm_trk_state* st) {
+        uint64_t ran = 0;
+        for (uint32_t e = 0; e < passes; ++e)
+            for (uint32_t c = 0; c < n_channels; ++c) {
+                ran += processed[size_t(e) * n_channels + c];
                 if (lost[size_t(e) * n_channels + c]) {
                     // the reference's message carries prn 0 (reset() runs first, :199-201); FIXED reports the real one
-                    const uint8_t prn = code_index_mode == GM_CODE_INDEX_FAITHFUL ? uint8_t(0) : channel_prn[c];
+                    const uint8_t prn = opt.code_index_mode == GM_CODE_INDEX_FAITHFUL ? uint8_t(0) : channel_prn[c];
                     trk_to_acq.send(TrackingMessage{TrackingMessageKind::SatelliteLost, prn});
+                    busy[c] = 0;
                 }
-        ctl.trk_passes += done;
-        if (done == 0) {                                                                // Condvar wait (:392-406)
+            }
+        ctl.trk_passes += done; ctl.channel_epochs += ran;
+        if (opt.on_epochs) {
+            const auto t0 = std::chrono::steady_clock::now();
+            EpochBlock b; b.passes = passes; b.n_channels = n_channels; b.head = head; b.outs = outs.data();
+            b.processed = processed.data(); b.lost = lost.data(); b.states = st; b.channel_prn = channel_prn.data();
+            opt.on_epochs(b);
+            ctl.hook_ns += stage_ns(t0);
+        }
+        ctl.trk_collected_head = head;
+    };
+    // collect what is ready (everything, waiting, when `all`); true if a call was collected
+    const auto drain = [&](bool all) {
+        bool got = false;
+        while (!tickets.empty()) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const uint32_t passes = manager.pass_count(tickets.front().ticket);
+            uint32_t done = 0;
+            const bool ready = manager.collect(tickets.front().ticket, all || tickets.size() >= opt.max_in_flight, &done,
+                                               want_outs ? &outs : nullptr, &processed, &lost, &snap);
+            ctl.trk_ns += stage_ns(t0);
+            if (!ready) break;
+            const uint64_t head = tickets.front().head, seq = tickets.front().seq;
+            tickets.pop_front();
+            // the collected snapshot is the truth for every channel that was not (re)started after that call was enqueued
+            for (uint32_t c = 0; c < n_channels; ++c)
+                if (seq >= start_seq[c]) states[c] = snap[c];
+            report(passes, done, head, snap.data());
+            got = true;
+        }
+        return got;
+    };
+
+    bool stopping = false;
+    for (;;) {
+        if (!stopping && ctl.stop.load()) { stopping = true; if (!opt.drain_on_stop) break; }
+        take_acquisitions();
+        bool any_active = false;
+        for (uint32_t c = 0; c < n_channels; ++c) any_active = any_active || busy[c];
+        bool progressed = false;
+        if (opt.async_tickets) {
+            const uint64_t head = multi_ring_buf.get_enqueued_head();
+            if (any_active && tickets.size() < opt.max_in_flight) {
+                const uint32_t passes = std::min(detail::passes_to_head(states, busy, head, covered), max_passes);
+                if (passes > 2 || (stopping && tickets.empty())) {      // > 2: at least one whole code period is there for some channel
+                    const auto t0 = std::chrono::steady_clock::now();
+                    tickets.push_back(Pending{manager.process_channels_async(multi_ring_buf, passes), head, issued++});
+                    ctl.trk_ns += stage_ns(t0);
+                    planned_head = head;
+                    for (uint32_t c = 0; c < n_channels; ++c) {         // how far this call takes each channel (all the way unless capped)
+                        if (!busy[c] || !states[c].num_samples_per_code) continue;
+                        const uint64_t n = states[c].num_samples_per_code;
+                        uint64_t idx = states[c].next_sample_index;
+                        if (int64_t(covered[c] - idx) > 0) idx += ((covered[c] - idx) / n) * n;
+                        const uint64_t reach = idx + uint64_t(passes) * n;
+                        covered[c] = int64_t(reach - head) < 0 ? reach : head;
+                    }
+                    progressed = true;
+                }
+            }
+            const size_t before = tickets.size();
+            const uint64_t passes_before = ctl.trk_passes.load();
+            progressed = drain(stopping) || progressed;
+            if (stopping) {
+                // done when a drained call found nothing left to run and nothing new is waiting
+                if (tickets.empty() && before && ctl.trk_passes.load() == passes_before && acq_to_trk.len() == 0) break;
+                if (!any_active && acq_to_trk.len() == 0) break;
+                continue;
+            }
+            if (!any_active) ctl.trk_collected_head = head;       // nothing to track: the feeder is not held back
+        } else {
+            // ... every active channel with a whole code period available runs update(), up to LOOP_MS passes, synchronously
+            const auto t0 = std::chrono::steady_clock::now();
+            const uint64_t head = multi_ring_buf.get_head();
+            const uint32_t done = manager.process_channels(multi_ring_buf, LOOP_MS, want_outs ? &outs : nullptr, &processed, &lost);
+            ctl.trk_ns += stage_ns(t0);
+            report(LOOP_MS, done, head, nullptr);
+            progressed = done != 0;
+            if (stopping) { if (!done && acq_to_trk.len() == 0) break; continue; }
+            if (!done) states = manager.states();                 // next_tracking_index (:373-381) needs the current records
+        }
+        if (!progressed && opt.async_tickets && !tickets.empty()) {
+            // calls in flight: their completion and the writer's next ENQUEUED block are what this thread reacts to — neither moves
+            // the published head's Condvar, so look again shortly (one ticket per writer block keeps the collected head a few
+            // blocks behind the writer instead of a ticket's worth of blocks)
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        } else if (!progressed) {                                                       // Condvar wait (:392-406)
             uint64_t required_idx = 0; bool any = false;                                // next_tracking_index (:373-381)
             for (uint32_t c = 0; c < n_channels; ++c) {
-                const gm_trk_state st = manager.channels[c].state();
-                if (!st.active) continue;
-                const uint64_t need = st.next_sample_index + st.num_samples_per_code;
-                if (!any || need < required_idx) required_idx = need;
+                if (!busy[c] || !states[c].active) continue;
+                uint64_t need = states[c].next_sample_index + states[c].num_samples_per_code;
+                if (opt.async_tickets && int64_t(planned_head - need) >= 0) need = planned_head + states[c].num_samples_per_code;
+                if (!any || int64_t(need - required_idx) < 0) required_idx = need;
                 any = true;
             }
             if (any) multi_ring_buf.wait_head(required_idx, 2);     // bounded so that `stop` and new acquisitions are seen
             else std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
     }
-    if (final_states) {
-        final_states->resize(n_channels);
-        for (uint32_t c = 0; c < n_channels; ++c) (*final_states)[c] = manager.channels[c].state();
-    }
+    while (!tickets.empty()) drain(true);
+    ctl.trk_finished = true;
+    if (opt.final_states) *opt.final_states = manager.states();
+}
+
+// the signature of rounds 3-5 (tests/cpp/test_host_api.cpp): the default options, i.e. the ticket loop
+inline void run_tracking(MulticastRingBuffer& multi_ring_buf, Channel<AcquisitionResult>& acq_to_trk,
+                         Channel<TrackingMessage>& trk_to_acq, float fs, StageControl& ctl,
+                         int code_index_mode = GM_CODE_INDEX_FIXED, uint32_t n_channels = 15,
+                         std::vector<gm_trk_state>* final_states = nullptr) {
+    TrackingRunOptions opt;
+    opt.code_index_mode = code_index_mode; opt.n_channels = n_channels; opt.final_states = final_states;
+    run_tracking(multi_ring_buf, acq_to_trk, trk_to_acq, fs, ctl, opt);
 }
 
 // ---- crate root FFT<T> / RealFFT<T> (src/fft.rs:5-56), T = f32

@@ -74,6 +74,12 @@ class MulticastRingBuffer:
         check(lib().gm_ring_get_head(self._h, C.byref(h)), "get_head")
         return h.value
 
+    def get_enqueued_head(self):
+        """what the asynchronous writer has enqueued so far (>= get_head()): the head update_all_async's passes are gated on"""
+        h = C.c_uint64(0)
+        check(lib().gm_ring_get_enqueued_head(self._h, C.byref(h)), "get_enqueued_head")
+        return h.value
+
     def copy_to_slice(self, start, n):
         d = np.zeros(n, np.complex64)
         check(lib().gm_ring_copy_to_slice(self._h, int(start), _p(d), n), "copy_to_slice")
@@ -141,24 +147,42 @@ class TrackingManager:
         self._ticket_epochs[tok.value] = int(max_epochs)
         return tok.value
 
-    def collect(self, ticket, wait=False):
-        """-> None while the call is still running (wait = False), else update_all's (outs, processed, lost, epochs_done)"""
+    def collect(self, ticket, wait=False, with_states=False):
+        """-> None while the call is still running (wait = False), else update_all's (outs, processed, lost, epochs_done)
+        (+ the list of channel states as they stood behind that call's passes when with_states)"""
         if ticket not in getattr(self, "_ticket_epochs", {}):      # let the library say so (GM_ERR_INVALID_ARG)
             ready = C.c_int(0)
-            check(lib().gm_trk_collect(self._h, int(ticket), int(bool(wait)), None, None, None, None, C.byref(ready)), "gm_trk_collect")
+            check(lib().gm_trk_collect(self._h, int(ticket), int(bool(wait)), None, None, None, None, None, C.byref(ready)), "gm_trk_collect")
             raise KeyError(ticket)
         E, Cn = self._ticket_epochs[ticket], self.n_channels
         outs = (TrkOut * (E * Cn))()
         proc = np.zeros((E, Cn), np.uint8)
         lost = np.zeros((E, Cn), np.uint8)
         done, ready = C.c_uint32(0), C.c_int(0)
-        check(lib().gm_trk_collect(self._h, int(ticket), int(bool(wait)), C.cast(outs, C.c_void_p), _p(proc), _p(lost), C.byref(done),
-                                   C.byref(ready)), "gm_trk_collect")
+        states = (TrkState * Cn)() if with_states else None
+        rc = lib().gm_trk_collect(self._h, int(ticket), int(bool(wait)), C.cast(outs, C.c_void_p), _p(proc), _p(lost),
+                                  C.cast(states, C.c_void_p) if with_states else None, C.byref(done), C.byref(ready))
+        if rc != 0:
+            del self._ticket_epochs[ticket]          # a failed collect has consumed the ticket (include/gnss_mi355x.h)
+            check(rc, "gm_trk_collect")
         if not ready.value:
             return None
         del self._ticket_epochs[ticket]
         o = np.frombuffer(outs, np.float32).reshape(E, Cn, 10)[:, :, :2 * self.n_arms].copy()
+        if with_states:
+            return o, proc, lost, done.value, list(states)
         return o, proc, lost, done.value
+
+    def get_states(self):
+        """every channel's record in one call (gm_trk_get_states)"""
+        states = (TrkState * self.n_channels)()
+        check(lib().gm_trk_get_states(self._h, C.cast(states, C.c_void_p)), "gm_trk_get_states")
+        return list(states)
+
+    def set_states(self, states, which=None):
+        arr = (TrkState * self.n_channels)(*states)
+        w = None if which is None else np.ascontiguousarray(which, np.uint8)
+        check(lib().gm_trk_set_states(self._h, C.cast(arr, C.c_void_p), _p(w) if w is not None else None), "gm_trk_set_states")
 
     def update_all_dev(self, ring, epochs):
         check(lib().gm_trk_update_all_dev(self._h, ring._h, int(epochs)), "gm_trk_update_all_dev")

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define GM_ABI_VERSION 6   /* 6: gm_acq_prepare_dev returns a token, gm_acq_search_prepared_dev / gm_acq_drop_prepared (round 5) */
+#define GM_ABI_VERSION 7   /* 7: gm_trk_collect hands over the channel states, gm_trk_get_states / gm_trk_set_states,
+                              gm_ring_get_enqueued_head (round 6); 6: gm_acq_prepare_dev returns a token (round 5) */
 
 typedef enum {
     GM_OK = 0,
@@ -311,6 +312,10 @@ int gm_ring_copy_to_slice(gm_ring *r, uint64_t start, gm_c32 *dest, size_t n); /
  * held the stream, i.e. the next block, until the runtime's callback thread woke up: milliseconds, now and then). */
 int gm_ring_write_samples_async(gm_ring *r, const gm_c32 *samples, size_t n);
 int gm_ring_flush(gm_ring *r);
+/* What the asynchronous writer has ENQUEUED so far (>= gm_ring_get_head, which counts what has landed): the head that
+ * gm_trk_update_all_async's passes are gated on, i.e. what a stage driver that never waits for the copies plans its pass count
+ * from.  Equal to the head for a ring that is written synchronously.  ABI 7. */
+int gm_ring_get_enqueued_head(gm_ring *r, uint64_t *head);
 /* The notifier/Condvar of the reference ring (:42-43, :94-98) as used by do_tracking::run (do_tracking.rs:392-406):
  * sleep until head >= required_idx (wrapping signed comparison) or timeout_ms elapsed; *reached = 1 / 0. */
 int gm_ring_wait_head(gm_ring *r, uint64_t required_idx, uint32_t timeout_ms, int *reached);
@@ -412,6 +417,11 @@ int gm_trk_start(gm_trk *t, uint32_t ch, const gm_acq_result *r);
 int gm_trk_reset(gm_trk *t, uint32_t ch);                              /* ::reset :311-327 */
 int gm_trk_get_state(gm_trk *t, uint32_t ch, gm_trk_state *out);
 int gm_trk_set_state(gm_trk *t, uint32_t ch, const gm_trk_state *in);
+/* All n_channels records in ONE synchronisation + ONE copy (ABI 7) — what a manager that mirrors the channels' pub fields
+ * (TrackingManager.channels, do_tracking.rs:329-333) calls once per pass instead of 2 x n_channels single-channel calls.
+ * which: NULL = every channel, else [n_channels] flags — only flagged channels are written (the others keep the device's words). */
+int gm_trk_get_states(gm_trk *t, gm_trk_state *out);
+int gm_trk_set_states(gm_trk *t, const gm_trk_state *in, const uint8_t *which);
 /* get_ca_chip(phase) :274-277 for channel ch (host-side table look-up with the configured mode). */
 int gm_trk_get_ca_chip(gm_trk *t, uint32_t ch, float phase, float *chip);
 /* LoopFilter::new / ::update (:52-71), host-side scalars. */
@@ -443,12 +453,16 @@ int gm_trk_update_all_dev(gm_trk *t, gm_ring *ring, uint32_t epochs);
  * head — the host neither waits for the samples to land nor for the passes to run.  Results ([outs | processed | lost] as in
  * gm_trk_update_all) land in one of 8 pinned slots; *ticket (never 0) names the call.
  * gm_trk_collect(ticket, wait, ...): wait = 0 -> *ready = 0 and nothing else when the call has not finished; otherwise the results
- * are handed over (any of outs / processed / lost / epochs_done may be NULL), *ready = 1 and the slot is free again.  Tickets are
+ * are handed over (any of outs / processed / lost / states / epochs_done may be NULL), *ready = 1 and the slot is free again.
+ * states (ABI 7): [n_channels] records as they stood when THIS call's passes had run (a snapshot taken on the device in stream
+ * order, whatever has been enqueued behind it) — the pub fields a manager shows for that moment, without a synchronisation.  Tickets are
  * collected in any order; a call is refused (GM_ERR_OUT_OF_RANGE, nothing launched) while the ticket issued eight calls earlier —
- * whose slot it would take — has not been collected.
+ * whose slot it would take — has not been collected.  A collect that returns an ERROR (a HIP failure of the wait, an exchange
+ * time-out reported by the kernel) has CONSUMED the ticket: its slot is free, its results are gone, a second collect of it is
+ * GM_ERR_INVALID_ARG; wrappers drop their record of a ticket whenever the library returns an error for it.
  * Same channel states and sums as the synchronous entry, bit for bit (tests/test_gpu_pipeline.py). */
 int gm_trk_update_all_async(gm_trk *t, gm_ring *ring, uint32_t max_epochs, uint64_t *ticket);
-int gm_trk_collect(gm_trk *t, uint64_t ticket, int wait, gm_trk_out *outs, uint8_t *processed, uint8_t *lost,
+int gm_trk_collect(gm_trk *t, uint64_t ticket, int wait, gm_trk_out *outs, uint8_t *processed, uint8_t *lost, gm_trk_state *states,
                    uint32_t *epochs_done, int *ready);
 int gm_trk_synchronize(gm_trk *t);
 /* The handle's own stream is created at the device's HIGHEST priority: the tracking loop is the receiver's latency path (one short

@@ -90,6 +90,9 @@ extern "C" {
     pub fn gm_ring_destroy(r: *mut GmRing) -> c_int;
     pub fn gm_ring_write_samples(r: *mut GmRing, s: *const Complex32, n: usize) -> c_int;
     pub fn gm_ring_get_head(r: *mut GmRing, head: *mut u64) -> c_int;
+    pub fn gm_ring_write_samples_async(r: *mut GmRing, s: *const Complex32, n: usize) -> c_int;
+    pub fn gm_ring_flush(r: *mut GmRing) -> c_int;
+    pub fn gm_ring_get_enqueued_head(r: *mut GmRing, head: *mut u64) -> c_int;
     // do_tracking.rs:118-158, 311-327
     pub fn gm_trk_create(cfg: *const GmTrkCfg, out: *mut *mut GmTrk) -> c_int;
     pub fn gm_trk_destroy(t: *mut GmTrk) -> c_int;
@@ -109,8 +112,12 @@ extern "C" {
                              processed: *mut u8, lost: *mut u8, epochs_done: *mut u32) -> c_int;
     /// the same passes ordered on the DEVICE behind what the ring's writer has enqueued (the Condvar wait of :392-406 without a host wait)
     pub fn gm_trk_update_all_async(t: *mut GmTrk, ring: *mut GmRing, max_epochs: u32, ticket: *mut u64) -> c_int;
+    /// states (ABI 7): the channel records as they stood behind THAT call's passes; a collect that fails has consumed the ticket
     pub fn gm_trk_collect(t: *mut GmTrk, ticket: u64, wait: c_int, outs: *mut GmTrkOut, processed: *mut u8, lost: *mut u8,
-                          epochs_done: *mut u32, ready: *mut c_int) -> c_int;
+                          states: *mut GmTrkState, epochs_done: *mut u32, ready: *mut c_int) -> c_int;
+    /// every channel's record in one synchronisation + one copy; `which`: NULL = all, else per-channel flags
+    pub fn gm_trk_get_states(t: *mut GmTrk, out: *mut GmTrkState) -> c_int;
+    pub fn gm_trk_set_states(t: *mut GmTrk, states: *const GmTrkState, which: *const u8) -> c_int;
     // fft.rs:5-56
     pub fn gm_fft_c2c_f32(n: usize, dir: c_int, inout: *mut Complex32, batch: usize) -> c_int;
     pub fn gm_fft_power_spectrum_f32(n: usize, inout: *mut Complex32, power: *mut f32) -> c_int;

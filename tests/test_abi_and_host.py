@@ -82,7 +82,7 @@ def test_null_handles_are_refused_not_dereferenced(gm):
     # the asynchronous tracking entries (ABI 6): null handle / ring / ticket pointer, ticket 0, null `ready`
     tok, ready = C.c_uint64(7), C.c_int(5)
     assert L.gm_trk_update_all_async(None, None, 4, C.byref(tok)) == -1 and tok.value == 7
-    assert L.gm_trk_collect(None, 1, 1, None, None, None, None, C.byref(ready)) == -1 and ready.value == 5
+    assert L.gm_trk_collect(None, 1, 1, None, None, None, None, None, C.byref(ready)) == -1 and ready.value == 5
     assert b"bad argument" in L.gm_last_error()
 
 
@@ -378,3 +378,25 @@ def test_beidou_b1i_codes_known_properties(gm):
             if i == j:
                 assert cc[0] == 2047
     assert vals == {-65, -1, 63}
+
+
+def test_receiver_harness_loads_and_fails_loudly_without_a_device(gm):
+    """host/receiver_harness.cpp (the C++ stage drivers behind an extern "C" surface, what bench.py's receiver leg times): the
+    library is built by build(), exports its four entries, links the product library and nothing of the oracle, and — no CPU
+    fallback — returns GM_ERR_NO_DEVICE on a box without a GPU."""
+    from gnss_sdr_rs_amd import receiver as R
+    L = R.lib()
+    assert L.gmrx_abi_version() == 1
+    nm = subprocess.run(["nm", "-D", "--defined-only", R.library_path()], stdout=subprocess.PIPE, text=True).stdout
+    assert set(re.findall(r" T (gmrx_[a-z0-9_]+)", nm)) == {"gmrx_abi_version", "gmrx_last_error", "gmrx_receiver_run", "gmrx_tracking_ab"}
+    out = subprocess.run(["ldd", R.library_path()], stdout=subprocess.PIPE, text=True).stdout
+    assert "libgnss_mi355x.so" in out and "liboracle" not in out and "torch" not in out
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, ctypes as C; import gnss_sdr_rs_amd as g;"
+            "from gnss_sdr_rs_amd import receiver as R; L = g.lib(); n = C.c_int(0); L.gm_device_count(C.byref(n));\n"
+            "try:\n    R.receiver_run(np.zeros(2 * 4096, np.int8), 4.096e6, 0.0, warmup_calls=0); print(n.value, 0)\n"
+            "except g.GmError as e:\n    print(n.value, e.status)") % ROOT
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    ndev, rc = r.stdout.split()[-2:]
+    if int(ndev) == 0:
+        assert int(rc) == -3, r.stdout + r.stderr

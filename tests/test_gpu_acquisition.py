@@ -653,8 +653,8 @@ def test_prepare_dev_is_safe_to_misuse(gpu, hipbuf, N, fmt_name):
     assert hip.hipMemcpyAsync(d_big, big.ctypes.data, big.nbytes, 1, s_copy) == 0     # pageable: staged, takes a while
     assert hip.hipMemcpyAsync(d_buf, snaps[0].ctypes.data, nbytes, 1, s_copy) == 0
     tok = eng.prepare_dev(d_buf, fmt, ready_stream=s_copy.value)
-    if composite:
-        assert hip.hipStreamSynchronize(s_copy) == 0          # (composite: the search itself reads the buffer: the caller orders it)
+    # (composite sizes prepare nothing — the search itself reads the buffer — but keep the promise: the event recorded on
+    # ready_stream at prepare time is what the search waits for on the handle's stream; no host synchronisation here)
     eng.search_prepared_dev(tok, d_met)
     assert (words_now() == want[0]).all()
     assert hip.hipStreamSynchronize(s_copy) == 0 and hip.hipStreamDestroy(s_copy) == 0
@@ -688,16 +688,22 @@ def test_back_to_back_dwell_entries_with_options_and_mask_changes(gpu, hipbuf, o
     seq = [(0, 0), (1, 1), (1, 2), (0, 1), (1, 0), (0, 2)]
     got = []
     eng.set_prn_mask(masks[seq[0][1]])
-    eng.prepare_dev(d_x[seq[0][0]], A.FMT_I8_IQ)
+    tok = eng.prepare_dev(d_x[seq[0][0]], A.FMT_I8_IQ)
+    prepared = 0
     for i, (k, mi) in enumerate(seq):
-        eng.search_dev(d_x[k], A.FMT_I8_IQ, None)            # carries the decision of dwell i - 1 only on the plain path
+        if tok is not None:                                  # dwells 0, 1, 3, 5: stage C on the prepared spectra (cut tail: the ticket
+            eng.search_prepared_dev(tok, None)               # clear is left to corr()); the pending decision is flushed in front
+            tok, prepared = None, prepared + 1
+        else:
+            eng.search_dev(d_x[k], A.FMT_I8_IQ, None)        # dwells 2, 4: the plain path carries the decision of dwell i - 1
         if i + 1 < len(seq) and i % 2 == 0:
-            eng.prepare_dev(d_x[seq[i + 1][0]], A.FMT_I8_IQ)
+            tok = eng.prepare_dev(d_x[seq[i + 1][0]], A.FMT_I8_IQ)
         eng.decide_dev(None)                                 # deferred: asked with mask mi
         if i + 1 < len(seq):
             eng.set_prn_mask(masks[seq[i + 1][1]])           # changed BEFORE the deferred decision has run
         if i % 3 == 2 or i + 1 == len(seq):
             got.append((i, [key(r) for r in eng.fetch_results(P)]))
+    assert prepared == 4
     for i, res in got:
         assert res == want[seq[i]], (opts, i)
     eng.close()
