@@ -639,7 +639,8 @@ def main():
             for k in path:
                 v = v.get(k) if isinstance(v, dict) else None
             return v if isinstance(v, (int, float, bool)) else None
-        out["config"].update({
+        cfg = out["config"]
+        cfg.update({
             "tracking_ch_msps": pick("tracking", "value"), "tracking_ms_per_epoch": pick("tracking", "ms_per_epoch"),
             "tracking_frac": pick("tracking", "roofline", "frac"), "tracking_channels_locked": pick("tracking", "channels_locked"),
             "tracking_cpu_ch_msps": pick("tracking", "cpu_baseline", "value"),
@@ -651,11 +652,26 @@ def main():
             "cfg4_galileo_ms_per_dwell": pick("cfg4_galileo_geometry", "ms_per_dwell"),
             "cfg4_galileo_corr_kernel_ms": pick("cfg4_galileo_geometry", "corr_kernel_ms"),
             "cfg4_grid_ms_per_dwell": pick("cfg4_grid", "ms_per_dwell"), "cfg4_grid_cells_per_s": pick("cfg4_grid", "cells_per_s"),
-            "cfg5_ch_msps": pick("cfg5_geometry", "ch_msps"), "cfg5_channels_locked": pick("cfg5_geometry", "channels_locked"),
+            "cfg5_ch_msps": pick("cfg5_geometry", "ch_msps"), "cfg5_ms_per_code_period": pick("cfg5_geometry", "ms_per_code_period"),
+            "cfg5_channels_locked": pick("cfg5_geometry", "channels_locked"),
             "frontend_msps": pick("frontend", "msps"),
             "receiver_x_real_time": pick("receiver", "x_real_time"), "receiver_tracking_wall_s": pick("receiver", "wall_seconds_per_stage", "tracking"),
             "receiver_channels_frame_synchronised": pick("receiver", "channels_frame_synchronised"),
+            "receiver_warmup_async_calls": pick("receiver", "warmup_async_calls"), "receiver_python_gc_disabled": pick("receiver", "python_gc_disabled"),
         })
+        # A record that keeps only the head of `config` (the driver's `parsed.config` held the first 24 keys in round 5 and cut the
+        # receiver / cfg4 / cfg5 scalars) must still carry BOTH halves of BASELINE's metric and one number per BASELINE config: the
+        # keys go out in this order — workload first, then the other half of the metric (tracking), then one headline scalar per
+        # leg; what merely repeats a top-level field, and legs that did not run (None), travel behind them.
+        head = ["workload", "prns_per_gpu", "doppler_bins", "fft_size", "integrations", "cells_per_step", "parallelism", "detections_ok"]
+        if world > 1:
+            head += ["exchange", "exchange_us_per_dwell", "exchange_overlapped_with_next_dwell"]
+        head += ["tracking_ch_msps", "tracking_ms_per_epoch", "tracking_frac", "tracking_channels_locked",
+                 "receiver_x_real_time", "receiver_channels_frame_synchronised",
+                 "cfg4_grid_ms_per_dwell", "cfg4_galileo_corr_kernel_ms", "cfg5_ch_msps", "cfg5_ms_per_code_period", "frontend_msps",
+                 "cfg1_ms_per_dwell", "cfg1_corr_kernel_ms", "cfg1_cells_per_s", "cfg4_galileo_ms_per_dwell", "host_buffer_api_ms_per_dwell"]
+        first = [k for k in head if cfg.get(k) is not None]
+        out["config"] = {**{k: cfg[k] for k in first}, **{k: v for k, v in cfg.items() if k not in first}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1335,6 +1335,7 @@ int gm_acq_debug_stamps(gm_acq* a, long long* out) {
         if (d_st) { gm::set_corr_stamps(nullptr); hipFree(d_st); d_st = nullptr; }
         HIPC(hipMalloc(&d_st, bytes));
         HIPC(hipMemset(d_st, 0, bytes));
+        HIPC(hipStreamSynchronize(nullptr));
         gm::set_corr_stamps(d_st);
         return GM_OK;
     }
@@ -1380,7 +1381,11 @@ int gm_ring_create(size_t buf_size, gm_ring** out) {
     r->slot_samples = buf_size < gm_ring::SLOT_SAMPLES_MAX ? buf_size : gm_ring::SLOT_SAMPLES_MAX;
     hipError_t e = hipMalloc(&r->d_buf, buf_size * 8);
     if (e == hipSuccess) e = hipMemset(r->d_buf, 0, buf_size * 8);
-    if (e != hipSuccess) { delete r; return hip_fail(e, "hipMalloc(ring)"); }
+    // hipMemset of device memory returns before the fill has run and is ordered on the NULL stream only; the ring's writers work on
+    // NON-BLOCKING streams, which that stream does not order: without this wait the fill can land on top of the first blocks written
+    // (seen in round 6 as a tracking run that differed from its twin by a few zeroed samples, only in a long-lived process)
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) { hipFree(r->d_buf); delete r; return hip_fail(e, "hipMalloc(ring)"); }
     *out = r;
     return GM_OK;
 }
@@ -2107,7 +2112,7 @@ int gm_trk_debug_stamps(gm_trk* t, uint32_t cap, long long* out) {
     if (int rc = ensure_device(t->device)) return rc;
     if (!out) {   // arm
         hipFree(t->d_stamps); t->d_stamps = nullptr; t->stamps_cap = 0;
-        if (cap) { HIPC(hipMalloc(&t->d_stamps, size_t(cap) * 48 * sizeof(long long))); HIPC(hipMemset(t->d_stamps, 0, size_t(cap) * 384)); t->stamps_cap = cap; }
+        if (cap) { HIPC(hipMalloc(&t->d_stamps, size_t(cap) * 48 * sizeof(long long))); HIPC(hipMemset(t->d_stamps, 0, size_t(cap) * 384)); HIPC(hipStreamSynchronize(nullptr)); t->stamps_cap = cap; }
         return GM_OK;
     }
     if (!t->d_stamps || cap > t->stamps_cap) return set_err(GM_ERR_INVALID_ARG, "stamps not armed");
@@ -2251,6 +2256,7 @@ int gm_frontend_create(float f_if, float fs_in, float fs_out, gm_frontend** out)
     if (e == hipSuccess) e = hipMemcpy(f->d_lut, f->lut.data(), 2 * 2048 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&f->d_state, sizeof(gm::FeState));
     if (e == hipSuccess) e = hipMemset(f->d_state, 0, sizeof(gm::FeState));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);    // the fill has run before a kernel on a non-blocking stream can touch the state (see gm_ring_create)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { gm_frontend_destroy(f); return hip_fail(e, "gm_frontend_create"); }
     *out = f;

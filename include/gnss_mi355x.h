@@ -14,6 +14,13 @@
  *     hands one `&mut` worker/channel to each rayon task)
  *   - host pointers unless the name ends in `_dev`; `_dev` pointers are HIP device pointers on the
  *     handle's device and the call is asynchronous on the handle's stream
+ *   - STREAMS: every stream the library creates is NON-BLOCKING (hipStreamNonBlocking).  Work on the NULL stream (hipMemset,
+ *     hipMemcpy of device memory, a launch without a stream) is NOT ordered against the library's work in either direction.  A
+ *     device buffer handed to a `_dev` entry must be READY on the stream the handle works on: pass the producer's stream with
+ *     gm_acq_set_stream / gm_trk_set_stream (the entry then runs behind the producer in stream order, and what it writes is ready
+ *     on that stream), or synchronise the producer first.  gm_acq_prepare_dev takes the producer's stream per call
+ *     (`ready_stream`).  The reference copies its 10 ms out of the ring and THEN searches them (do_acquisition.rs:297-313): the
+ *     stream order is that sequence.  INTEGRATION.md §3.3; tests/test_gpu_acquisition.py::test_caller_stream_orders_...
  *   - arithmetic type: f32 everywhere, as in the reference (num_complex::Complex32 = {f32 re, im})
  *   - the compute path is HIP on gfx950 only; there is NO CPU fallback — without a usable device
  *     every compute entry returns GM_ERR_NO_DEVICE
@@ -267,11 +274,15 @@ int gm_acq_set_deferred_decision(gm_acq *a, int on);
  * last round is already filled.  Same metric words as the plain search.  The first call allocates the second spectrum buffer
  * (n_bins * n_integrations * fft_size * 8 bytes), the stream and three events — all of them or, on failure, none;
  * gm_acq_destroy releases them.  Composite sizes prepare nothing: they issue a token all the same and run the whole search at
- * gm_acq_search_prepared_dev from d_samples as it is THEN. */
+ * gm_acq_search_prepared_dev from d_samples as it is THEN — behind the event recorded on `ready_stream` at prepare time (ABI 7: the
+ * ordering promise holds on every size). */
 int gm_acq_prepare_dev(gm_acq *a, const void *d_samples, int fmt, void *ready_stream, uint64_t *token);
 int gm_acq_search_prepared_dev(gm_acq *a, uint64_t token, void *d_metrics);
 int gm_acq_drop_prepared(gm_acq *a);
-/* Use an existing HIP stream (e.g. torch's current stream) instead of the handle's own. */
+/* Use an existing HIP stream (e.g. torch's current stream, or the stream that fills the sample buffer) instead of the handle's
+ * own: every later entry of the handle is enqueued there, i.e. BEHIND what the caller has queued on it and in front of what the
+ * caller queues next — the way to order a `_dev` entry against the producer of its samples and the consumer of its metrics without
+ * a synchronisation (see STREAMS at the top).  The caller keeps the stream alive until the handle is destroyed or given another. */
 int gm_acq_set_stream(gm_acq *a, void *hip_stream);
 
 /* Per-(worker, bin) planes of the last search: max, first-argmax, sum of the accumulated power

@@ -47,7 +47,7 @@ pub struct GmAcqCfg {               // gm_acq_cfg
     pub strict_sum_order: i32,       // 1 = is_good_satellite's sum in the reference's 8-lane order (do_acquisition.rs:229-235)
     pub reference_products: i32,     // 1 = x conj(code) and norm_sqr() rounded as num-complex rounds them (no fused multiply-add; :184-192)
 }
-#[repr(C)] #[derive(Clone, Copy, Debug, Default)]
+#[repr(C)] #[derive(Clone, Copy, Debug, Default, PartialEq)]
 pub struct GmTrkState {             // gm_trk_state  <->  the evolving fields of TrackingChannel (do_tracking.rs:88-116)
     pub prn: u8, pub active: u8, pub reserved: [u8; 2], pub lost_counter: u32,
     pub next_sample_index: u64, pub num_samples_per_code: u64,

@@ -297,6 +297,15 @@ def test_rust_binding_source_matches_the_abi(gm):
     for name in ("do_acquisition.rs", "do_tracking.rs"):
         assert signatures(strip_comments(rs[name]))[""]["run"] == ref[name]["pub_fn"][""]["run"], name
 
+    # the manager's passes go through the bulk state entries (a dirty test, no per-channel FFI call, no Vec
+    # per call) and run() drives the ticket path (enqueue behind the mirror's copies, collect later)
+    trk = strip_comments(rs["do_tracking.rs"])
+    mgr = trk[trk.index("impl TrackingManager"):trk.index("impl Drop for TrackingManager")]
+    assert "gm_trk_set_states(" in mgr and "gm_trk_get_states(" in mgr and "gm_trk_update_all_async(" in mgr and "gm_trk_collect(" in mgr
+    assert not re.search(r"gm_trk_[gs]et_state\(", mgr) and "vec![" not in mgr[mgr.index("fn take_acquisitions"):]
+    run_body = trk[trk.index("pub fn run("):]
+    assert "process_channels_async(" in run_body and "collect_ready(" in run_body and "condvar.wait(" in run_body
+
     # ---- where the files go, and that every path they name resolves ----
     # module tree of the crate as the reference has it (names only, tests/golden/make_api_signatures.py) + the shipped modules
     from rs_api import mod_decls, pub_items

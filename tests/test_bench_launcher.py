@@ -109,3 +109,26 @@ def test_visible_gpus_counts_from_sysfs_without_hip(tmp_path):
     src = open(os.path.join(ROOT, "bench.py")).read()
     body = src[src.index("def visible_gpus"):src.index("def launch_ranks")]
     assert "import torch" not in body.replace('"import torch; print(torch.cuda.device_count())"', "")   # only inside the child's -c string
+
+
+def test_config_head_fits_the_drivers_parse():
+    """The driver's `parsed.config` kept the first 24 keys of `config` in round 5 and so lost the receiver / cfg4 / cfg5 scalars
+    (VERDICT round 5, item 3).  bench.py now sends an explicit head: at N = 1 it must fit in 24 keys and hold one scalar per
+    BASELINE config plus the other half of the metric; the multi-GPU head (with the exchange keys) may not push the tracking
+    half of the metric out either."""
+    import ast
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("        head = [\"workload\""):src.index("        first = [k for k in head")]
+    lists = [ast.literal_eval(m) for m in re.findall(r"(\[[^\]]*\])", body)]
+    single = lists[0] + lists[2]
+    multi = lists[0] + lists[1] + lists[2]
+    assert len(single) == len(set(single)) <= 24, len(single)
+    for k in ("workload", "tracking_ch_msps", "tracking_frac", "receiver_x_real_time", "cfg4_grid_ms_per_dwell",
+              "cfg4_galileo_corr_kernel_ms", "cfg5_ch_msps", "cfg5_ms_per_code_period", "frontend_msps", "cfg1_ms_per_dwell"):
+        assert k in single[:24], k
+    for k in ("exchange", "tracking_ch_msps", "tracking_frac", "cfg4_grid_ms_per_dwell", "cfg5_ch_msps"):
+        assert k in multi[:24], k
+    # every head key is one the line actually carries
+    for k in multi:
+        assert ('"%s"' % k) in src.replace(body, ""), k

@@ -661,6 +661,68 @@ def test_prepare_dev_is_safe_to_misuse(gpu, hipbuf, N, fmt_name):
     eng.close()
 
 
+@pytest.mark.parametrize("N", [2048, 32000])
+def test_caller_stream_orders_the_samples_without_a_synchronise(gpu, hipbuf, oracle, N):
+    """The stream contract of include/gnss_mi355x.h (STREAMS) in its positive form — the hazard commit 50b74e7 found in a test
+    helper, turned round: the samples of a dwell are produced by ASYNCHRONOUS work on a caller's non-blocking stream (a slow
+    pageable copy of a large block in front of them, then the fill of the sample buffer, then a clear of the metrics block), the
+    handle is given that stream (gm_acq_set_stream), and search_dev + decide_dev + a D2H copy of the metrics are enqueued behind
+    it with NO host synchronisation in between.  The words and the detections are those of the same scene searched
+    synchronously; the snapshot-then-search order this stands for is do_acquisition.rs:297-313.  An in-LDS size and a composite."""
+    import ctypes as C
+    from gnss_sdr_rs_amd import acquisition as A, synth
+    t = oracle.ca_code_table()
+    fs, M = N * 1000.0, 2
+    dop = np.arange(-1000.0, 1001.0, 500.0, dtype=np.float32)
+    prns = [3, 7, 12, 25]
+    P, D = len(prns), dop.size
+    words = 3 * P * D
+    rate = 1.023e6
+    sats = [dict(prn_row=6, cn0_dbhz=52.0, doppler_hz=470.0, code_start=N // 3), dict(prn_row=24, cn0_dbhz=50.0, doppler_hz=-820.0, code_start=17)]
+    x = synth.to_i8_iq(synth.make_scene(t, fs, 0.0, M * N, sats, config_id=40 + N % 7, code_rate=rate))
+    other = synth.to_i8_iq(synth.make_scene(t, fs, 0.0, M * N, sats[:1], config_id=50, code_rate=rate))
+    eng = A.AcquisitionEngine(fs, 0.0, N, doppler_hz=dop, prn_ids=prns, n_integrations=M, decision_mode=A.DECIDE_BEST_BIN)
+    # the reference answer, synchronously, from a buffer of its own
+    d_ref, d_met_ref = hipbuf.upload(x), hipbuf.alloc(words * 4)
+    eng.search_dev(d_ref, A.FMT_I8_IQ, d_met_ref); eng.decide_dev(d_met_ref)
+    want_res = eng.fetch_results(P)
+    want = hipbuf.download(d_met_ref, words * 4, np.uint32).copy()
+    assert want_res[1] and want_res[3] and not want_res[0] and want_res[1]["code_phase_samples"] == N // 3
+    hip = hipbuf.hip
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipHostFree.argtypes = [C.c_void_p]
+    d_buf = hipbuf.upload(other)                                  # holds ANOTHER scene until the caller's stream refills it
+    d_met = hipbuf.alloc(words * 4, fill=0xFF)
+    s_user = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(s_user), 1) == 0  # hipStreamNonBlocking, like the library's own
+    h_met = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(h_met), words * 4, 0) == 0
+    C.memset(h_met, 0xEE, words * 4)
+    big = np.zeros(96 << 20, np.uint8)
+    d_big = hipbuf.alloc(big.nbytes)
+    eng.set_stream(s_user.value)
+    # producer (caller's stream): a long pageable copy, then the samples, then a clear of the metrics block ...
+    assert hip.hipMemcpyAsync(d_big, big.ctypes.data, big.nbytes, 1, s_user) == 0
+    assert hip.hipMemcpyAsync(d_buf, x.ctypes.data, x.nbytes, 1, s_user) == 0
+    assert hip.hipMemsetAsync(d_met, 0, words * 4, s_user) == 0
+    # ... the library's dwell behind it, in stream order, and the consumer behind the dwell: no synchronise anywhere in between
+    eng.search_dev(d_buf, A.FMT_I8_IQ, d_met)
+    eng.decide_dev(d_met)
+    assert hip.hipMemcpyAsync(h_met, d_met, words * 4, 2, s_user) == 0
+    assert hip.hipStreamSynchronize(s_user) == 0
+    got = np.frombuffer(C.string_at(h_met, words * 4), np.uint32)
+    assert (got == want).all()
+    key = lambda r: r and (r["prn"], r["code_phase_samples"], r["doppler_bin"], r["mag_relative"])
+    assert [key(r) for r in eng.fetch_results(P)] == [key(r) for r in want_res]
+    eng.close()
+    assert hip.hipHostFree(h_met) == 0 and hip.hipStreamDestroy(s_user) == 0
+
+
 @pytest.mark.parametrize("opts", [dict(strict_sum_order=True), dict(reference_products=True), dict()])
 def test_back_to_back_dwell_entries_with_options_and_mask_changes(gpu, hipbuf, opts):
     """The two back-to-back-dwell entries together, on handles with strict_sum_order / reference_products, at the headline size

@@ -15,6 +15,16 @@ def _state_bytes(s):
     return bytes(C.string_at(C.addressof(s), C.sizeof(s)))
 
 
+def _assert_same_states(ab, n):
+    """every word of every channel record equal; on a mismatch the message names the fields (not a wall of bytes)"""
+    diff = []
+    for c in range(n):
+        a, b = ab["sync"][c], ab["async_"][c]
+        if _state_bytes(a) != _state_bytes(b):
+            diff += [(c, k, getattr(a, k), getattr(b, k)) for k, _ in a._fields_ if k != "reserved" and getattr(a, k) != getattr(b, k)]
+    assert not diff, "synchronous loop vs ticket loop (channel, field, sync, tickets): %r; epochs %r" % (diff, ab["epochs"])
+
+
 def test_cpp_tracking_driver_tickets_equal_the_synchronous_loop_on_the_full_chain_scene(gpu, oracle):
     """The scene of test_full_chain_frontend_to_nav_bits (int8 IF -> DigitalFrontend -> ring, one satellite with 50 bit/s data,
     3.1 s): acquisition + fine Doppler give the hand-over; then gnss::run_tracking alone on that ring, once with the synchronous
@@ -49,8 +59,7 @@ def test_cpp_tracking_driver_tickets_equal_the_synchronous_loop_on_the_full_chai
     ab = R.tracking_ab(base, [hand_over], fs, n_channels=15, write_block=(1 << 18) + 1234)
     assert ab["epochs"][0] == ab["epochs"][1] >= 3080, ab["epochs"]
     assert ab["locked"] == (1, 1) and ab["lost"] == (0, 0)
-    for c in range(15):
-        assert _state_bytes(ab["sync"][c]) == _state_bytes(ab["async_"][c]), c
+    _assert_same_states(ab, 15)
     s = ab["async_"][0]
     assert s.active and s.prn == 9 and abs(s.carrier_freq - 1337.0) < 15.0
     assert s.next_sample_index + s.num_samples_per_code > n_ms * N          # every whole code period in the ring was run
@@ -79,8 +88,7 @@ def test_cpp_tracking_driver_tickets_several_channels_and_a_lost_one(gpu, oracle
     ab = R.tracking_ab(x, results, fs, n_channels=4, ring_log2=20, write_block=7 * N + 321)
     assert ab["locked"] == (4, 4) and ab["lost"] == (1, 1)
     assert ab["epochs"][0] == ab["epochs"][1] > 3 * 150
-    for c in range(4):
-        assert _state_bytes(ab["sync"][c]) == _state_bytes(ab["async_"][c]), c
+    _assert_same_states(ab, 4)
     for c, (p, (d, _)) in enumerate(truth.items()):
         s = ab["async_"][c]
         assert s.active and s.prn == p and abs(s.carrier_freq - d) < 15.0 and s.lost_counter == 0
