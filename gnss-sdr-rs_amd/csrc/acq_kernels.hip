@@ -215,11 +215,22 @@ __device__ __forceinline__ void corr_stamp(long long* base, int m, int wave, int
         base[(size_t(m) * 8 + wave) * 8 + phase] = (long long)t;
     }
 }
+// The stamped instantiation of every correlation plan (hundreds of scratch instructions each: lane 0's stamps keep state the product
+// loop does not) exists only in a DIAGNOSTIC build — GM_EXTRA_FLAGS=-DGM_DIAG_STAMPS GM_LIB_SUFFIX=_diag python build.py, loaded
+// with GM_LIB_PATH (tools/acq_stamps.py) — never in libgnss_mi355x.so: there gm_acq_debug_stamps is
+// GM_ERR_UNSUPPORTED and the flag below is a compile-time false.
+#ifdef GM_DIAG_STAMPS
 static bool g_corr_stamps_armed = false;
+bool corr_stamps_built() { return true; }
 void set_corr_stamps(long long* d_ptr) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_corr_stamps), &d_ptr, sizeof(d_ptr));
     g_corr_stamps_armed = d_ptr != nullptr;
 }
+#else
+static constexpr bool g_corr_stamps_armed = false;
+bool corr_stamps_built() { return false; }
+void set_corr_stamps(long long*) {}
+#endif
 
 // ------------------------------------------------------------------------------------ stage C
 // REF_MUL (gm_acq_cfg.reference_products): x conj(code) and |.|^2 formed exactly as num-complex does (separate multiplies and
@@ -906,7 +917,7 @@ template <class PL> struct Launch {
         // at the start of its allocation (cdna_hip_programming.md G16 "Re-initialise every call")
         if (split_k > 1 && !tickets_cleared) (void)hipMemsetAsync(split_counter, 0, size_t(GM_CORR_SPLIT_MAX_ITEMS) * sizeof(uint32_t), st);
         if constexpr (WS31) {
-            if (!g_corr_stamps_armed) {
+            if (!g_corr_stamps_armed) {       // (always, in the product build: the generic kernel of this size exists in a diagnostic build only)
                 if (ref_mul)
                     hipLaunchKernelGGL((acq_corr_ws31_kernel<CP, true>), dim3(grid), dim3(1024), 0, st, spectra, code_fft, mmax, margmax, msum,
                                        worker_list, n_workers, n_bins, n_int, map_mode, split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
@@ -916,18 +927,30 @@ template <class PL> struct Launch {
                 return;
             }
         }
-        if (g_corr_stamps_armed)   // diagnostic build of the same kernel (gm_acq_debug_stamps)
+#ifdef GM_DIAG_STAMPS
+        if (g_corr_stamps_armed) {  // diagnostic build of the same kernel (gm_acq_debug_stamps)
             hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, true, false>), dim3(grid), dim3(PL::T), 0, st,
                                spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
                                split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
-        else if (ref_mul)          // gm_acq_cfg.reference_products: the reference's own rounding of x conj(code) and |.|^2
-            hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, false, true>), dim3(grid), dim3(PL::T), 0, st,
-                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
-                               split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
-        else
-            hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, false, false>), dim3(grid), dim3(PL::T), 0, st,
-                               spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
-                               split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
+            return;
+        }
+#endif
+        // the generic kernel of a wave-specialised size is not even instantiated in the product build
+#ifdef GM_DIAG_STAMPS
+        constexpr bool GENERIC = true;
+#else
+        constexpr bool GENERIC = !WS31;
+#endif
+        if constexpr (GENERIC) {
+            if (ref_mul)          // gm_acq_cfg.reference_products: the reference's own rounding of x conj(code) and |.|^2
+                hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, false, true>), dim3(grid), dim3(PL::T), 0, st,
+                                   spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
+                                   split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
+            else
+                hipLaunchKernelGGL((acq_corr_kernel<PL, CP::KEEP_CODE, false, false>), dim3(grid), dim3(PL::T), 0, st,
+                                   spectra, code_fft, tw_inv, mmax, margmax, msum, worker_list, n_workers, n_bins, n_int, map_mode,
+                                   split_from, split_k, split_items, split_scratch, split_counter, strict_sum);
+        }
     }
     static void code_fft(hipStream_t st, const int8_t* code_samples, const cf* tw_fwd, cf* out, int n_codes) {
         hipLaunchKernelGGL(acq_code_fft_kernel<PL>, dim3(n_codes), dim3(PL::T), 0, st, code_samples, tw_fwd, out);

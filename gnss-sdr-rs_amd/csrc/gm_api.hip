@@ -1328,6 +1328,8 @@ int gm_acq_decide_host(const float* mmax, const uint32_t* margmax, const float* 
 // out = [n_integrations][8 waves][8 phases] shader-clock values of the last search.
 int gm_acq_debug_stamps(gm_acq* a, long long* out) {
     if (!a) return set_err(GM_ERR_INVALID_ARG, "null handle");
+    if (!gm::corr_stamps_built())
+        return set_err(GM_ERR_UNSUPPORTED, "the stamped correlation kernels are in a diagnostic build only (GM_EXTRA_FLAGS=-DGM_DIAG_STAMPS, tools/README.md)");
     if (int rc = ensure_device(a->device)) return rc;
     static long long* d_st = nullptr;
     const size_t bytes = size_t(a->M) * 64 * sizeof(long long);

@@ -87,6 +87,7 @@ int list_plans(uint32_t* sizes, int cap);
 
 // diagnostic: device buffer [n_int][8 waves][8 phases] of s_memtime stamps written by workgroup 0 of acq_corr_kernel
 void set_corr_stamps(long long* d_ptr);
+bool corr_stamps_built();          // false in the product library (the stamped kernels are compiled under -DGM_DIAG_STAMPS only)
 
 // composite transform sizes N = Q * Nb (acq_composite.hip): decimated in time, the inverse fused with the power reduction
 struct CompOps {

@@ -301,7 +301,8 @@ int gm_acq_last_timing(gm_acq *a, float *ms_mix_fft, float *ms_corr, float *ms_d
 int gm_acq_timing_summary(gm_acq *a, uint32_t *launches, float *avg_ms_mix_fft, float *avg_ms_corr);
 
 /* Diagnostic (not in the reference): out == NULL arms, then out = [n_integrations][8][8] int64 shader-clock stamps
- * of workgroup 0's waves at the phase boundaries of each transform of the last search. */
+ * of workgroup 0's waves at the phase boundaries of each transform of the last search.  The stamped kernels are compiled into a
+ * DIAGNOSTIC build of the library only (-DGM_DIAG_STAMPS): the product library returns GM_ERR_UNSUPPORTED and launches nothing. */
 int gm_acq_debug_stamps(gm_acq *a, long long *out);
 
 /* AcquisitionManager (do_acquisition.rs:39-74): mode 0 ColdStart / 1 WarmStart / 2 SteadyState. */

@@ -1,4 +1,7 @@
-"""Diagnostic: where one workgroup of acq_corr_kernel spends its cycles (per-wave phase stamps, configs[1])."""
+"""Diagnostic: where one workgroup of acq_corr_kernel spends its cycles (per-wave phase stamps, configs[1]).  Needs the DIAGNOSTIC
+build of the library (the product library does not carry the stamped kernels):
+    GM_EXTRA_FLAGS=-DGM_DIAG_STAMPS GM_LIB_SUFFIX=_diag python gnss-sdr-rs_amd/build.py
+    GM_LIB_PATH=gnss-sdr-rs_amd/lib/libgnss_mi355x_diag.so python tools/acq_stamps.py"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
