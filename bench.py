@@ -1005,20 +1005,27 @@ def cfg5_leg(torch, stream, T, world=1, rank=0, dist=None, dev=None, debug_gloo=
     (channels are independent, do_tracking.rs:364-371); ch_msps = 36 x 50 x signal time / the slowest rank's wall time.
     The reference has no Galileo/BOC code: stand-in random codes, GPU-only number."""
     from gnss_sdr_rs_amd import distributed as Dm
-    fs, L, rate, C, periods = 50.0e6, 4092, 1.023e6, 36, 6
+    # 24 code periods (96 ms of signal) per launch since round 6 (6 before): the launch's fixed costs — the dispatcher reaches one XCD
+    # 8 us after the others, the host's launch + synchronise — weighed 2-3 us per period on six periods; a receiver's launches are
+    # long (one per block of samples).  The scene is built period by period from one period of (code x sub-carrier x carrier) per
+    # satellite and a phasor per period: every satellite is code-aligned at sample 0 and a code period is exactly n samples.
+    fs, L, rate, C, periods = 50.0e6, 4092, 1.023e6, 36, 24
     n = int(round(fs / (rate / L)))
     mine = Dm.shard_prns(list(range(C)), world, rank)
     rng = np.random.default_rng(5)
     codes = np.where(rng.integers(0, 2, (C, L)) > 0, 1, -1).astype(np.int8)
-    tt = np.arange((periods + 1) * n, dtype=np.float64)
-    cp = (tt * rate / fs) % L
+    t1p = np.arange(n, dtype=np.float64)
+    cp = (t1p * rate / fs) % L
     sub = np.where((cp - np.floor(cp)) < 0.5, 1.0, -1.0).astype(np.float32)
     ci = np.floor(cp).astype(np.int64)
-    x = (rng.standard_normal(tt.size) + 1j * rng.standard_normal(tt.size)).astype(np.complex64) * np.float32(8.0)
+    x = (rng.standard_normal((periods + 1) * n) + 1j * rng.standard_normal((periods + 1) * n)).astype(np.complex64) * np.float32(8.0)
     dopp = rng.uniform(-2000, 2000, C)
+    xv = x.reshape(periods + 1, n)
     for c in range(C):   # all satellites code-aligned at sample 0 (keeps the generator cheap); the whole sky on every rank
-        x += (np.float32(0.6) * codes[c][ci] * sub * np.exp(2j * np.pi * dopp[c] * tt / fs)).astype(np.complex64)
-    ring = T.MulticastRingBuffer(1 << 21)
+        one = (np.float32(0.6) * codes[c][ci] * sub * np.exp(2j * np.pi * dopp[c] * t1p / fs)).astype(np.complex64)
+        step = np.exp(2j * np.pi * dopp[c] * n / fs)
+        xv += one[None, :] * (step ** np.arange(periods + 1))[:, None].astype(np.complex64)
+    ring = T.MulticastRingBuffer(1 << 23)
     ring.write_samples(x)
     Cl = len(mine)
     mgr = T.TrackingManager(fs, n_channels=Cl, n_arms=5, code_index_mode=T.CODE_INDEX_FIXED, early_late_space=0.25,
@@ -1046,7 +1053,8 @@ def cfg5_leg(torch, stream, T, world=1, rank=0, dist=None, dev=None, debug_gloo=
             err = err or "another rank failed"
     if err:
         return {"error": err}
-    times = []
+    times, ktimes = [], []
+    mgr.enable_timing(True)
     for _ in range(3):
         restart()
         torch.cuda.synchronize()
@@ -1056,6 +1064,7 @@ def cfg5_leg(torch, stream, T, world=1, rank=0, dist=None, dev=None, debug_gloo=
         mgr.update_all_dev(ring, periods)
         mgr.synchronize()
         t1 = time.perf_counter() - t0
+        ktimes.append(mgr.last_timing()[0])
         if world > 1:      # the job is done when the slowest rank is
             tm = torch.tensor([t1], dtype=torch.float64, device="cpu" if debug_gloo else dev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -1073,6 +1082,7 @@ def cfg5_leg(torch, stream, T, world=1, rank=0, dist=None, dev=None, debug_gloo=
             "scaling": "strong", "n_gpus": world,
             "channels_per_rank": [len(Dm.shard_prns(list(range(C)), world, r)) for r in range(world)],
             "ch_msps": C * fs / 1e6 * (sig_s / dt), "ms_per_code_period": dt / periods * 1e3, "channels_locked": locked,
+            "code_periods_per_launch": periods, "kernel_ms_per_code_period": float(np.median(ktimes)) / periods,
             "algorithmic_GBs": C * n * 8 * periods / dt / 1e9}
 
 

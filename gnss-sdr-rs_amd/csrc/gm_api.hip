@@ -1738,7 +1738,7 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
             if (f >= 1 && f <= 32 && size_t(f) * slots <= size_t(cus) * per_cu && f * nv <= 256) g = f;
         }
         t->G = g;
-        const size_t xb = (size_t(2) * t->C * g * nv + size_t(t->C) * g) * sizeof(unsigned long long);   // partials + XCC_ID granules
+        const size_t xb = (size_t(2) * t->C * gm::trk_persistent_granule_stride(g) * nv + size_t(t->C) * g) * sizeof(unsigned long long);   // partials + XCC_ID granules
         HIPT(hipMalloc(&t->d_xchg, xb));
         HIPT(hipMemsetAsync(t->d_xchg, 0, xb, t->stream));
         HIPT(hipHostMalloc(reinterpret_cast<void**>(&t->d_error), sizeof(int), hipHostMallocDefault));   // read on the host after a stream sync: no copy

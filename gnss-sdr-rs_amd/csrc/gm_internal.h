@@ -188,6 +188,7 @@ constexpr int TRK_PERSIST_WG_PER_CU = 2;
 inline int trk_persistent_slots(int n_channels) { return (n_channels + 7) / 8 * 8; }   // grid = slots * G workgroups
 int trk_persistent_blocks_per_cu(const TrkDevCfg&);   // resident workgroups per CU of the instantiation this config selects
 // persistent multi-epoch tracking (one launch = `epochs` passes over all channels); G workgroups per channel
+int trk_persistent_granule_stride(int G);      // granules per arm in the exchange block of the persistent kernel (16 for G <= 16)
 void launch_trk_results_to_host(hipStream_t, const void* d_src, void* h_dst_pinned, size_t bytes, const void* d_src2 = nullptr, void* h_dst2_pinned = nullptr,
                                 size_t bytes2 = 0);
 void launch_trk_persistent(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_trk_state* d_states,

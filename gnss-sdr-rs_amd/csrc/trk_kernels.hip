@@ -121,6 +121,14 @@ __device__ __forceinline__ void reset_state(gm_trk_state& s) {
     s.i_prompt = 0.f; s.q_prompt = 0.f;
 }
 
+#ifndef GM_TRK_IL5
+#define GM_TRK_IL5 2          // samples per straight-line block of the five-arm fast path (2 or 4)
+#endif
+// persistent kernel's dynamic LDS.  Plain: [code_len + 2 floats of the padded chip row].  BOC: [2 code_len + 4 half chips, whole
+// float4s][the padded chip row] — the table the fast path reads sits FIRST, at a compile-time LDS address, so that its look-ups are
+// `v_lshlrev` + `ds_read offset:constant` (a run-time base costs a half-rate v_lshl_add with a scalar source per look-up)
+__host__ __device__ __forceinline__ int boc_plain_offset(int code_len) { return (2 * code_len + 4 + 3) & ~3; }
+
 // per-epoch constants of one channel, derived from its state exactly once per epoch
 struct EpochConsts {
     float carrier_phase, two_pi_f, code_phase, step, fs, inv_fs, lenf, el, vel;
@@ -294,6 +302,12 @@ __device__ __forceinline__ void correlate_sample_fast(const EpochConsts& c, cons
 // the look-ups' latency; (3) products into the sums.  Calling correlate_sample_fast NB times in a row left it to the
 // scheduler, which kept the samples one after another (least registers): a wave then issued one DEPENDENT instruction per
 // ~8 cycles and sat out an LDS round trip per sample.  Values are bit-identical to the one-sample form.
+// BOC(1,1) (BOC_T): `tab` is the HALF-CHIP table (trk_persistent_kernel: entry j + 2 = chip floor(j / 2) x the sub-carrier sign of
+// half chip j, j = -2 .. 2 len + 1).  An arm's phase p = fl(chip_idx + s) is looked up at j = floor(2 p), and 2 p = fl(2 chip_idx
+// + 2 s) EXACTLY — binary rounding commutes with the doubling — so one fused multiply-add gives the index of the chip AND of its
+// sub-carrier half: floor(p) = floor(j / 2), fract(p) < 0.5 <=> j even.  Same values as the chip look-up + fract / compare / select
+// of the plain table, bit for bit (the products are exact either way), at 4 instructions per arm instead of 8 (round 6: the
+// five-arm BOC geometry of BASELINE configs[4] is throughput-shaped, 200 000 samples per channel-epoch).
 template <int ARMS, int BOC_T, int NB>
 __device__ __forceinline__ void correlate_block_fast(const EpochConsts& c, const float* tab, const cf (&d)[NB], const float (&f)[NB],
                                                      float (&acc0)[2 * ARMS], float (&acc1)[2 * ARMS]) {
@@ -305,14 +319,28 @@ __device__ __forceinline__ void correlate_block_fast(const EpochConsts& c, const
         const uint32_t ua = __float_as_uint(t), ub = __float_as_uint(t - c.lenf), uc = __float_as_uint(t - 2.0f * c.lenf);
         chip_idx[k] = __uint_as_float(min(min(ua, ub), uc));
     }
+    if constexpr (BOC_T == 1) {
+        const float el2 = c.el + c.el, vel2 = c.vel + c.vel;          // exact doublings
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        pc[k] = tab[floor_i32(chip_idx[k]) + 1];
-        ec[k] = tab[floor_i32(chip_idx[k] + c.el) + 1];
-        lc[k] = tab[floor_i32(chip_idx[k] - c.el) + 1];
-        if constexpr (ARMS == 5) {
-            vec[k] = tab[floor_i32(chip_idx[k] + c.vel) + 1];
-            vlc[k] = tab[floor_i32(chip_idx[k] - c.vel) + 1];
+        for (int k = 0; k < NB; ++k) {
+            pc[k] = tab[floor_i32(chip_idx[k] + chip_idx[k]) + 2];
+            ec[k] = tab[floor_i32(__builtin_fmaf(chip_idx[k], 2.0f, el2)) + 2];
+            lc[k] = tab[floor_i32(__builtin_fmaf(chip_idx[k], 2.0f, -el2)) + 2];
+            if constexpr (ARMS == 5) {
+                vec[k] = tab[floor_i32(__builtin_fmaf(chip_idx[k], 2.0f, vel2)) + 2];
+                vlc[k] = tab[floor_i32(__builtin_fmaf(chip_idx[k], 2.0f, -vel2)) + 2];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            pc[k] = tab[floor_i32(chip_idx[k]) + 1];
+            ec[k] = tab[floor_i32(chip_idx[k] + c.el) + 1];
+            lc[k] = tab[floor_i32(chip_idx[k] - c.el) + 1];
+            if constexpr (ARMS == 5) {
+                vec[k] = tab[floor_i32(chip_idx[k] + c.vel) + 1];
+                vlc[k] = tab[floor_i32(chip_idx[k] - c.vel) + 1];
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -334,11 +362,11 @@ __device__ __forceinline__ void correlate_block_fast(const EpochConsts& c, const
 #pragma unroll
         for (int k = 0; k < NB; ++k) kq[k] = __builtin_rintf(w[k] * 0.636619747f);
 #pragma unroll
-        for (int k = 0; k < NB; ++k) ph[k] = kq[k] * c1;
+        for (int k = 0; k < NB; ++k) ph[k] = kq[k] * -c1;                                   // -(k c1), exactly (held negated: the fused
+#pragma unroll                                                                              // multiply-add then takes c1 as a literal, not from
+        for (int k = 0; k < NB; ++k) pl[k] = __builtin_fmaf(kq[k], c1, ph[k]);              // a scalar register: half the issue cost)
 #pragma unroll
-        for (int k = 0; k < NB; ++k) pl[k] = __builtin_fmaf(kq[k], c1, -ph[k]);
-#pragma unroll
-        for (int k = 0; k < NB; ++k) w[k] = w[k] - ph[k];
+        for (int k = 0; k < NB; ++k) w[k] = w[k] + ph[k];
 #pragma unroll
         for (int k = 0; k < NB; ++k) pl[k] = __builtin_fmaf(kq[k], c2, pl[k]);
 #pragma unroll
@@ -371,7 +399,7 @@ __device__ __forceinline__ void correlate_block_fast(const EpochConsts& c, const
     // ---- stage 3: sums (chips are exactly +-1 x BOC sign: the product is exact, fma(x, chip, acc) == acc + x*chip bitwise)
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        if (BOC_T) {   // BOC(1,1): sub-carrier sign = +1 on the first half chip, -1 on the second (fract = x - floor(x))
+        if (BOC_T != 0 && BOC_T != 1) {   // (run-time BOC flag: not instantiated by the persistent kernel; the half-chip table carries the sign)
             pc[k] = __builtin_amdgcn_fractf(chip_idx[k]) < 0.5f ? pc[k] : -pc[k];
             ec[k] = __builtin_amdgcn_fractf(chip_idx[k] + c.el) < 0.5f ? ec[k] : -ec[k];
             lc[k] = __builtin_amdgcn_fractf(chip_idx[k] - c.el) < 0.5f ? lc[k] : -lc[k];
@@ -790,9 +818,15 @@ struct TrkPersistArgs {
     gm_trk_state* states;
     const cf* ring; uint64_t mask, head;
     int G, epochs;
+    int GS;                          // granules per arm in the exchange block: 16 for G <= 16 (a DPP row per arm, absent partners read as
+                                     // +0.0: the totals then take the row-scan path for EVERY G up to 16), else G
     int stamp_block;                 // diagnostic: the workgroup whose phases are stamped (GM_TRK_STAMP_WG, default 0)
     int force_write_through;         // diagnostic (GM_TRK_FORCE_SC1=1): keep the cross-XCD exchange form even when a channel's workgroups share an XCD
     uint32_t per;                    // samples per workgroup slice (multiple of 64), fixed for the launch
+    uint32_t stagger;                // 10 ns ticks a channel of stagger class 1 waits before its first epoch (class k: k times that; 0: none): see the kernel
+    int fair_mode;                   // 1: raised for every other block; 2 (default): for three blocks of four; 3: for all of them (GM_TRK_FAIR, diagnostics)
+    int fair_share;                  // CUs per XCD when the epochs are throughput-shaped (the five-arm loop's priority toggle), else 0
+    uint32_t stagger_tab[2];         // the classes, 2 bits per channel of an XCD: [0] XCDs holding ceil(C / 8) channels, [1] the others
     uint32_t tag_base;               // unique per launch: tag = tag_base + epoch + 1
     unsigned long long* xchg;        // [2][n_channels][G][NV] granules of partials, then [n_channels][G] of XCC_IDs
     gm_trk_out* outs; uint8_t *processed, *lost, *lost_prn;   // [epochs][n_channels] (may be null)
@@ -803,10 +837,13 @@ struct TrkPersistArgs {
 
 // diagnostic stamp (gm_trk_debug_stamps): one asm statement so the wait stays with the read, fenced against
 // the scheduler on both sides (cdna_hip_programming.md §7 "In-kernel stamps")
+// s_memrealtime: the constant 100 MHz counter (10 ns per unit).  s_memtime's rate is NOT constant on this part — the same epoch read
+// 27 000 units with 432 workgroups resident and 44 000 with 240, in the same wall time (round 6) — so phase stamps in its units
+// cannot be compared between configurations.
 __device__ __forceinline__ long long stamp_now() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
     return (long long)t;
 }
@@ -933,8 +970,10 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     __shared__ gm_trk_state st_sh[2];
     static_assert(NW >= 4, "waves 0/1 run the two halves of the serial section, waves 2/3 the phase advances");
     __shared__ float gathered[2][256];  // the G*NV partials of one epoch (G other than 16 / 32): one staging area per gathering wave
-    extern __shared__ float chips_pad[];   // the channel's chip row as floats, one guard entry at each end (correlate_sample_fast)
-    float* const chips = chips_pad;
+    extern __shared__ float chips_pad[];   // the channel's chip row as floats, one guard entry at each end (correlate_sample_fast);
+    // BOC: the half-chip table (with the sub-carrier sign) in FRONT of it (boc_plain_offset)
+    float* const chips = BOC_T == 1 ? chips_pad + boc_plain_offset(cfg.code_len) : chips_pad;
+    const float* const fast_tab = chips_pad;
 
     // an earlier launch of the same call (more than 4095 passes are several launches) has timed out: do nothing, the host
     // reports the error after it synchronises
@@ -954,7 +993,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     // epoch's partials); after the first epoch's exchange each one has read all G of them and, when they agree, later epochs
     // publish with PLAIN stores, which stay in the XCD's L2 where the partners' L1-bypassing polls find them (a write-through
     // store drops the line, so the poll goes out to the fabric: 2050 -> 550 cycles of waiting per epoch at 32 channels).
-    unsigned long long* const xcc_slot = a.xchg + size_t(2) * C * a.G * NV + size_t(ch) * a.G;
+    unsigned long long* const xcc_slot = a.xchg + size_t(2) * C * a.GS * NV + size_t(ch) * a.G;
     uint32_t my_xcc = 0;
     bool same_xcd = false;
     if (ran) {
@@ -968,6 +1007,14 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
         if (tid == 0) {   // what floor(phase) = -1 and = len read (get_ca_chip :275: `as usize` saturates / FIXED wraps; `% len`)
             chips[0] = float(crow[cfg.code_index_mode == GM_CODE_INDEX_FAITHFUL ? 0 : cfg.code_len - 1]);
             chips[cfg.code_len + 1] = float(crow[0]);
+        }
+        if constexpr (BOC_T == 1) {   // the half-chip table of correlate_block_fast: entry j + 2 <-> half chip j = -2 .. 2 len + 1
+            float* const t2 = chips_pad;
+            for (int j = tid; j < 2 * cfg.code_len; j += T) t2[j + 2] = (j & 1) ? -float(crow[j >> 1]) : float(crow[j >> 1]);
+            if (tid == 0) {
+                const float lo = float(crow[cfg.code_index_mode == GM_CODE_INDEX_FAITHFUL ? 0 : cfg.code_len - 1]), hi = float(crow[0]);
+                t2[0] = lo; t2[1] = -lo; t2[2 * cfg.code_len + 2] = hi; t2[2 * cfg.code_len + 3] = -hi;
+            }
         }
         // an upper bound of any epoch's sample count in this launch, for the fast forms' range checks
         // (wave-uniform floats that live for the whole launch are pinned to scalar registers: left in VGPRs they were the
@@ -990,6 +1037,35 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
         cf pf2 = a.ring[(s0.next_sample_index + i0 + tid + 2 * T) & a.mask];
         cf pf3 = a.ring[(s0.next_sample_index + i0 + tid + 3 * T) & a.mask];
 
+        // Throughput-shaped epochs (many samples per lane): the two workgroups a CU holds belong to different channels, start
+        // together and do the same work, so they stay in lock-step — both correlate at once (sharing the issue slots), then both
+        // sit in their serial sections (exchange + scalar update: the CU idles).  Channels that share CUs therefore start a third
+        // (or two thirds) of an epoch apart, once per launch: from then on one tenant's serial section runs under the other's
+        // correlation.  All G workgroups of a channel take the same decision (they meet in every epoch's exchange).  A hint
+        // only: wherever the dispatcher puts the workgroups, the results are the same.
+        if (a.stamps && a.stamp_block == -2 && tid == 0) {        // diagnostic (GM_TRK_STAMP_WG=-2): where the dispatcher put every workgroup
+            uint32_t hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            a.stamps[blockIdx.x] = (long long)(((unsigned long long)my_xcc << 32) | hw);
+            a.stamps[512 + blockIdx.x] = stamp_now();            // ... and when it got going (absolute, 10 ns); its end at [1024 + b] below
+        }
+        // (see the five-arm correlation loop) second round of the dispatcher over this XCD's CUs: the younger tenant of its CU
+        const bool younger = a.fair_share && int(blockIdx.x >> 3) >= a.fair_share;
+        if (a.stagger) {
+            // class of this channel (2 bits per channel of the XCD, by its index there; one table for the XCDs that hold the larger
+            // channel count, one for the others): a colouring, made on the host, of "shares CUs with" — see launch_trk_persistent
+            const int xcd = int(blockIdx.x & 7), local = int(blockIdx.x >> 3) / a.G;
+            const int count = (C - xcd + 7) >> 3, most = (C + 7) >> 3;
+            const uint32_t cls = ((count == most ? a.stagger_tab[0] : a.stagger_tab[1]) >> (2 * (local & 7))) & 3u;
+            if (cls) {
+                if (tid == 0) {
+                    const long long t0 = wall_clock64();                       // 100 MHz, whatever the shader clock does
+                    const long long until = (long long)(a.stagger * cls);
+                    while (wall_clock64() - t0 < until) __builtin_amdgcn_s_sleep(32);
+                }
+                __syncthreads();
+            }
+        }
         for (; e < a.epochs; ++e) {
             const uint32_t n = sh.alive ? sh.n : 0u;
             if (n == 0) break;                     // state is identical in the G workgroups: they all leave
@@ -1019,6 +1095,89 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 constexpr float TF = float(T);
                 // block width: four samples with three arms; two with five (ten accumulators per sample: four spill)
                 constexpr uint32_t IL = ARMS == 3 ? 4 : 2;
+                if constexpr (ARMS == 5) {
+                    // Five arms: throughput-shaped epochs (BASELINE configs[4]: 200 000 samples per channel-epoch, ~33 per lane), so
+                    // the samples travel TWO blocks ahead of their use in a rotating pair of named register pairs — (pf0, pf1)
+                    // feeds the blocks at j = 0, 4, 8 .. and is refilled with the samples of j + 4 the moment it has been read,
+                    // (pf2, pf3) likewise for j = 2, 6, 10 .. — instead of being loaded at the head of the block that consumes them
+                    // (every wave then sat out most of a memory round trip per block: 45 % of the wave cycles parked, round 5).
+                    // At the loop's entry the four registers hold samples 0 .. 3 (requested during the previous epoch's exchange).
+#if GM_TRK_IL5 == 4
+                    // blocks of FOUR samples (four interleaved dependent chains per wave: the phase is bound by the latency of a
+                    // wave's instruction stream), the NEXT block's samples requested the moment this block's have been taken out
+                    // of (pf0 .. pf3); sample q of a block adds into the same set of sums as in blocks of two (even -> acc, odd -> acc2)
+                    for (uint32_t j = 0; j < wtot; j += 4) {
+                        const uint32_t left = wtot - j;
+                        cf dd[4];
+                        float ff[4];
+                        dd[0] = pf0; dd[1] = pf1; dd[2] = pf2; dd[3] = pf3;
+                        if (j + 4 < wtot) {          // (wave-uniform; a lane past its own count reads a sample it will not use: the ring is masked)
+                            pf0 = a.ring[(win + b0 + (j + 4) * T) & a.mask];
+                            pf1 = a.ring[(win + b0 + (j + 5) * T) & a.mask];
+                            pf2 = a.ring[(win + b0 + (j + 6) * T) & a.mask];
+                            pf3 = a.ring[(win + b0 + (j + 7) * T) & a.mask];
+                        }
+                        if (j + 4 > full) {          // wave-uniform: this block touches the ragged last row
+#pragma unroll
+                            for (uint32_t q = 0; q < 4; ++q) dd[q] = j + q < tot ? dd[q] : zero;
+                        }
+                        ff[0] = fb0 + float(j * T);
+#pragma unroll
+                        for (uint32_t q = 1; q < 4; ++q) ff[q] = ff[0] + float(q) * TF;
+                        if (left >= 4) correlate_block_fast<ARMS, BOC_T, 4>(ec, fast_tab, dd, ff, acc, acc2);
+                        else if (left == 3)
+                            correlate_block_fast<ARMS, BOC_T, 3>(ec, fast_tab, reinterpret_cast<const cf(&)[3]>(dd), reinterpret_cast<const float(&)[3]>(ff), acc, acc2);
+                        else if (left == 2)
+                            correlate_block_fast<ARMS, BOC_T, 2>(ec, fast_tab, reinterpret_cast<const cf(&)[2]>(dd), reinterpret_cast<const float(&)[2]>(ff), acc, acc2);
+                        else
+                            correlate_block_fast<ARMS, BOC_T, 1>(ec, fast_tab, reinterpret_cast<const cf(&)[1]>(dd), reinterpret_cast<const float(&)[1]>(ff), acc, acc2);
+                    }
+#else
+                    // `full` rows hold a sample for EVERY lane of the workgroup: their blocks take the registers as they are; only the
+                    // ragged last row (wtot = full + 1) zeroes the lanes beyond their count (a compare + two selects per sample
+                    // otherwise: half-rate instructions on every sample of the epoch)
+                    const auto run2 = [&](uint32_t j, cf s0, cf s1) {
+                        const uint32_t left = wtot - j;
+                        cf dd[2];
+                        float ff[2];
+                        dd[0] = s0; dd[1] = s1;
+                        if (j + 2 > full) {                         // wave-uniform: this block touches the ragged row
+                            dd[0] = j < tot ? s0 : zero;
+                            dd[1] = j + 1 < tot ? s1 : zero;
+                        }
+                        ff[0] = fb0 + float(j * T);
+                        ff[1] = ff[0] + TF;
+                        if (left >= 2) correlate_block_fast<ARMS, BOC_T, 2>(ec, fast_tab, dd, ff, acc, acc2);
+                        else correlate_block_fast<ARMS, BOC_T, 1>(ec, fast_tab, reinterpret_cast<const cf(&)[1]>(dd), reinterpret_cast<const float(&)[1]>(ff), acc, acc2);
+                    };
+                    for (uint32_t j = 0; j < wtot; j += 4) {
+                        const cf u0 = pf0, u1 = pf1;
+                        if (j + 4 < wtot) {          // (wave-uniform; a lane past its own count reads a sample it will not use: the ring is masked)
+                            pf0 = a.ring[(win + b0 + (j + 4) * T) & a.mask];
+                            pf1 = a.ring[(win + b0 + (j + 5) * T) & a.mask];
+                        }
+                        // Fair shares for the two tenants of a CU: a SIMD issues for its OLDEST ready wave, so the workgroup that got to
+                        // the CU first (the dispatcher's first round over the XCD) ran a whole epoch in 13.5 us while its co-tenant of
+                        // the second round took 20 .. 24 us (per-workgroup start / end times, tools/trk_placement.py) — and the launch
+                        // lasts as long as its slowest channel.  The second-round workgroup raises its priority for three blocks of four
+                        // (fair_mode 2; every other block, mode 1, still leaves it behind — it spends most of its TIME in the blocks it
+                        // runs unraised; always, mode 3, starves the other tenant instead): channel durations within 6 % of each other,
+                        // 21.6 -> 19.7 us per code period on one box.  Rotating four priority levels over the four waves of a SIMD, or
+                        // raising the upper half of each workgroup's waves as well, did worse (20.4 / 20.2 us).
+                        if (younger) __builtin_amdgcn_s_setprio(1);
+                        run2(j, u0, u1);
+                        if (younger && !(a.fair_mode >= 3 || (a.fair_mode == 2 && (j & 4)))) __builtin_amdgcn_s_setprio(0);
+                        if (j + 2 >= wtot) break;
+                        const cf u2 = pf2, u3 = pf3;
+                        if (j + 6 < wtot) {
+                            pf2 = a.ring[(win + b0 + (j + 6) * T) & a.mask];
+                            pf3 = a.ring[(win + b0 + (j + 7) * T) & a.mask];
+                        }
+                        run2(j + 2, u2, u3);
+                    }
+                    if (younger) __builtin_amdgcn_s_setprio(0);
+#endif
+                } else
                 for (uint32_t j = 0; j < wtot; j += IL) {                // the first block(s) come from the prefetched registers
                     const uint32_t left = wtot - j;
                     cf dd[IL];
@@ -1032,9 +1191,6 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                             if (tot > 2) dd[2] = pf2;
                             if (tot > 3) dd[3] = pf3;
                         }
-                    } else if (IL == 2 && j == 2) {
-                        if (tot > 2) dd[0] = pf2;
-                        if (tot > 3) dd[1] = pf3;
                     } else {
 #pragma unroll
                         for (uint32_t q = 0; q < IL; ++q)
@@ -1044,13 +1200,13 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
 #pragma unroll
                     for (uint32_t q = 1; q < IL; ++q) ff[q] = ff[0] + float(q) * TF;
                     // one instantiation per block size; a slot beyond the wave's count (left < IL) is not computed at all
-                    if (left >= IL) correlate_block_fast<ARMS, BOC_T, IL>(ec, chips, dd, ff, acc, acc2);
+                    if (left >= IL) correlate_block_fast<ARMS, BOC_T, IL>(ec, fast_tab, dd, ff, acc, acc2);
                     else if (IL == 4 && left == 3)
-                        correlate_block_fast<ARMS, BOC_T, 3>(ec, chips, reinterpret_cast<const cf(&)[3]>(dd), reinterpret_cast<const float(&)[3]>(ff), acc, acc2);
+                        correlate_block_fast<ARMS, BOC_T, 3>(ec, fast_tab, reinterpret_cast<const cf(&)[3]>(dd), reinterpret_cast<const float(&)[3]>(ff), acc, acc2);
                     else if (IL == 4 && left == 2)
-                        correlate_block_fast<ARMS, BOC_T, 2>(ec, chips, reinterpret_cast<const cf(&)[2]>(dd), reinterpret_cast<const float(&)[2]>(ff), acc, acc2);
+                        correlate_block_fast<ARMS, BOC_T, 2>(ec, fast_tab, reinterpret_cast<const cf(&)[2]>(dd), reinterpret_cast<const float(&)[2]>(ff), acc, acc2);
                     else
-                        correlate_block_fast<ARMS, BOC_T, 1>(ec, chips, reinterpret_cast<const cf(&)[1]>(dd), reinterpret_cast<const float(&)[1]>(ff), acc, acc2);
+                        correlate_block_fast<ARMS, BOC_T, 1>(ec, fast_tab, reinterpret_cast<const cf(&)[1]>(dd), reinterpret_cast<const float(&)[1]>(ff), acc, acc2);
                 }
             } else if (STRICT && (sh.fast_car & sh.fast_code)) {   // strict_libm: the exact fast forms of the code phase and of
                 // x / fs, the carrier's cos / sin by sincosf_glibc (f64) — sample by sample, no prefetch use
@@ -1101,7 +1257,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 const bool st1_on = a.stamps && int(blockIdx.x) == a.stamp_block && tid == 64;
                 // this workgroup's partial (waves added in a fixed order), published as {value, tag} granules
                 const uint32_t tag = a.tag_base + uint32_t(e) + 1u;
-                unsigned long long* slot = a.xchg + (size_t(e & 1) * C + ch) * a.G * NV;
+                unsigned long long* slot = a.xchg + (size_t(e & 1) * C + ch) * a.GS * NV;
                 if (wave == 0 && lane < NV) {
                     float pw[NW];
 #pragma unroll
@@ -1112,13 +1268,14 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     const unsigned long long gran =
                         (unsigned long long)__float_as_uint(p) | ((unsigned long long)tag << 32);
                     if (same_xcd)      // plain: the line stays in this XCD's L2 (see the hand-shake above)
-                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(&slot[lane * a.G + g]), "v"(gran) : "memory");
+                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(&slot[lane * a.GS + g]), "v"(gran) : "memory");
                     else
-                        __hip_atomic_store(&slot[lane * a.G + g], gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // arm-major: [k][g]
+                        __hip_atomic_store(&slot[lane * a.GS + g], gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // arm-major: [k][g], GS granules per arm
                 }
                 if (st_on) stp[3] = stamp_now();
-                // gather the G partials: lane l polls granules l, l+64, ... (G*NV <= 256)
-                const int ng = a.G * NV;
+                // gather the G partials: lane l polls granules l, l+64, ... (GS*NV <= 256); with GS = 16 > G the places of partners
+                // that do not exist are never polled and count as +0.0
+                const int ng = a.GS * NV;
                 float val[4] = {0.f, 0.f, 0.f, 0.f};
                 const long long t0 = wall_clock64();
                 bool to = false;
@@ -1128,7 +1285,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 bool pending[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    pending[q] = lane + q * 64 < ng;
+                    pending[q] = lane + q * 64 < ng && (a.GS == a.G || ((lane + q * 64) & 15) < a.G);
                     if (pending[q]) gr[q] = __hip_atomic_load(&slot[lane + q * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
@@ -1148,7 +1305,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (lane + q * 64 < ng) val[q] = __uint_as_float(uint32_t(gr[q]));
+                    if (lane + q * 64 < ng) val[q] = __uint_as_float(uint32_t(gr[q]));       // (never polled: gr = 0 = +0.0f)
                 if (e == 0 && wave == 0) {   // the hand-shake: the partners' XCC_IDs (published before their first partials were)
                     const unsigned long long want = (unsigned long long)(a.tag_base + 1u);
                     unsigned long long xg = want << 32 | my_xcc;
@@ -1164,12 +1321,12 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 if (st_on) { stp[4] = stamp_now(); stp[45] = (long long)rounds; }
                 if (st1_on) { stp[40] = stamp_now(); stp[46] = (long long)rounds; }
                 // totals of the G partials of every arm, identical in all lanes and in all workgroups of the channel.
-                // Granules are arm-major ([k][g]).  G == 16: arm k's partials sit in one DPP row of 16 lanes (arms 0-3 in
+                // Granules are arm-major ([k][g]).  G <= 16 (GS == 16): arm k's partials sit in one DPP row of 16 lanes (arms 0-3 in
                 // the first sweep's registers, 4.. in the next), so four row_shr adds leave the arm total in the row's last
                 // lane and a readlane broadcasts it — no LDS, no fences.  Other G: staged in LDS (DS operations of one wave
                 // complete in order) and added by lane k in workgroup order.
                 float v[NV];
-                if (a.G == 16) {
+                if (a.GS == 16) {
                     float r[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) r[q] = val[q];
@@ -1294,6 +1451,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
             // `sh` only after the next epoch's first barrier, which no wave reaches before reading it above
             if (st_on) stp[7] = stamp_now();
         }
+        if (a.stamps && a.stamp_block == -2 && tid == 0) a.stamps[1024 + blockIdx.x] = stamp_now();
         if (tid == 0 && timed_out) {
             *a.error_flag = 1;                                                                       // host's copy (pinned)
             __hip_atomic_store(a.error_flag_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // later launches' copy
@@ -1321,8 +1479,15 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     }
 }
 
+// granules per arm in the exchange block (TrkPersistArgs::GS); the block is 2 * n_channels * GS * (2 * arms) granules + n_channels * G
+int trk_persistent_granule_stride(int G) { return G <= 16 ? 16 : G; }
+
 // dynamic LDS of the persistent kernel: the chip row as floats with one guard entry at each end, rounded up to 16 B
-static size_t trk_persistent_lds(const TrkDevCfg& cfg) { return (size_t(cfg.code_len + 2) * sizeof(float) + 15) & ~size_t(15); }
+static size_t trk_persistent_lds(const TrkDevCfg& cfg) {
+    size_t floats = size_t(cfg.code_len + 2);                                    // the padded chip row
+    if (cfg.boc11) floats += size_t(boc_plain_offset(cfg.code_len));             // + the half-chip table of the BOC fast path in front of it
+    return (floats * sizeof(float) + 15) & ~size_t(15);
+}
 
 void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_codes, gm_trk_state* d_states,
                            const cf* ring, uint64_t mask, uint64_t head, int G, int epochs, uint32_t tag_base,
@@ -1332,14 +1497,59 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     a.error_flag_dev = d_error_dev;
     a.stamps = d_stamps;
     a.cfg = cfg; a.codes = d_codes; a.states = d_states; a.ring = ring; a.mask = mask; a.head = head;
-    a.G = G; a.epochs = epochs; a.tag_base = tag_base;
+    a.G = G; a.GS = trk_persistent_granule_stride(G); a.epochs = epochs; a.tag_base = tag_base;
     a.stamp_block = diag_int("GM_TRK_STAMP_WG", 0);
     a.force_write_through = diag_int("GM_TRK_FORCE_SC1", 0) != 0 ? 1 : 0;
     {   // slice length from the nominal code period (+1 % margin), whole wavefronts
         const float nn = roundf(cfg.fs / (cfg.nominal_code_rate / cfg.code_len_f));
         const uint64_t n_nom = nn > 0 ? uint64_t(nn * 1.01f) + 64 : 64;
         a.per = uint32_t(((n_nom + G - 1) / G + 63) / 64 * 64);
-    } a.xchg = d_xchg; a.outs = d_outs;
+    }
+    {   // stagger (see the kernel): only when an epoch is many samples per lane, i.e. when correlation, not the serial chain, fills it.
+        // The dispatcher deals an XCD's workgroups round-robin over its CUs (measured: tools/trk_placement.py), so ordinals o and
+        // o + CUs-per-XCD share a CU; channel `l` of an XCD owns ordinals [l G, (l + 1) G).  Channels that share a CU get different
+        // classes (0, 1, 2: a greedy colouring — the conflict graph of five channels of twelve workgroups on 32 CUs is a 5-cycle,
+        // so two classes do not do), class k starts k thirds of an epoch late.
+        const uint32_t rows = a.per / uint32_t(TRK_PERSIST_THREADS);                 // samples per lane and epoch
+        // (measured, round 6: the stagger alone buys NOTHING — 21.2 us per code period at BASELINE configs[4] with and without, plus
+        // its own delay — because the co-tenants are not symmetric: see `fair_share`.  Off unless asked for; kept for experiments.)
+        const int k = diag_int("GM_TRK_STAGGER_K", 0);                               // 10 ns ticks per row of samples and class
+        a.stagger = rows >= 8 && G >= 2 ? rows * uint32_t(k < 0 ? 0 : k) : 0u;
+        a.stagger_tab[0] = a.stagger_tab[1] = 0u;
+        static int cus_cache[16] = {0};                     // per device, asked once (hipGetDeviceProperties is not a per-launch call)
+        int dev = 0, cus = 32;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int& c = cus_cache[dev & 15];
+            if (c == 0) {
+                hipDeviceProp_t prop;
+                c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) ? prop.multiProcessorCount / 8 : 32;
+            }
+            cus = c;
+        }
+        a.fair_mode = diag_int("GM_TRK_FAIR", 2);
+        a.fair_share = (rows >= 8 && a.fair_mode != 0) ? cus : 0;
+        if (a.stagger) {
+            const int most = (cfg.n_channels + 7) / 8;
+            for (int v = 0; v < 2; ++v) {
+                const int count = most - v;
+                if (count < 1 || count > 8) continue;
+                int cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int l = 0; l < count; ++l) {           // greedy: the smallest class no earlier co-tenant has
+                    bool used[4] = {false, false, false, false};
+                    for (int m = 0; m < l; ++m) {
+                        bool share = false;                  // some ordinal of l and some ordinal of m differ by a multiple of `cus`
+                        for (int o = l * G; o < (l + 1) * G && !share; ++o)
+                            for (int q = m * G; q < (m + 1) * G; ++q)
+                                if ((o - q) % cus == 0) { share = true; break; }
+                        if (share) used[cls[m]] = true;
+                    }
+                    cls[l] = !used[0] ? 0 : !used[1] ? 1 : !used[2] ? 2 : 3;
+                    a.stagger_tab[v] |= uint32_t(cls[l]) << (2 * l);
+                }
+            }
+        }
+    }
+    a.xchg = d_xchg; a.outs = d_outs;
     a.processed = d_processed; a.lost = d_lost; a.lost_prn = d_lost_prn; a.error_flag = d_error;
     const size_t lds = trk_persistent_lds(cfg);
     const dim3 grid(trk_persistent_slots(cfg.n_channels) * G);     // channel slots: n_channels rounded up to the eight XCDs
