@@ -1180,6 +1180,10 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 } else
                 for (uint32_t j = 0; j < wtot; j += IL) {                // the first block(s) come from the prefetched registers
                     const uint32_t left = wtot - j;
+                    if (younger) {                                       // fair issue shares for a CU's two tenants (see the five-arm loop)
+                        if (a.fair_mode >= 3 || (j & (a.fair_mode == 2 ? 12u : 4u))) __builtin_amdgcn_s_setprio(1);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
                     cf dd[IL];
                     float ff[IL];
 #pragma unroll
@@ -1208,6 +1212,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     else
                         correlate_block_fast<ARMS, BOC_T, 1>(ec, fast_tab, reinterpret_cast<const cf(&)[1]>(dd), reinterpret_cast<const float(&)[1]>(ff), acc, acc2);
                 }
+                if (ARMS == 3 && younger) __builtin_amdgcn_s_setprio(0);
             } else if (STRICT && (sh.fast_car & sh.fast_code)) {   // strict_libm: the exact fast forms of the code phase and of
                 // x / fs, the carrier's cos / sin by sincosf_glibc (f64) — sample by sample, no prefetch use
                 for (uint32_t i = i0 + tid; i < i1; i += T)
