@@ -1555,6 +1555,7 @@ struct gm_trk {
     bool timing = false; uint32_t timed_launches = 0;
     // persistent multi-epoch kernel: G workgroups per channel, granule exchange buffer, launch counter
     int G = 1;
+    bool packed = false;                // the persistent grid's packed layout (trk_kernels.hip): G workgroups per channel dealt over the XCDs as one run
     unsigned long long* d_xchg = nullptr;
     int* d_error = nullptr;             // host-pinned, device-visible: written by the kernel only when an exchange times out
     int* d_error_dev = nullptr;         // its device-memory twin, read by every later launch (trk_persistent_kernel)
@@ -1733,9 +1734,20 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
             while (g > 1 && g * nv > 256) --g;
             if (g > 16 && g < 32) g = 16;
         }
+        {   // Packed layout: a channel count that does not fill the eight XCDs evenly (36 -> 5, 5, 5, 5, 4, 4, 4, 4 slots of 12
+            // workgroups: 432 of 512 places, and the launch lasts as long as the 5-channel XCDs) is dealt as ONE run of C * G
+            // workgroups, 14 each at 36 channels (504 places); a channel at the edge of an XCD's piece exchanges through the fabric.
+            // Only where correlation fills the epoch (>= 8 samples per lane): a latency-chain launch wants its channels on one XCD.
+            const size_t places = (size_t(cus) * per_cu) / (cfg->share_device ? 4 : 1);
+            int gp = int(places / t->C < 16 ? places / t->C : 16);
+            while (gp > 1 && gp * nv > 256) --gp;
+            const float nn = roundf(d.fs / (d.nominal_code_rate / d.code_len_f));
+            const bool shaped = nn > 0 && gp >= 1 && nn / float(gp) / 512.0f >= 8.0f;
+            if ((t->C % 8) != 0 && gp > g && shaped && gm::diag_int("GM_TRK_PACKED", 1) != 0) { g = gp; t->packed = true; }
+        }
         {   // diagnostic override (GM_DIAGNOSTICS=1 only; must keep n_channels * G resident)
             const int f = gm::diag_int("GM_TRK_G", 0);
-            if (f >= 1 && f <= 32 && size_t(f) * slots <= size_t(cus) * per_cu && f * nv <= 256) g = f;
+            if (f >= 1 && f <= 32 && size_t(f) * slots <= size_t(cus) * per_cu && f * nv <= 256) { g = f; t->packed = false; }
         }
         t->G = g;
         const size_t xb = (size_t(2) * t->C * gm::trk_persistent_granule_stride(g) * nv + size_t(t->C) * g) * sizeof(unsigned long long);   // partials + XCC_ID granules
@@ -1952,7 +1964,7 @@ static int trk_launch_all(gm_trk* t, gm_ring* ring, uint32_t epochs, uint64_t he
         const size_t o = size_t(e0) * t->C;
         t->launch_seq = (t->launch_seq + 1) & 0xfffffu;
         if (t->launch_seq == 0) t->launch_seq = 1;
-        gm::launch_trk_persistent(t->stream, t->dc, t->d_codes, t->d_states, ring->d_buf, ring->mask, head, t->G,
+        gm::launch_trk_persistent(t->stream, t->dc, t->d_codes, t->d_states, ring->d_buf, ring->mask, head, t->G, t->packed ? 1 : 0,
                                   int(ne), t->launch_seq << 12, t->d_xchg, t->d_outs + o, t->d_proc + o, t->d_lost + o,
                                   t->d_lostprn + o, t->d_error, t->d_error_dev, (t->d_stamps && e0 == 0 && ne <= t->stamps_cap) ? t->d_stamps : nullptr);
     }

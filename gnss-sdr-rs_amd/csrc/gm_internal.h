@@ -192,7 +192,7 @@ int trk_persistent_granule_stride(int G);      // granules per arm in the exchan
 void launch_trk_results_to_host(hipStream_t, const void* d_src, void* h_dst_pinned, size_t bytes, const void* d_src2 = nullptr, void* h_dst2_pinned = nullptr,
                                 size_t bytes2 = 0);
 void launch_trk_persistent(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_trk_state* d_states,
-                           const cf* ring, uint64_t mask, uint64_t head, int G, int epochs, uint32_t tag_base,
+                           const cf* ring, uint64_t mask, uint64_t head, int G, int packed, int epochs, uint32_t tag_base,
                            unsigned long long* d_xchg, gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost,
                            uint8_t* d_lost_prn, int* d_error, int* d_error_dev, long long* d_stamps);
 

@@ -818,6 +818,7 @@ struct TrkPersistArgs {
     gm_trk_state* states;
     const cf* ring; uint64_t mask, head;
     int G, epochs;
+    int packed;                      // 0: channel slots x G (a channel's workgroups on one XCD); else the packed layout's workgroups per XCD
     int GS;                          // granules per arm in the exchange block: 16 for G <= 16 (a DPP row per arm, absent partners read as
                                      // +0.0: the totals then take the row-scan path for EVERY G up to 16), else G
     int stamp_block;                 // diagnostic: the workgroup whose phases are stamped (GM_TRK_STAMP_WG, default 0)
@@ -954,9 +955,21 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
     // leave at once).  The placement is only the expectation: what the exchange does is decided from the XCC_ID each
     // workgroup reads from the hardware (see the exchange below), never from this arithmetic.
     const int C = cfg.n_channels;
-    const int ch = (int(blockIdx.x >> 3) / a.G) * 8 + int(blockIdx.x & 7);
-    const int g = int(blockIdx.x >> 3) % a.G;
-    if (ch >= C) return;
+    int ch, g;
+    if (a.packed) {
+        // Packed layout (throughput-shaped launches whose channel count does not fill the eight XCDs evenly, e.g. 36): the C * G
+        // workgroups form ONE run, dealt to the XCDs in eight equal pieces — workgroup o of XCD x is number x * per_xcd + o of the
+        // run, channel = number / G.  Every place of every CU is used (36 channels: 14 workgroups each, 504 of 512 places, where the
+        // slot layout gave 12 each on 432); a channel at a piece's edge has workgroups on two XCDs and exchanges through the
+        // fabric (the XCC_ID hand-shake below decides that per channel, as always).
+        const int num = int(blockIdx.x & 7) * a.packed + int(blockIdx.x >> 3);
+        if (int(blockIdx.x >> 3) >= a.packed || num >= C * a.G) return;
+        ch = num / a.G; g = num - ch * a.G;
+    } else {
+        ch = (int(blockIdx.x >> 3) / a.G) * 8 + int(blockIdx.x & 7);
+        g = int(blockIdx.x >> 3) % a.G;
+        if (ch >= C) return;
+    }
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     __shared__ float wsum[NW][NV];
@@ -1495,7 +1508,7 @@ static size_t trk_persistent_lds(const TrkDevCfg& cfg) {
 }
 
 void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d_codes, gm_trk_state* d_states,
-                           const cf* ring, uint64_t mask, uint64_t head, int G, int epochs, uint32_t tag_base,
+                           const cf* ring, uint64_t mask, uint64_t head, int G, int packed, int epochs, uint32_t tag_base,
                            unsigned long long* d_xchg, gm_trk_out* d_outs, uint8_t* d_processed, uint8_t* d_lost,
                            uint8_t* d_lost_prn, int* d_error, int* d_error_dev, long long* d_stamps) {
     TrkPersistArgs a;
@@ -1503,6 +1516,7 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     a.stamps = d_stamps;
     a.cfg = cfg; a.codes = d_codes; a.states = d_states; a.ring = ring; a.mask = mask; a.head = head;
     a.G = G; a.GS = trk_persistent_granule_stride(G); a.epochs = epochs; a.tag_base = tag_base;
+    a.packed = packed ? (cfg.n_channels * G + 7) / 8 : 0;
     a.stamp_block = diag_int("GM_TRK_STAMP_WG", 0);
     a.force_write_through = diag_int("GM_TRK_FORCE_SC1", 0) != 0 ? 1 : 0;
     {   // slice length from the nominal code period (+1 % margin), whole wavefronts
@@ -1519,7 +1533,7 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
         // (measured, round 6: the stagger alone buys NOTHING — 21.2 us per code period at BASELINE configs[4] with and without, plus
         // its own delay — because the co-tenants are not symmetric: see `fair_share`.  Off unless asked for; kept for experiments.)
         const int k = diag_int("GM_TRK_STAGGER_K", 0);                               // 10 ns ticks per row of samples and class
-        a.stagger = rows >= 8 && G >= 2 ? rows * uint32_t(k < 0 ? 0 : k) : 0u;
+        a.stagger = rows >= 8 && G >= 2 && !packed ? rows * uint32_t(k < 0 ? 0 : k) : 0u;
         a.stagger_tab[0] = a.stagger_tab[1] = 0u;
         static int cus_cache[16] = {0};                     // per device, asked once (hipGetDeviceProperties is not a per-launch call)
         int dev = 0, cus = 32;
@@ -1557,7 +1571,7 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     a.xchg = d_xchg; a.outs = d_outs;
     a.processed = d_processed; a.lost = d_lost; a.lost_prn = d_lost_prn; a.error_flag = d_error;
     const size_t lds = trk_persistent_lds(cfg);
-    const dim3 grid(trk_persistent_slots(cfg.n_channels) * G);     // channel slots: n_channels rounded up to the eight XCDs
+    const dim3 grid(a.packed ? 8 * a.packed : trk_persistent_slots(cfg.n_channels) * G);     // channel slots: n_channels rounded up to the eight XCDs
     // compile-time arms / code-index mode / BOC: straight-line sample code
     const int key = (cfg.n_arms == 5 ? 4 : 0) | (cfg.code_index_mode == GM_CODE_INDEX_FIXED ? 2 : 0) | (cfg.boc11 ? 1 : 0);
     constexpr int T = TRK_PERSIST_THREADS;

@@ -27,22 +27,30 @@ _lib.check(Lb.gm_trk_debug_stamps(mgr._h, E, buf.ctypes.data_as(C.c_void_p)), 'r
 v = buf.reshape(-1)
 slots = ((Cn + 7) // 8) * 8
 G = int(os.environ.get("TRK_G", "12"))
+PACKED = os.environ.get("TRK_PACKED", "0") == "1"       # the packed layout (trk_kernels.hip): TRK_G = its workgroups per channel (14 at 36 channels)
+per_xcd = (Cn * G + 7) // 8
+def chan_of(b):
+    if PACKED:
+        num = (b & 7) * per_xcd + (b >> 3)
+        return (num // G, num % G) if (b >> 3) < per_xcd and num < Cn * G else (None, None)
+    return ((b >> 3) // G * 8 + (b & 7), (b >> 3) % G)
+NB = 8 * per_xcd if PACKED else slots * G
 place = {}
-for b in range(slots * G):
+for b in range(NB):
     if v[b] == 0:
         continue
     xcc, hw = int(v[b]) >> 32, int(v[b]) & 0xffffffff
     cu, sh, se = (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 0x7
-    ch = (b >> 3) // G * 8 + (b & 7); g = (b >> 3) % G
+    ch, g = chan_of(b)
     place.setdefault((xcc, se, sh, cu), []).append((ch, g, b))
-t0s = np.array([v[512 + b] for b in range(slots * G) if v[b]]); t1s = np.array([v[1024 + b] for b in range(slots * G) if v[b]])
+t0s = np.array([v[512 + b] for b in range(NB) if v[b]]); t1s = np.array([v[1024 + b] for b in range(NB) if v[b]])
 base = t0s.min()
 print("start spread (us): min 0, median %.2f, max %.2f; end (us after the first start): min %.2f median %.2f max %.2f" % (
     np.median(t0s - base) / 100, (t0s.max() - base) / 100, (t1s.min() - base) / 100, np.median(t1s - base) / 100, (t1s.max() - base) / 100))
 chs = {}
-for b in range(slots * G):
+for b in range(NB):
     if v[b]:
-        ch = (b >> 3) // G * 8 + (b & 7)
+        ch = chan_of(b)[0]
         chs.setdefault(ch, []).append(((v[512 + b] - base) / 100, (v[1024 + b] - base) / 100))
 for ch in sorted(chs):
     a_ = np.array(chs[ch])
