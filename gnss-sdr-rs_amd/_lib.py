@@ -145,6 +145,7 @@ SIGNATURES = {
     "gm_frontend_process_dev_batch": (_i, [_vp, _u32, _vp, _i, _vp, _sz, _vp]),
     "gm_frontend_synchronize": (_i, [_vp]),
     "gm_frontend_write_ring": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "gm_frontend_debug_repairs": (_i, [_vp, C.POINTER(_u32)]),
     "gm_trk_create": (_i, [C.POINTER(TrkCfg), C.POINTER(_vp)]),
     "gm_trk_destroy": (_i, [_vp]),
     "gm_trk_start": (_i, [_vp, _u32, C.POINTER(AcqResult)]),

@@ -306,11 +306,291 @@ __global__ __launch_bounds__(FF_T) void frontend_fast_kernel(FrontendArgs a) {
     if (tid == 0) st.state->phase_accumulator = st.ph_table[st.tab_pos_end] * st.tab_scale;   // -0.0 for a negative chain on 0
     if (tid < 16) { if (tid < 8) st.state->bias_re[tid] = bias; else st.state->bias_im[tid - 8] = bias; }
 }
+
+// ------------------------------------------------------------------------------------ speculative form: one block on K workgroups
+// What stays sequential in frontend_fast_kernel is the DC remover's sixteen f32 recurrences bias' = fl(fl(bias * con) + x * alpha):
+// 0.55 ms per block of 2^19 samples on ONE wave, the bound of the whole receiver chain.  They forget their start: two chains
+// fed the same samples contract by con = 0.999 per step and, once within an ulp or two, land on the same float and stay together —
+// measured on the CPU: identical from 1 ulp apart after ~300 steps (worst of 12: 2 400), from 25 ulps after ~1 900 (worst of 42: 5 300).
+// So a block is cut into K runs of pipeline segments, one workgroup each.  Workgroup s
+//   1. GUESSES the sixteen biases WARM segments in front of its run: the recurrence in exact arithmetic (f64) over the <= 16 384 steps
+//      before that point, from the block's true initial state — within ~25 ulps of the f32 chain (its own roundings, a random walk);
+//   2. runs the ordinary pipeline (stage A / chain / stage C) from there, with outputs suppressed through the warm-up: 8 640 steps
+//      in which the guessed chains fall onto the true ones;
+//   3. records the state it ENTERED its run with and the state it left it with.
+// A second, one-workgroup kernel then walks the runs in order: run s stands if the state it entered with is bit for bit the state
+// run s - 1 (already known to be right) left — all sixteen words; else that run alone is done again from the right state (its
+// outputs rewritten), which is the sequential kernel on 1 / K of the block.  EXACT by construction: a guess that did not converge
+// costs time, never a wrong sample.  Workgroups whose warm-up would start before the block simply start AT the block's first
+// sample with the true state (no guess).  The input must not alias the output (the warm-up re-reads samples of earlier runs).
+constexpr int FS_WARM_SEGS = 18;                 // 8 640 chain steps of warm-up
+constexpr int FS_GUESS_STEPS = 16384;            // con^16384 = 7.6e-8: what is left of the prior's error is far below an ulp
+constexpr int FS_PARTS = 128;
+
+struct __attribute__((aligned(16))) FeSharedMem {
+    float xa[2][16][FF_ROW];
+    float ckpt[2][16][FF_QROW];
+    float start[2][16];
+    float lre[LUT], lim[LUT];
+    double parts[FS_PARTS][16];
+    int flag;
+};
+
+__device__ __forceinline__ double fs_pow(double c, uint32_t m) {          // c^m by squaring
+    double r = 1.0;
+    while (m) { if (m & 1u) r *= c; c *= c; m >>= 1; }
+    return r;
+}
+
+// lanes tid < 16: the bias of chain tid at sample p (a multiple of 8) by the exact-arithmetic recurrence from `b_init` (the block's
+// initial state); other lanes: unspecified.  All FF_T lanes take part.
+template <int FMT>
+__device__ __forceinline__ float fs_guess(const FrontendArgs& a, const FrontendArgs::Stream& st, FeSharedMem& S, size_t p, float b_init) {
+    const int tid = threadIdx.x;
+    const uint32_t steps_before = uint32_t(p / 8);
+    const uint32_t nw = steps_before < uint32_t(FS_GUESS_STEPS) ? steps_before : uint32_t(FS_GUESS_STEPS);
+    const uint32_t k0 = steps_before - nw, pl = (nw + FS_PARTS - 1) / FS_PARTS;
+    const int j = tid & 7, part = tid >> 3;                   // SIMD lane j (its re AND im chain), part of the window
+    const double c = double(a.con);
+    const uint32_t ka = k0 + uint32_t(part) * pl, kb = (ka + pl < k0 + nw) ? ka + pl : k0 + nw;
+    double are = 0.0, aim = 0.0;
+    for (uint32_t k = ka; k < kb; ++k) {
+        float re, im;
+        load_sample<FMT>(st.in, size_t(k) * 8 + j, re, im);
+        are = are * c + double(re * a.alpha);                 // x * alpha rounded to f32, as stage A hands it to the chain
+        aim = aim * c + double(im * a.alpha);
+    }
+    const double w = ka < kb ? fs_pow(c, (k0 + nw) - kb) : 0.0;
+    S.parts[part][j] = are * w;
+    S.parts[part][8 + j] = aim * w;
+    __syncthreads();
+    float g = 0.0f;
+    if (tid < 16) {
+        double t = double(b_init) * fs_pow(c, nw);
+        for (int q = 0; q < FS_PARTS; ++q) t += S.parts[q][tid];
+        g = float(t);
+    }
+    __syncthreads();
+    return g;
+}
+
+// The pipeline of frontend_fast_kernel over the pipeline segments [seg_begin, seg_end) of the block, outputs for the segments
+// >= seg_out only.  bias (lanes tid < 16): in = the state entering seg_begin, out = the state leaving seg_end - 1; bias_at_out =
+// the state entering seg_out.  Every lane of the workgroup calls it (it holds workgroup barriers).
+template <int FMT>
+__device__ __forceinline__ void fs_pipeline(const FrontendArgs& a, const FrontendArgs::Stream& st, FeSharedMem& S, int seg_begin, int seg_out,
+                                            int seg_end, size_t n8, float& bias, float& bias_at_out) {
+    const int tid = threadIdx.x;
+    const float alpha = a.alpha, con = a.con;
+    const bool chain_wave = tid < 64;
+    const int hl = tid - 64, HT = FF_T - 64;
+    constexpr int UA = (FF_SEG + (FF_T - 64) - 1) / (FF_T - 64);
+    float nar[UA], nai[UA];
+    auto seg_len = [&](int sg) { const size_t o = size_t(sg) * FF_SEG; return int(n8 - o < size_t(FF_SEG) ? n8 - o : size_t(FF_SEG)); };
+    auto stage_a_loads = [&](int tt) {
+        const bool dA = tt < seg_end;
+        const size_t sA = size_t(dA ? tt : 0) * FF_SEG;
+        const int lA = dA ? seg_len(tt) : 0;
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int i = hl + u * HT;
+            nar[u] = nai[u] = 0.0f;
+            if (i < lA) load_sample<FMT>(st.in, sA + i, nar[u], nai[u]);
+        }
+    };
+    float nxr[4], nxi[4], nph[4];
+    auto stage_c_loads = [&](int tt) {
+        const int scn = tt - 2;
+        const bool dC = scn >= seg_out && scn < seg_end;
+        const size_t sC = size_t(dC ? scn : 0) * FF_SEG;
+        const int stepsC = dC ? seg_len(scn) / 8 : 0;
+        uint64_t p0 = uint64_t(st.tab_pos) + sC;
+        if (p0 >= st.tab_len) p0 = (st.tab_len - st.tab_lambda) + (p0 - (st.tab_len - st.tab_lambda)) % st.tab_lambda;
+        const int j = hl & 7, q = hl >> 3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * q + k, i = 8 * c + j;
+            nxr[k] = nxi[k] = nph[k] = 0.0f;
+            if (c < stepsC) {
+                load_sample<FMT>(st.in, sC + i, nxr[k], nxi[k]);
+                uint32_t p = uint32_t(p0) + uint32_t(i);
+                if (p >= st.tab_len) p -= st.tab_lambda;
+                nph[k] = st.ph_table[p];
+            }
+        }
+    };
+    if (!chain_wave) { stage_a_loads(seg_begin); stage_c_loads(seg_begin); }
+    __syncthreads();
+    for (int t = seg_begin; t < seg_end + 2; ++t) {
+        if (chain_wave) {
+            const int sb = t - 1;
+            if (sb >= seg_begin && sb < seg_end && tid < 16) {
+                __builtin_amdgcn_s_setprio(3);
+                const int steps = seg_len(sb) / 8;
+                const float4* xa4 = reinterpret_cast<const float4*>(&S.xa[sb & 1][tid][0]);
+                float4* ck4 = reinterpret_cast<float4*>(&S.ckpt[sb & 1][tid][0]);
+                S.start[sb & 1][tid] = bias;
+                if (sb == seg_out) bias_at_out = bias;
+                float conv = con;
+                asm volatile("" : "+v"(conv));
+                auto quad = [&](const float4 v) {
+                    bias = bias * conv + v.x;
+                    bias = bias * conv + v.y;
+                    bias = bias * conv + v.z;
+                    bias = bias * conv + v.w;
+                    return bias;
+                };
+                const int q4 = steps / 4, q16 = q4 / 4;
+                for (int g = 0; g < q16; ++g) {
+                    const float4 v0 = xa4[4 * g], v1 = xa4[4 * g + 1], v2 = xa4[4 * g + 2], v3 = xa4[4 * g + 3];
+                    float4 o;
+                    o.x = quad(v0); o.y = quad(v1); o.z = quad(v2); o.w = quad(v3);
+                    ck4[g] = o;
+                }
+                for (int q = q16 * 4; q < q4; ++q) S.ckpt[sb & 1][tid][q] = quad(xa4[q]);
+                for (int k = q4 * 4; k < steps; ++k) bias = bias * conv + S.xa[sb & 1][tid][k];
+                __builtin_amdgcn_s_setprio(0);
+            }
+        } else {
+            float ar[UA], ai[UA];
+#pragma unroll
+            for (int u = 0; u < UA; ++u) { ar[u] = nar[u]; ai[u] = nai[u]; }
+            const int sc = t - 2;
+            const bool doA = t < seg_end, doC = sc >= seg_out && sc < seg_end;
+            const size_t segC = size_t(doC ? sc : 0) * FF_SEG;
+            const int LA = doA ? seg_len(t) : 0;
+            const int LC = doC ? seg_len(sc) : 0;
+            stage_a_loads(t + 1);
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int i = hl + u * HT;
+                if (i < LA) {
+                    S.xa[t & 1][i & 7][i >> 3] = ar[u] * alpha;
+                    S.xa[t & 1][8 + (i & 7)][i >> 3] = ai[u] * alpha;
+                }
+            }
+            float xr[4], xi[4], ph[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { xr[k] = nxr[k]; xi[k] = nxi[k]; ph[k] = nph[k]; }
+            stage_c_loads(t + 1);
+            if (doC) {
+                const int stepsC = LC / 8;
+                const int j = hl & 7, q = hl >> 3;
+                if (4 * q < stepsC) {
+                    float bre = q ? S.ckpt[sc & 1][j][q - 1] : S.start[sc & 1][j];
+                    float bim = q ? S.ckpt[sc & 1][8 + j][q - 1] : S.start[sc & 1][8 + j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = 4 * q + k, i = 8 * c + j;
+                        if (c < stepsC) {
+                            bre = bre * con + xr[k] * alpha;
+                            bim = bim * con + xi[k] * alpha;
+                            const float re = xr[k] - bre, im = xi[k] - bim;
+                            const uint32_t idx = as_usize_mod_lut(ph[k] * st.tab_scale);
+                            const float lc = S.lre[idx], ls = S.lim[idx];
+                            float2 o;
+                            o.x = re * lc + im * ls;
+                            o.y = re * ls - im * lc;
+                            reinterpret_cast<float2*>(st.out)[(st.out_start + segC + i) & st.out_mask] = o;
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+// run s of the block: its first / one-past-last pipeline segment (empty: first >= last)
+__device__ __forceinline__ void fs_run_bounds(int nseg, int K, int s, int& first, int& last) {
+    const int per = (nseg + K - 1) / K;
+    first = s * per < nseg ? s * per : nseg;
+    last = first + per < nseg ? first + per : nseg;
+}
+
+template <int FMT>
+__global__ __launch_bounds__(FF_T) void frontend_spec_kernel(FrontendArgs a) {
+    __shared__ FeSharedMem S;
+    const int tid = threadIdx.x, s = blockIdx.x, K = a.spec_k;
+    const FrontendArgs::Stream st = a.one;
+    for (int i = tid; i < LUT; i += FF_T) { S.lre[i] = a.lut[i]; S.lim[i] = a.lut[LUT + i]; }
+    const size_t n8 = st.n_samples & ~size_t(7);
+    const int nseg = int((n8 + FF_SEG - 1) / FF_SEG);
+    int first, last;
+    fs_run_bounds(nseg, K, s, first, last);
+    float* rec = a.spec_buf + size_t(s) * 32;
+    if (first >= last) return;                                   // (an empty run: the walk skips it by the same arithmetic)
+    const int warm = a.spec_warm > 0 ? a.spec_warm : FS_WARM_SEGS;
+    const int seg_begin = first > warm ? first - warm : 0;
+    float b_init = 0.0f;
+    if (tid < 16) b_init = tid < 8 ? st.state->bias_re[tid] : st.state->bias_im[tid - 8];
+    float bias = b_init;
+    if (seg_begin > 0) {
+        bias = fs_guess<FMT>(a, st, S, size_t(seg_begin) * FF_SEG, b_init);
+        if (a.spec_poison && tid < 16) bias = bias * 1.25f + 0.5f;     // diagnostic: a guess that cannot converge (the walk must repair every run)
+    }
+    float at_out = bias;
+    fs_pipeline<FMT>(a, st, S, seg_begin, first, last, n8, bias, at_out);
+    if (tid < 16) { rec[tid] = at_out; rec[16 + tid] = bias; }
+}
+
+// the walk over the runs (one workgroup): verify, repair where a guess did not converge, then the block's final state and its tail
+template <int FMT>
+__global__ __launch_bounds__(FF_T) void frontend_spec_walk_kernel(FrontendArgs a) {
+    __shared__ FeSharedMem S;
+    const int tid = threadIdx.x, K = a.spec_k;
+    const FrontendArgs::Stream st = a.one;
+    const size_t n8 = st.n_samples & ~size_t(7);
+    const int nseg = int((n8 + FF_SEG - 1) / FF_SEG);
+    bool lut_loaded = false;
+    float cur = 0.0f;                                            // lanes < 16: the TRUE state after the runs walked so far
+    if (tid < 16) cur = a.spec_buf[16 + tid];                    // run 0 started from the block's true state
+    for (int s = 1; s < K; ++s) {
+        int first, last;
+        fs_run_bounds(nseg, K, s, first, last);
+        if (first >= last) break;
+        const float* rec = a.spec_buf + size_t(s) * 32;
+        const int bad = (tid < 16 && __float_as_uint(rec[tid]) != __float_as_uint(cur)) ? 1 : 0;
+        if (__syncthreads_or(bad)) {                             // the run entered with another state than its predecessor left: again, from the right one
+            if (!lut_loaded) {
+                for (int i = tid; i < LUT; i += FF_T) { S.lre[i] = a.lut[i]; S.lim[i] = a.lut[LUT + i]; }
+                lut_loaded = true;
+            }
+            float bias = cur, at_out = cur;
+            fs_pipeline<FMT>(a, st, S, first, first, last, n8, bias, at_out);
+            cur = bias;
+            if (tid == 0 && a.spec_repairs) atomicAdd(a.spec_repairs, 1u);   // repairs so far (diagnostic)
+        } else if (tid < 16) {
+            cur = rec[16 + tid];
+        }
+    }
+    for (size_t i = n8 + tid; i < st.n_samples; i += FF_T) {     // the tail that chunks_exact leaves untouched: converted, not processed
+        float2 o;
+        load_sample<FMT>(st.in, i, o.x, o.y);
+        reinterpret_cast<float2*>(st.out)[(st.out_start + i) & st.out_mask] = o;
+    }
+    if (tid == 0) st.state->phase_accumulator = st.ph_table[st.tab_pos_end] * st.tab_scale;
+    if (tid < 16) { if (tid < 8) st.state->bias_re[tid] = cur; else st.state->bias_im[tid - 8] = cur; }
+}
+
 }  // namespace
 
 void launch_frontend_fast(hipStream_t s, const FrontendArgs& a, int n_streams, int fmt) {
     if (fmt == GM_FMT_C32) frontend_fast_kernel<GM_FMT_C32><<<n_streams, FF_T, 0, s>>>(a);
     else frontend_fast_kernel<GM_FMT_I8_IQ><<<n_streams, FF_T, 0, s>>>(a);
+}
+
+// one stream, one block on a.spec_k workgroups + the walk (see frontend_spec_kernel)
+void launch_frontend_spec(hipStream_t s, const FrontendArgs& a, int fmt) {
+    if (fmt == GM_FMT_C32) {
+        frontend_spec_kernel<GM_FMT_C32><<<a.spec_k, FF_T, 0, s>>>(a);
+        frontend_spec_walk_kernel<GM_FMT_C32><<<1, FF_T, 0, s>>>(a);
+    } else {
+        frontend_spec_kernel<GM_FMT_I8_IQ><<<a.spec_k, FF_T, 0, s>>>(a);
+        frontend_spec_walk_kernel<GM_FMT_I8_IQ><<<1, FF_T, 0, s>>>(a);
+    }
 }
 
 void launch_frontend(hipStream_t s, const FrontendArgs& a, int n_streams, int fmt) {

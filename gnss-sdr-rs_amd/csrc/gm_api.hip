@@ -2173,7 +2173,10 @@ struct gm_frontend {
     float* d_tab = nullptr;
     uint32_t tab_mu = 0, tab_lambda = 0;           // lambda' = the period repeated until >= FE_FAST_SEG
     uint32_t pos = 0;                              // table index of the next sample
+    float* d_spec = nullptr;                       // [FE_SPEC_K][32] + 1 floats: the speculative form's run records (fe_kernels.hip)
 };
+static constexpr int FE_SPEC_K = 32;               // most workgroups per block in the speculative form (the record block's size); 16 are used
+static constexpr size_t FE_SPEC_MIN = size_t(gm::FE_FAST_SEG) * 48;     // blocks shorter than 48 pipeline segments stay on one workgroup
 
 // r -> fract(fl(r + s)): the fast form of `(phase + step) % 2048` in revolutions (fe_kernels.hip nco_segment_fast)
 static inline float fe_orbit_step(float r, float s) { const float t = r + s; return t - floorf(t); }
@@ -2243,7 +2246,22 @@ static int frontend_launch(gm_frontend* f, hipStream_t st, const void* d_in, int
     a.streams = nullptr;
     a.one = frontend_stream(f, d_in, d_out, out_start, out_mask, n);
     a.lut = f->d_lut; a.alpha = f->alpha; a.con = f->con;
-    if (a.one.ph_table) gm::launch_frontend_fast(st, a, 1, fmt);
+    // the speculative form: a long block whose output does not alias its input (the runs' warm-ups re-read earlier samples)
+    const int spec = gm::diag_int("GM_FE_SPEC", 1);
+    if (a.one.ph_table && spec != 0 && n >= FE_SPEC_MIN && d_in != d_out) {
+        if (!f->d_spec) {
+            HIPC(hipMalloc(&f->d_spec, (size_t(FE_SPEC_K) * 32 + 1) * sizeof(float)));
+            HIPC(hipMemsetAsync(f->d_spec, 0, (size_t(FE_SPEC_K) * 32 + 1) * sizeof(float), st));
+        }
+        {
+            const int k = gm::diag_int("GM_FE_SPEC_K", 16);
+            a.spec_k = k < 2 ? 2 : (k > FE_SPEC_K ? FE_SPEC_K : k);
+            a.spec_warm = gm::diag_int("GM_FE_SPEC_WARM", 0);
+        }
+        a.spec_buf = f->d_spec; a.spec_poison = spec == 2 ? 1 : 0;
+        a.spec_repairs = reinterpret_cast<unsigned int*>(f->d_spec + size_t(FE_SPEC_K) * 32);
+        gm::launch_frontend_spec(st, a, fmt);
+    } else if (a.one.ph_table) gm::launch_frontend_fast(st, a, 1, fmt);
     else gm::launch_frontend(st, a, 1, fmt);
     HIPC(hipGetLastError());
     return GM_OK;
@@ -2281,9 +2299,19 @@ int gm_frontend_destroy(gm_frontend* f) {
     if (!f) return GM_OK;
     hipSetDevice(f->device);
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
-    hipFree(f->d_lut); hipFree(f->d_state); hipFree(f->d_io); hipFree(f->d_batch); hipFree(f->d_tab);
+    hipFree(f->d_lut); hipFree(f->d_state); hipFree(f->d_io); hipFree(f->d_batch); hipFree(f->d_tab); hipFree(f->d_spec);
     for (void* p : f->d_raw) hipFree(p);
     delete f;
+    return GM_OK;
+}
+
+int gm_frontend_debug_repairs(gm_frontend* f, uint32_t* runs) {
+    if (!f || !runs) return set_err(GM_ERR_INVALID_ARG, "null pointer");
+    *runs = 0;
+    if (!f->d_spec) return GM_OK;
+    if (int rc = ensure_device(f->device)) return rc;
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(runs, f->d_spec + size_t(FE_SPEC_K) * 32, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return GM_OK;
 }
 

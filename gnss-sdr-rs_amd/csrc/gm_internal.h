@@ -219,7 +219,13 @@ struct FrontendArgs {
     Stream one;                    // used when streams == nullptr (single-stream launches need no upload)
     const float* lut;              // [2][2048]: lut_re, lut_im (nco_lut.rs:28-32), built on the host with glibc cosf/sinf
     float alpha, con;
+    // speculative form (launch_frontend_spec): the block of `one` on spec_k workgroups; spec_buf = [spec_k][32] floats (the state run s
+    // entered with / left with) + one word (repairs, diagnostic)
+    int spec_k = 0, spec_poison = 0, spec_warm = 0;      // spec_warm: warm-up pipeline segments (0: the kernel's default, 18)
+    float* spec_buf = nullptr;
+    unsigned int* spec_repairs = nullptr;   // runs the walk has had to repeat (diagnostic counter)
 };
+void launch_frontend_spec(hipStream_t, const FrontendArgs&, int fmt);
 void launch_frontend(hipStream_t, const FrontendArgs&, int n_streams, int fmt);
 // every stream carries a phase table: the pipelined kernel (DC chains on one wave, everything else data-parallel)
 void launch_frontend_fast(hipStream_t, const FrontendArgs&, int n_streams, int fmt);

@@ -59,6 +59,12 @@ class DigitalFrontend:
     def synchronize(self):
         check(lib().gm_frontend_synchronize(self._h), "gm_frontend_synchronize")
 
+    def debug_repairs(self):
+        """runs of the speculative form the verification has had to repeat on this handle (diagnostic)"""
+        n = C.c_uint32(0)
+        check(lib().gm_frontend_debug_repairs(self._h, C.byref(n)), "gm_frontend_debug_repairs")
+        return n.value
+
     def write_ring(self, ring, samples):
         """samples: complex64 array, or int8 array of interleaved I/Q."""
         s = np.ascontiguousarray(samples)

@@ -360,6 +360,14 @@ int gm_frontend_synchronize(gm_frontend *f);
  * kernel writing straight into the ring mirror; head advances when the block is in HBM (gm_ring_flush to wait).  Blocks of up
  * to 2^19 samples per copy + launch; the kernels run on a stream of the ring's own behind the copies (an event per staging slot). */
 int gm_frontend_write_ring(gm_frontend *f, gm_ring *ring, const void *samples, size_t n_samples, int fmt);
+/* Long blocks (>= 48 pipeline segments of 3840 samples, output not aliasing the input) run in the SPECULATIVE form since round 6: the
+ * block is cut into 16 runs on 16 workgroups, each starting from a GUESSED DC-remover state (the recurrence in exact arithmetic over the
+ * 16 384 steps before its warm-up) that an 8 640-step warm-up lets fall onto the true f32 chain; a second kernel verifies run by run
+ * that the state a run entered with is bit for bit the state its predecessor left, and does a run again — sequentially, from the right
+ * state — where it is not.  The results are those of the sequential front-end, word for word, whatever the guesses were
+ * (tests/test_gpu_frontend.py::test_speculative_blocks_are_exact spoils every one of them); 0.52 -> 0.15 ms per 2^19-sample block.
+ * Diagnostic (not in the reference): *runs = how many runs the verification has had to repeat on this handle so far. */
+int gm_frontend_debug_repairs(gm_frontend *f, uint32_t *runs);
 
 /* ------------------------------------------------------------------ Tracking
  * The evolving fields of TrackingChannel (src/tracking/do_tracking.rs:88-116). */

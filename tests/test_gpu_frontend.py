@@ -134,3 +134,63 @@ def test_batch_of_streams_equals_single_stream_calls(gpu, oracle, hipbuf):
         F.process_dev_batch([fes[0], fes[0]], d_in[:2], _lib.FMT_I8_IQ, d_out[:2], n)
     for f in fes:
         f.close()
+
+
+_SPEC_SCRIPT = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+from gnss_sdr_rs_amd import _lib, frontend as F, tracking as T
+_lib.init(0)
+rng = np.random.default_rng(2024)
+n = (1 << 19) + 1000
+# a DC offset that wanders and jumps (what makes a guessed bias converge late), clipped int8 noise around it
+t = np.arange(3 * n)
+dc = 20.0 * np.sin(t * 3.0e-5) + np.where((t // 300000) %% 2 == 0, 25.0, -15.0)
+raw = np.clip(np.rint(rng.normal(0.0, 18.0, (3 * n, 2)) + dc[:, None] * np.array([1.0, -0.6])), -127, 127).astype(np.int8).reshape(-1)
+fe = F.DigitalFrontend(4.1304e6, 16.3676e6, 16.3676e6)
+ring = T.MulticastRingBuffer(1 << 21)
+h = hashlib.sha256()
+for b in range(3):                                   # three blocks back to back: the state runs through them
+    fe.write_ring(ring, raw[2 * b * n:2 * (b + 1) * n])
+ring.flush()
+h.update(ring.copy_to_slice(0, 3 * n).tobytes())
+ph, br, bi = fe.state()
+h.update(np.float32(ph).tobytes() + br.tobytes() + bi.tobytes())
+print(h.hexdigest(), fe.debug_repairs())
+"""
+
+
+@pytest.mark.parametrize("mode", ["default", "every_guess_poisoned", "one_workgroup"])
+def test_speculative_blocks_are_exact(gpu, oracle, mode):
+    """The speculative form of the front-end (fe_kernels.hip: a block of >= 48 pipeline segments on 16 workgroups, each from a GUESSED
+    DC-remover state that an 8 640-step warm-up lets fall onto the true chain, verified run by run and repaired where it did not):
+    three blocks of 2^19 + 1000 int8 samples with a wandering, jumping DC offset — every output float of the ring and every state word
+    equal to the oracle's sequential front-end, (a) as shipped, (b) with every guess spoiled (GM_FE_SPEC=2 under GM_DIAGNOSTICS=1: the
+    walk must then redo every speculated run) and (c) with the speculation off (one workgroup per block).  Exact by construction:
+    a guess that does not converge costs time, never a sample."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    if mode != "default":
+        env["GM_DIAGNOSTICS"] = "1"
+        env["GM_FE_SPEC"] = "2" if mode == "every_guess_poisoned" else "0"
+    r = subprocess.run([sys.executable, "-c", _SPEC_SCRIPT % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got, repairs = r.stdout.split()[-2], int(r.stdout.split()[-1])
+    # 137 pipeline segments on 16 workgroups: runs 3 .. 15 start from a guess (13 per long block, 3 blocks)
+    assert repairs == {"default": repairs, "every_guess_poisoned": 39, "one_workgroup": 0}[mode] and (mode != "default" or repairs <= 3), (mode, repairs)
+    # the oracle on the same stream, block by block (its state runs through as well)
+    rng = np.random.default_rng(2024)
+    n = (1 << 19) + 1000
+    t = np.arange(3 * n)
+    dc = 20.0 * np.sin(t * 3.0e-5) + np.where((t // 300000) % 2 == 0, 25.0, -15.0)
+    raw = np.clip(np.rint(rng.normal(0.0, 18.0, (3 * n, 2)) + dc[:, None] * np.array([1.0, -0.6])), -127, 127).astype(np.int8).reshape(-1)
+    ofe = oracle.DigitalFrontend(4.1304e6, 16.3676e6, 16.3676e6)
+    h = hashlib.sha256()
+    out = [ofe.process_block(raw[2 * b * n:2 * (b + 1) * n].astype(np.float32)).view(np.complex64) for b in range(3)]
+    h.update(np.concatenate(out).tobytes())
+    h.update(np.float32(ofe.s.phase_accumulator).tobytes() + np.array(ofe.s.bias_re[:], np.float32).tobytes() + np.array(ofe.s.bias_im[:], np.float32).tobytes())
+    assert got == h.hexdigest(), mode
