@@ -545,12 +545,31 @@ __global__ __launch_bounds__(FF_T) void frontend_spec_walk_kernel(FrontendArgs a
     const size_t n8 = st.n_samples & ~size_t(7);
     const int nseg = int((n8 + FF_SEG - 1) / FF_SEG);
     bool lut_loaded = false;
+    // the common case first, all runs at once: lane (s, j) compares what run s entered with against what run s - 1 left; if every
+    // run stands, the block's final state is what the last run left (one barrier instead of a dependent global read per run)
+    int last_run = 0;
+    for (int s = 1; s < K; ++s) { int f, l; fs_run_bounds(nseg, K, s, f, l); if (f < l) last_run = s; }
+    int first_bad = K;
+    {
+        const int s = tid >> 4, j = tid & 15;
+        int bad = 0;
+        if (s >= 1 && s <= last_run && tid < FF_T)
+            bad = __float_as_uint(a.spec_buf[size_t(s) * 32 + j]) != __float_as_uint(a.spec_buf[size_t(s - 1) * 32 + 16 + j]) ? 1 : 0;
+        if (!__syncthreads_or(bad)) first_bad = K;
+        else {                                                    // the first run that does not stand (rare): found by a second sweep
+            S.flag = K;
+            __syncthreads();
+            if (bad) atomicMin(&S.flag, s);
+            __syncthreads();
+            first_bad = S.flag;
+        }
+    }
     float cur = 0.0f;                                            // lanes < 16: the TRUE state after the runs walked so far
-    if (tid < 16) cur = a.spec_buf[16 + tid];                    // run 0 started from the block's true state
-    for (int s = 1; s < K; ++s) {
+    const int from = first_bad < K ? first_bad : last_run + 1;   // runs before `from` stand as they are
+    if (tid < 16) cur = a.spec_buf[size_t(from - 1) * 32 + 16 + tid];
+    for (int s = from; s <= last_run; ++s) {
         int first, last;
         fs_run_bounds(nseg, K, s, first, last);
-        if (first >= last) break;
         const float* rec = a.spec_buf + size_t(s) * 32;
         const int bad = (tid < 16 && __float_as_uint(rec[tid]) != __float_as_uint(cur)) ? 1 : 0;
         if (__syncthreads_or(bad)) {                             // the run entered with another state than its predecessor left: again, from the right one

@@ -640,7 +640,7 @@ inline void run_tracking(MulticastRingBuffer& multi_ring_buf, Channel<Acquisitio
                 if (!any || int64_t(need - required_idx) < 0) required_idx = need;
                 any = true;
             }
-            if (any) multi_ring_buf.wait_head(required_idx, 2);     // bounded so that `stop` and new acquisitions are seen
+            if (any) multi_ring_buf.wait_head(required_idx, 1);     // bounded (1 ms) so that `stop` and new acquisitions are seen
             else std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
     }
