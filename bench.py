@@ -1136,6 +1136,7 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
            "warmup_async_calls": WARM, "python_gc_disabled": False,
            "signal_seconds": sig_s, "wall_seconds": wall, "x_real_time": sig_s / wall, "sustained_msps": n_ms * N / wall / 1e6,
            "dwells": rep["dwells"], "channel_epochs": rep["channel_epochs"], "tracking_passes": rep["tracking_passes"],
+           "frontend_blocks": rep["blocks"], "frontend_speculated_runs_done_again": rep["fe_runs_repaired"],
            "satellites_in_scene": len(sats), "channels_started": rep["channels_started"],
            "channels_on_true_doppler": locked,
            "channels_bit_synchronised": sum(1 for c in chans if c["bit_sync"]),

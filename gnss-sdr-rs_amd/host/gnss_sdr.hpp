@@ -217,6 +217,7 @@ public:
     // rf_thread's block step (rf_thread.rs:43-48): process_block + write_samples, fused on the GPU, non-blocking
     void write_ring(MulticastRingBuffer& ring, const Complex32* block, size_t n) { check(gm_frontend_write_ring(h_, ring.handle(), block, n, GM_FMT_C32), "write_ring"); }
     void write_ring_i8(MulticastRingBuffer& ring, const int8_t* iq, size_t n) { check(gm_frontend_write_ring(h_, ring.handle(), iq, n, GM_FMT_I8_IQ), "write_ring"); }
+    uint32_t debug_repairs() const { uint32_t n = 0; check(gm_frontend_debug_repairs(h_, &n), "debug_repairs"); return n; }   // runs of the speculative form done again
 };
 
 // ---- decoding::NavSyncStatus + nav_decoding's per-epoch step up to frame sync (src/decoding.rs:40-227, legacy)

@@ -48,7 +48,7 @@ typedef struct {
     double wall_seconds, signal_seconds;
     double seconds_frontend, seconds_acquisition, seconds_fine_doppler, seconds_tracking, seconds_nav_bits;
     double fe_block_first_s, fe_block_median_s, fe_block_max_after_first_s, feeder_held_back_s;
-    uint32_t dwells, channels_started, blocks;
+    uint32_t dwells, channels_started, blocks, fe_runs_repaired;     // fe_runs_repaired: runs of the speculative front-end done again (gm_frontend_debug_repairs)
     uint64_t channel_epochs, tracking_passes;
     double first_handover_signal_ms, first_handover_wall_s;
     double first_bit_sync_signal_ms, first_bit_sync_wall_s;
@@ -213,6 +213,7 @@ int gmrx_receiver_run(const gmrx_cfg* cfg, const int8_t* iq, size_t n_samples, g
             rep->fe_block_median_s = s[s.size() / 2];
             rep->fe_block_max_after_first_s = s.back();
         }
+        rep->fe_runs_repaired = fe.debug_repairs();
         rep->channel_epochs = ctl.channel_epochs.load();
         rep->tracking_passes = ctl.trk_passes.load();
         for (uint32_t c = 0; c < C && c < finals.size(); ++c) {

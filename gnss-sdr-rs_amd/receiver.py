@@ -31,7 +31,7 @@ class RxReport(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("wall_seconds", "signal_seconds", "seconds_frontend", "seconds_acquisition",
                                           "seconds_fine_doppler", "seconds_tracking", "seconds_nav_bits", "fe_block_first_s",
                                           "fe_block_median_s", "fe_block_max_after_first_s", "feeder_held_back_s")] + \
-               [("dwells", C.c_uint32), ("channels_started", C.c_uint32), ("blocks", C.c_uint32),
+               [("dwells", C.c_uint32), ("channels_started", C.c_uint32), ("blocks", C.c_uint32), ("fe_runs_repaired", C.c_uint32),
                 ("channel_epochs", C.c_uint64), ("tracking_passes", C.c_uint64)] + \
                [(k, C.c_double) for k in ("first_handover_signal_ms", "first_handover_wall_s", "first_bit_sync_signal_ms",
                                           "first_bit_sync_wall_s", "first_frame_sync_signal_ms", "first_frame_sync_wall_s")] + \
