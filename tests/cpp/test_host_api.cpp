@@ -262,10 +262,37 @@ static int test_frontend_refinement_navsync() {
     return 0;
 }
 
+// The ticket loop's planning (host/gnss_sdr.hpp detail::passes_to_head): passes = the whole code periods between the slowest active
+// channel's PLANNED position and the head, + 2 — the planned position being the collected record advanced by the whole periods the calls
+// in flight cover.  Host arithmetic only: no device.
+static int test_ticket_loop_planning() {
+    std::vector<gm_trk_state> st(3);
+    std::vector<uint8_t> busy = {1, 1, 0};
+    std::vector<uint64_t> covered = {0, 0, 0};
+    for (auto& s : st) { std::memset(&s, 0, sizeof(s)); s.num_samples_per_code = 1000; s.active = 1; }
+    st[0].next_sample_index = 5000; st[1].next_sample_index = 7300; st[2].next_sample_index = 0;      // channel 2 is idle: ignored
+    CHECK(gnss::detail::passes_to_head(st, busy, 5999, covered) == 2);            // no whole period for anyone: the margin only
+    CHECK(gnss::detail::passes_to_head(st, busy, 9000, covered) == 4 + 2);        // channel 0 is 4 periods behind
+    covered = {8000, 8000, 0};                                                    // a call in flight takes both to the last whole period before 8000
+    CHECK(gnss::detail::passes_to_head(st, busy, 9000, covered) == 1 + 2);        // channel 0 planned at 8000, channel 1 at 7300: one period each at most
+    CHECK(gnss::detail::passes_to_head(st, busy, 8000 + 5000 * 1000ull, covered) == 4095);   // capped at one persistent launch
+    busy = {0, 0, 0};
+    CHECK(gnss::detail::passes_to_head(st, busy, 9000, covered) == 2);
+    // wrap-safe: positions just below 2^64
+    busy = {1, 0, 0};
+    st[0].next_sample_index = ~0ull - 1499;
+    covered = {st[0].next_sample_index, 0, 0};                                    // (run_tracking sets covered = the start index when it starts a channel)
+                                                                                  // head 1500 is three whole periods ahead across the 2^64 wrap
+    CHECK(gnss::detail::passes_to_head(st, busy, 1500, covered) == 3 + 2);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const bool cpu_only = argc > 1 && !std::strcmp(argv[1], "--cpu-only");
     int rc = test_acquisition_manager();
     std::printf("test_acquisition_manager %s\n", rc ? "FAILED" : "ok");
+    rc |= test_ticket_loop_planning();
+    std::printf("test_ticket_loop_planning %s\n", rc ? "FAILED" : "ok");
     if (cpu_only || rc) return rc;
     init(0);
     rc |= test_multicast_ring_buffer();            std::printf("test_multicast_ring_buffer %s\n", rc ? "FAILED" : "ok");

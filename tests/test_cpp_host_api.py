@@ -23,7 +23,7 @@ def _build(gm):
 def test_cpp_host_api_builds_and_runs_cpu_part(gm):
     exe = _build(gm)
     r = subprocess.run([exe, "--cpu-only"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0 and "test_acquisition_manager ok" in r.stdout, r.stdout
+    assert r.returncode == 0 and "test_acquisition_manager ok" in r.stdout and "test_ticket_loop_planning ok" in r.stdout, r.stdout
 
 
 @pytest.mark.gpu
