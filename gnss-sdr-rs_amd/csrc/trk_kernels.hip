@@ -1519,9 +1519,11 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     a.packed = packed ? (cfg.n_channels * G + 7) / 8 : 0;
     a.stamp_block = diag_int("GM_TRK_STAMP_WG", 0);
     a.force_write_through = diag_int("GM_TRK_FORCE_SC1", 0) != 0 ? 1 : 0;
-    {   // slice length from the nominal code period (+1 % margin), whole wavefronts
+    {   // slice length from the nominal code period (+1 % margin; +0.2 % where an epoch is many samples per lane: there the margin is
+        // rows of work on every workgroup but the last, which takes whatever a longer period adds anyway), whole wavefronts
         const float nn = roundf(cfg.fs / (cfg.nominal_code_rate / cfg.code_len_f));
-        const uint64_t n_nom = nn > 0 ? uint64_t(nn * 1.01f) + 64 : 64;
+        const float margin = (nn > 0 && nn / float(G) / float(TRK_PERSIST_THREADS) >= 8.0f) ? 1.002f : 1.01f;
+        const uint64_t n_nom = nn > 0 ? uint64_t(nn * margin) + 64 : 64;
         a.per = uint32_t(((n_nom + G - 1) / G + 63) / 64 * 64);
     }
     {   // stagger (see the kernel): only when an epoch is many samples per lane, i.e. when correlation, not the serial chain, fills it.
