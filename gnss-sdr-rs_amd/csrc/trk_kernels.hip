@@ -361,12 +361,21 @@ __device__ __forceinline__ void correlate_block_fast(const EpochConsts& c, const
         for (int k = 0; k < NB; ++k) w[k] = c.carrier_phase + q0[k];                        // the phase x
 #pragma unroll
         for (int k = 0; k < NB; ++k) kq[k] = __builtin_rintf(w[k] * 0.636619747f);
+        if constexpr (ARMS == 3) {      // the form the 3 us latency chain of 32 channels x 25 Msps was tuned with: the one below costs
+#pragma unroll                          // it 45 ns per epoch (DESIGN_HISTORY R6.6)
+            for (int k = 0; k < NB; ++k) ph[k] = kq[k] * c1;
 #pragma unroll
-        for (int k = 0; k < NB; ++k) ph[k] = kq[k] * -c1;                                   // -(k c1), exactly (held negated: the fused
+            for (int k = 0; k < NB; ++k) pl[k] = __builtin_fmaf(kq[k], c1, -ph[k]);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) w[k] = w[k] - ph[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) ph[k] = kq[k] * -c1;                               // -(k c1), exactly (held negated: the fused
 #pragma unroll                                                                              // multiply-add then takes c1 as a literal, not from
-        for (int k = 0; k < NB; ++k) pl[k] = __builtin_fmaf(kq[k], c1, ph[k]);              // a scalar register: half the issue cost)
+            for (int k = 0; k < NB; ++k) pl[k] = __builtin_fmaf(kq[k], c1, ph[k]);          // a scalar register: half the issue cost)
 #pragma unroll
-        for (int k = 0; k < NB; ++k) w[k] = w[k] + ph[k];
+            for (int k = 0; k < NB; ++k) w[k] = w[k] + ph[k];
+        }
 #pragma unroll
         for (int k = 0; k < NB; ++k) pl[k] = __builtin_fmaf(kq[k], c2, pl[k]);
 #pragma unroll
@@ -943,7 +952,11 @@ __device__ __forceinline__ void prepare_epoch(const TrkDevCfg& cfg, uint64_t hea
     sh.fast_code = (fast_code_ok(ec, n) && float(uint32_t(n)) <= n_cap) ? 1 : 0;
 }
 
-template <int ARMS, int MODE_T, int BOC_T, int T, int STRICT>
+// FAIR3: the three-arm correlation loop carries the co-tenant priority toggle of the five-arm one.  A template parameter, not a
+// launch-uniform flag: the toggle's test inside the loop costs the 3 us latency chain of 32 channels x 25 Msps 75 ns per epoch even
+// when it never fires, and two copies of the loop in one kernel cost it 9 % (DESIGN_HISTORY R6.6); launches shaped for throughput
+// (a.fair_share != 0: eight or more rows per lane) take the FAIR3 instantiation, every other launch the plain one.
+template <int ARMS, int MODE_T, int BOC_T, int T, int STRICT, bool FAIR3 = false>
 // second launch bound = waves per SIMD with TRK_PERSIST_WG_PER_CU workgroups resident: the co-residency the exchange relies
 // on must not be lost to a register count above 512 / that
 __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persistent_kernel(TrkPersistArgs a) {
@@ -1079,6 +1092,11 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 __syncthreads();
             }
         }
+        // which granules of the exchange block this lane gathers (lane + 64 q: arm-major, GS per arm) is fixed for the launch — the
+        // places of partners that do not exist (GS = 16 > G) are never polled.  Worked out HERE, not in the epoch's serial section.
+        bool mine[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine[q] = lane + q * 64 < a.GS * NV && (a.GS == a.G || ((lane + q * 64) & 15) < a.G);
         for (; e < a.epochs; ++e) {
             const uint32_t n = sh.alive ? sh.n : 0u;
             if (n == 0) break;                     // state is identical in the G workgroups: they all leave
@@ -1193,9 +1211,11 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 } else
                 for (uint32_t j = 0; j < wtot; j += IL) {                // the first block(s) come from the prefetched registers
                     const uint32_t left = wtot - j;
-                    if (younger) {                                       // fair issue shares for a CU's two tenants (see the five-arm loop)
-                        if (a.fair_mode >= 3 || (j & (a.fair_mode == 2 ? 12u : 4u))) __builtin_amdgcn_s_setprio(1);
-                        else __builtin_amdgcn_s_setprio(0);
+                    if constexpr (FAIR3) {                               // fair issue shares for a CU's two tenants (see the five-arm loop)
+                        if (younger) {
+                            if (a.fair_mode >= 3 || (j & (a.fair_mode == 2 ? 12u : 4u))) __builtin_amdgcn_s_setprio(1);
+                            else __builtin_amdgcn_s_setprio(0);
+                        }
                     }
                     cf dd[IL];
                     float ff[IL];
@@ -1225,7 +1245,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                     else
                         correlate_block_fast<ARMS, BOC_T, 1>(ec, fast_tab, reinterpret_cast<const cf(&)[1]>(dd), reinterpret_cast<const float(&)[1]>(ff), acc, acc2);
                 }
-                if (ARMS == 3 && younger) __builtin_amdgcn_s_setprio(0);
+                if (FAIR3 && younger) __builtin_amdgcn_s_setprio(0);
             } else if (STRICT && (sh.fast_car & sh.fast_code)) {   // strict_libm: the exact fast forms of the code phase and of
                 // x / fs, the carrier's cos / sin by sincosf_glibc (f64) — sample by sample, no prefetch use
                 for (uint32_t i = i0 + tid; i < i1; i += T)
@@ -1303,7 +1323,7 @@ __global__ __launch_bounds__(T, TRK_PERSIST_WG_PER_CU * T / 256) void trk_persis
                 bool pending[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    pending[q] = lane + q * 64 < ng && (a.GS == a.G || ((lane + q * 64) & 15) < a.G);
+                    pending[q] = mine[q];
                     if (pending[q]) gr[q] = __hip_atomic_load(&slot[lane + q * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
@@ -1579,6 +1599,7 @@ void launch_trk_persistent(hipStream_t st, const TrkDevCfg& cfg, const int8_t* d
     constexpr int T = TRK_PERSIST_THREADS;
 #define GM_TRK_LAUNCH(A, M, B) \
     if (cfg.strict_libm) hipLaunchKernelGGL((trk_persistent_kernel<A, M, B, T, 1>), grid, dim3(T), lds, st, a); \
+    else if (A == 3 && a.fair_share) hipLaunchKernelGGL((trk_persistent_kernel<A, M, B, T, 0, A == 3>), grid, dim3(T), lds, st, a); \
     else hipLaunchKernelGGL((trk_persistent_kernel<A, M, B, T, 0>), grid, dim3(T), lds, st, a); \
     break
     switch (key) {
