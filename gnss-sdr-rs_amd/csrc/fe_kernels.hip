@@ -326,6 +326,8 @@ __global__ __launch_bounds__(FF_T) void frontend_fast_kernel(FrontendArgs a) {
 constexpr int FS_WARM_SEGS = 18;                 // 8 640 chain steps of warm-up
 constexpr int FS_GUESS_STEPS = 16384;            // con^16384 = 7.6e-8: what is left of the prior's error is far below an ulp
 constexpr int FS_PARTS = 128;
+static_assert(FS_PARTS * 8 == FF_T, "fs_guess: lane = (part of the window, SIMD lane j)");
+static_assert(FE_SPEC_K_MAX * 16 <= FF_T, "the walk verifies every run at once: lane = (run, chain)");
 
 struct __attribute__((aligned(16))) FeSharedMem {
     float xa[2][16][FF_ROW];

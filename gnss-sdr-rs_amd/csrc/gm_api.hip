@@ -2175,7 +2175,7 @@ struct gm_frontend {
     uint32_t pos = 0;                              // table index of the next sample
     float* d_spec = nullptr;                       // [FE_SPEC_K][32] + 1 floats: the speculative form's run records (fe_kernels.hip)
 };
-static constexpr int FE_SPEC_K = 32;               // most workgroups per block in the speculative form (the record block's size); 16 are used
+static constexpr int FE_SPEC_K = gm::FE_SPEC_K_MAX;
 static constexpr size_t FE_SPEC_MIN = size_t(gm::FE_FAST_SEG) * 48;     // blocks shorter than 48 pipeline segments stay on one workgroup
 
 // r -> fract(fl(r + s)): the fast form of `(phase + step) % 2048` in revolutions (fe_kernels.hip nco_segment_fast)
