@@ -84,6 +84,11 @@ def test_null_handles_are_refused_not_dereferenced(gm):
     assert L.gm_trk_update_all_async(None, None, 4, C.byref(tok)) == -1 and tok.value == 7
     assert L.gm_trk_collect(None, 1, 1, None, None, None, None, None, C.byref(ready)) == -1 and ready.value == 5
     assert b"bad argument" in L.gm_last_error()
+    # ABI 7: the bulk state entries, the enqueued head, the front-end's repair count
+    st, h, runs = (C.c_uint8 * 64)(), C.c_uint64(9), C.c_uint32(9)
+    assert L.gm_trk_get_states(None, C.cast(st, C.c_void_p)) == -1 and L.gm_trk_set_states(None, C.cast(st, C.c_void_p), None) == -1
+    assert L.gm_ring_get_enqueued_head(None, C.byref(h)) == -1 and h.value == 9
+    assert L.gm_frontend_debug_repairs(None, C.byref(runs)) == -1 and runs.value == 9
 
 
 def test_ca_table_and_resampler_host(gm, oracle):

@@ -258,6 +258,69 @@ def test_tracking_async_tickets_equal_the_per_block_path(gpu, oracle):
     mgr.close(); ring.close()
 
 
+def test_bulk_states_enqueued_head_and_collected_states(gpu, oracle):
+    """The ABI 7 entries on their own terms.  gm_trk_get_states == the per-channel gm_trk_get_state records; gm_trk_set_states
+    with a `which` mask writes the flagged channels only (runs of them, the ends included) and every channel without one;
+    gm_ring_get_enqueued_head is what the asynchronous writer has been handed — at once, before the copy has landed — never
+    behind gm_ring_get_head and equal to it after a flush; the states gm_trk_collect hands over are the channel records as
+    they stood behind THAT call's passes (a later call in flight does not show in them) and, for the last call, equal
+    gm_trk_get_states word for word; null pointers are refused."""
+    import ctypes as C
+    from gnss_sdr_rs_amd import tracking as T, synth, _lib
+    L = _lib.lib()
+    t = oracle.ca_code_table()
+    fs, N, n_ms = 4_096_000.0, 4096, 40
+    truth = {7: (-900.0, 300), 19: (1500.0, 2222)}
+    sats = [dict(prn=p, prn_row=p - 1, cn0_dbhz=50.0, doppler_hz=d, code_start=c, phase=0.2 * p) for p, (d, c) in truth.items()]
+    x = synth.to_c32(synth.make_scene(t, fs, 0.0, n_ms * N, sats, config_id=64))
+    ring = T.MulticastRingBuffer(1 << 18)
+    mgr = T.TrackingManager(fs, n_channels=6, code_index_mode=T.CODE_INDEX_FIXED)
+    raw = lambda s: bytes(C.string_at(C.addressof(s), C.sizeof(s)))
+    # ---- bulk read == per-channel reads; masked bulk write
+    base = mgr.get_states()
+    assert [raw(s) for s in base] == [raw(mgr.channels[c].state) for c in range(6)]
+    want = mgr.get_states()
+    for c, s in enumerate(want):
+        s.carrier_freq, s.code_phase, s.lost_counter = 100.0 + c, 0.25 * c, 3 * c
+    mgr.set_states(want, which=[1, 0, 0, 1, 1, 1])             # a run at the start, a run that reaches the end
+    got = mgr.get_states()
+    for c in range(6):
+        assert raw(got[c]) == raw(want[c] if c in (0, 3, 4, 5) else base[c]), c
+    mgr.set_states(want, which=[0] * 6)                           # nothing flagged: nothing written
+    assert [raw(s) for s in mgr.get_states()] == [raw(s) for s in got]
+    mgr.set_states(base)                                          # no mask: every channel
+    assert [raw(s) for s in mgr.get_states()] == [raw(s) for s in base]
+    st = (_lib.TrkState * 6)()
+    assert L.gm_trk_get_states(mgr._h, None) == -1 and L.gm_trk_set_states(mgr._h, None, None) == -1
+    assert L.gm_ring_get_enqueued_head(ring._h, None) == -1
+    # ---- the enqueued head
+    assert ring.get_enqueued_head() == ring.get_head() == 0
+    half = (n_ms // 2) * N + 777
+    ring.write_samples_async(x[:half])
+    assert ring.get_enqueued_head() == half >= ring.get_head()
+    ring.flush()
+    assert ring.get_enqueued_head() == ring.get_head() == half
+    # ---- the states a collect hands over belong to ITS call
+    for i, (p, (d, c0)) in enumerate(sorted(truth.items())):
+        mgr.channels[i].start(dict(prn=p, code_phase_samples=c0, code_phase_chips=0.0, carrier_freq=d + 15.0, fs=fs, mag_relative=1.0,
+                                   sample_global_index=c0, doppler_bin=0))
+    t1 = mgr.update_all_async(ring, n_ms // 2 + 2)
+    ring.write_samples_async(x[half:])
+    assert ring.get_enqueued_head() == x.size
+    t2 = mgr.update_all_async(ring, n_ms // 2 + 2)
+    o1, p1, l1, d1, s1 = mgr.collect(t1, wait=True, with_states=True)
+    o2, p2, l2, d2, s2 = mgr.collect(t2, wait=True, with_states=True)
+    assert not l1.any() and not l2.any()
+    for i, (p, (d, c0)) in enumerate(sorted(truth.items())):
+        n1, n2 = int(p1[:, i].sum()), int(p2[:, i].sum())
+        assert n1 == (half - c0) // N and n1 + n2 == (x.size - c0) // N
+        assert s1[i].next_sample_index == c0 + n1 * N and s2[i].next_sample_index == c0 + (n1 + n2) * N   # (code_rate stays within a sample of N here)
+        assert s1[i].active and s2[i].active and abs(s2[i].carrier_freq - d) < 15.0
+    assert [raw(s) for s in s2] == [raw(s) for s in mgr.get_states()]
+    assert [raw(s) for s in s1[2:]] == [raw(s) for s in base[2:]]                                          # idle channels: untouched
+    mgr.close(); ring.close()
+
+
 def test_ring_head_by_pull_with_concurrent_readers(gpu):
     """The asynchronous writer's head is published by PULL (ABI 6: no host callback on the copy stream): whoever looks retires the
     blocks whose copies have completed.  A writer thread and two reader threads on one ring — the single-writer / many-readers
