@@ -20,7 +20,7 @@ using Plan16368 = Plan<16368, 768, 33, 16, 31>;
 // 8184 = 24 * 11 * 31 (pairwise coprime): half of 16368 — the base of the 2 x 8184 composite form of the reference's own geometry
 // (two workgroups per CU: 65.5 KB each)
 #ifndef GM_PLAN_8184
-#define GM_PLAN_8184 Plan<8184, 384, 24, 11, 31>
+#define GM_PLAN_8184 Plan<8184, 384, 24, 11, 31>      // ([11, 24, 31] has no scratch at the same speed, 366 us at configs[1]'s grid, but two pass-0 butterflies per lane: not a composite base)
 #endif
 using Plan8184 = GM_PLAN_8184;
 using Plan4096 = Plan<4096, 256, 16, 16, 16>;
@@ -34,8 +34,8 @@ using Plan2000 = Plan<2000, 128, 25, 10, 8>;      // 2 Msps
 using Plan5000 = Plan<5000, 256, 25, 25, 8>;      // 5 Msps (last pass: 625 butterflies -> 3 per thread)
 using Plan6000 = Plan<6000, 512, 25, 15, 16>;     // 6 Msps
 using Plan8192 = Plan<8192, 512, 16, 32, 16>;     // 8.192 Msps
-using Plan15000 = Plan<15000, 1024, 25, 25, 24>;  // 15 Msps
-using Plan16384 = Plan<16384, 1024, 32, 32, 16>;  // 16.384 Msps
+using Plan15000 = Plan<15000, 768, 25, 25, 24>;   // 15 Msps (768 lanes = 3 waves per SIMD, 170 registers: at 1024 lanes the same radices spilled 39 inside the loop, 561 -> 519 us)
+using Plan16384 = Plan<16384, 1024, 16, 8, 8, 16>; // 16.384 Msps (four passes of <= 16 values per lane under the 128-register cap: [32, 32, 16] was 830 us against 498 at configs[1]'s grid)
 using Plan512 = Plan<512, 64, 8, 8, 8>;           // factors of the long fine-Doppler FFT (2^16 .. 2^19) at low sample rates
 using Plan256 = Plan<256, 64, 16, 16>;
 #ifndef GM_NO_PLAN_ROT
