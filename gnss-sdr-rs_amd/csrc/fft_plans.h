@@ -27,12 +27,18 @@ using Plan4096 = Plan<4096, 256, 16, 16, 16>;
 using Plan2048 = Plan<2048, 256, 8, 16, 16>;
 using Plan1024 = Plan<1024, 128, 8, 8, 16>;
 using Plan4000 = Plan<4000, 256, 25, 16, 10>;
-using Plan10000 = Plan<10000, 512, 25, 20, 20>;
-using Plan12000 = Plan<12000, 512, 25, 3, 10, 16>;
+using Plan10000 = Plan<10000, 1024, 10, 10, 10, 10>;   // (plan search, round 6: 350 -> 321 us at the 32 x 41 x 10 grid against [25, 20, 20] on 512 lanes)
+using Plan12000 = Plan<12000, 768, 20, 25, 24>;        // (plan search, round 6: 451 -> 389 us against [25, 3, 10, 16] on 512 lanes)
 using Plan16000 = Plan<16000, 1024, 25, 20, 32>;
 using Plan2000 = Plan<2000, 128, 25, 10, 8>;      // 2 Msps
-using Plan5000 = Plan<5000, 256, 25, 25, 8>;      // 5 Msps (last pass: 625 butterflies -> 3 per thread)
-using Plan6000 = Plan<6000, 512, 25, 15, 16>;     // 6 Msps
+#ifndef GM_PLAN_5000
+#define GM_PLAN_5000 Plan<5000, 256, 25, 20, 10>
+#endif
+using Plan5000 = GM_PLAN_5000;     // 5 Msps (plan search, round 6: 134 -> 121 us against [25, 25, 8])
+#ifndef GM_PLAN_6000
+#define GM_PLAN_6000 Plan<6000, 256, 25, 24, 10>
+#endif
+using Plan6000 = GM_PLAN_6000;     // 6 Msps (round 6 plan search, tools/corr_lab/plan_search.py: 162.6 -> 137.3 us at the 32 x 41 x 10 grid against [25, 15, 16] on 512 lanes)
 using Plan8192 = Plan<8192, 512, 16, 32, 16>;     // 8.192 Msps
 using Plan15000 = Plan<15000, 768, 25, 25, 24>;   // 15 Msps (768 lanes = 3 waves per SIMD, 170 registers: at 1024 lanes the same radices spilled 39 inside the loop, 561 -> 519 us)
 using Plan16384 = Plan<16384, 1024, 16, 8, 8, 16>; // 16.384 Msps (four passes of <= 16 values per lane under the 128-register cap: [32, 32, 16] was 830 us against 498 at configs[1]'s grid)

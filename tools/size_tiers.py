@@ -25,7 +25,7 @@ def _composite():
 
 
 COMPOSITE = _composite()
-P, D, M = 32, 9, 2
+P, D, M = (int(v) for v in os.environ.get("TIERS_PDM", "32,9,2").split(","))     # TIERS_PDM=32,41,4 TIERS_ONLY=6000,18000: an A/B at another grid
 
 
 def measure(path):
@@ -34,8 +34,11 @@ def measure(path):
     _lib.init(0)
     rng = np.random.default_rng(1)
     out = {}
+    only = [int(v) for v in os.environ.get("TIERS_ONLY", "").split(",") if v]
     for q, base in [(1, n) for n in IN_LDS] + COMPOSITE:
         N = q * base
+        if only and N not in only:
+            continue
         fs = N * 1000.0
         dop = (np.arange(D, dtype=np.float32) - D // 2) * 250.0
         x = rng.integers(-60, 60, 2 * M * N, dtype=np.int8)
