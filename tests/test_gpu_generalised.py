@@ -179,7 +179,10 @@ def test_five_arm_boc_persistent_kernel_first_epoch(gpu, oracle):
                                                        (24.552e6, 1023, 1.023e6, 24552, 3),       # 3 x 8184 (24 * 11 * 31: half the reference's size as a base)
                                                        (12.0e6, 4092, 1.023e6, 48000, 3),         # 3 x 16000: the wave-specialised kernel (acq_comp_ws.h) at another Q
                                                        (20.0e6, 4092, 1.023e6, 80000, 5),         # 5 x 16000: from Q = 5 its load units are single row pairs
-                                                       (32.0e6, 4092, 1.023e6, 128000, 8)])       # 8 x 16000 (its most register-hungry instantiation)
+                                                       (32.0e6, 4092, 1.023e6, 128000, 8),        # 8 x 16000 (its most register-hungry instantiation)
+                                                       (18.0e6, 1023, 1.023e6, 18000, 3),         # 3 x 6000 (the 256-lane base plan of round 6's plan search)
+                                                       (24.576e6, 1023, 1.023e6, 24576, 3),       # 3 x 8192
+                                                       (65.536e6, 1023, 1.023e6, 65536, 4)])      # 4 x 16384 (its four-pass base plan)
 def test_acquisition_beyond_one_lds_buffer(gpu, oracle, fs, code_len, code_rate, N, Q):
     """Transform sizes above 16384 (one code period of a 4 ms code at 8-10 Msps, or GPS at 25 Msps): N = Q x an in-LDS
     plan (acq_composite.hip).  Same checks as every other acquisition parity test: per-(worker, bin) max / first argmax /
