@@ -25,7 +25,10 @@ template <class PL> struct MixPlanOf { using type = PL; };
 #ifndef GM_NO_MIX_PLAN
 // stage F at N = 8000: four passes of radix 5 / 8 / 10 / 20 on 1024 lanes (56 VGPRs, 67.5 KB: two workgroups per CU) — 18.1 us per
 // 410-transform launch against 23.2 for [25, 20, 16] on 512 lanes (tools/mix_lab; [8,10,10,10]: 18.7, [16,25,20] on 512: 20.1)
-template <> struct MixPlanOf<Plan<8000, 512, 25, 20, 16>> { using type = Plan<8000, 1024, 5, 8, 10, 20>; };
+#ifndef GM_MIX_PLAN_8000
+#define GM_MIX_PLAN_8000 Plan<8000, 1024, 5, 8, 10, 20>
+#endif
+template <> struct MixPlanOf<Plan<8000, 512, 25, 20, 16>> { using type = GM_MIX_PLAN_8000; };
 // N = 16368 (one workgroup per CU either way: 290 transforms are two rounds): radix 16 first on 1024 lanes — every lane loads in
 // pass 0 — 45.7 us against 57.4 for [33, 16, 31] on 768 lanes ([16,3,11,31]: 47.8, [11,3,16,31]: 51.6)
 template <> struct MixPlanOf<Plan<16368, 768, 33, 16, 31>> { using type = Plan<16368, 1024, 16, 33, 31>; };
