@@ -31,7 +31,10 @@ template <class PL> struct MixPlanOf { using type = PL; };
 template <> struct MixPlanOf<Plan<8000, 512, 25, 20, 16>> { using type = GM_MIX_PLAN_8000; };
 // N = 16368 (one workgroup per CU either way: 290 transforms are two rounds): radix 16 first on 1024 lanes — every lane loads in
 // pass 0 — 45.7 us against 57.4 for [33, 16, 31] on 768 lanes ([16,3,11,31]: 47.8, [11,3,16,31]: 51.6)
-template <> struct MixPlanOf<Plan<16368, 768, 33, 16, 31>> { using type = Plan<16368, 1024, 16, 33, 31>; };
+#ifndef GM_MIX_PLAN_16368
+#define GM_MIX_PLAN_16368 Plan<16368, 1024, 16, 33, 31>
+#endif
+template <> struct MixPlanOf<Plan<16368, 768, 33, 16, 31>> { using type = GM_MIX_PLAN_16368; };
 // N = 16000 (the base of the configs[3] Galileo geometry's composite transform, comp_fwd_sub_kernel: 164 sub-transforms, one
 // round): forward sub + post 42.5 -> 38.4 us ([10,10,10,16]: 40.7, [16,10,10,10]: 38.6, [32,25,20]: 47.1; tools/comp_time.py on
 // A/B libraries) — the strided decimated loads and the post kernel are most of it

@@ -4,8 +4,9 @@ the GPU box by time_all.sh ("stage F ... median").  Same method as tools/corr_la
 import os, subprocess, sys, tempfile, shutil
 from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
-RAD = [4, 5, 8, 10, 16, 20, 25]
-N = 8000
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
+RAD = [4, 5, 8, 10, 16, 20, 25] if N == 8000 else [3, 4, 8, 11, 16, 24, 31, 33]      # 16368 = 2^4 * 3 * 11 * 31
+TS = (512, 768, 1024) if N == 8000 else (768, 1024)
 
 
 def facts(n, k):
@@ -18,7 +19,7 @@ def build(c):
     name = "_".join(map(str, c))
     d = tempfile.mkdtemp(prefix="mix_")
     r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
-                        "-fhip-fp32-correctly-rounded-divide-sqrt", "-DGM_MIX_PLAN_8000=Plan<8000,%s>" % ",".join(map(str, c)),
+                        "-fhip-fp32-correctly-rounded-divide-sqrt", "-DGM_MIX_PLAN_%d=Plan<%d,%s>" % (N, N, ",".join(map(str, c))), "-DLAB_PLAN=gm::Plan%d" % N,
                         os.path.join(HERE, "mix_lab.hip"), "-o", os.path.join(d, "lab")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=d)
     ok = r.returncode == 0
     if ok:
@@ -30,7 +31,7 @@ def build(c):
 cands = []
 for k in (3, 4, 5):
     for f in facts(N, k):
-        for T in (512, 768, 1024):
+        for T in TS:
             if N // max(f) > 2 * T or T * min(f) > 2 * N:       # no pass with > 2 butterflies per lane... nor a workgroup that is mostly idle in its widest pass
                 continue
             cands.append((T,) + f)
