@@ -381,7 +381,7 @@ def test_error_behaviour(gpu):
 
 
 @pytest.mark.parametrize("fs,N", [(2.0e6, 2000), (5.0e6, 5000), (6.0e6, 6000), (8.192e6, 8192), (10.0e6, 10000),
-                                  (12.0e6, 12000), (15.0e6, 15000), (16.0e6, 16000), (16.384e6, 16384), (4.0e6, 4000)])
+                                  (12.0e6, 12000), (15.0e6, 15000), (16.0e6, 16000), (16.384e6, 16384), (4.0e6, 4000), (8.184e6, 8184)])
 def test_every_other_plan_small_scene(gpu, oracle, fs, N):
     """One small scene per remaining fft_size plan (3 PRNs x 3 bins x 2 ms): planes and decisions vs the oracle."""
     from gnss_sdr_rs_amd import acquisition as A, synth
