@@ -379,6 +379,7 @@ template <class PL, uint32_t Q> struct CompLaunch {
 // 16368's generic plan runs here with its twiddles (AsPlain: the prime-factor form is the fused kernel's)
 namespace gm { template <> struct CompPlanOf<Plan16368> { using type = AsPlain<Plan16368>; }; }
 namespace gm { template <> struct CompPlanOf<Plan8184> { using type = AsPlain<Plan8184>; }; }
+namespace gm { template <> struct CompPlanOf<Plan8192> { using type = Plan8192; }; }     // the registered four-pass plan, not the fused kernel's [16, 32, 16]
 #ifdef GM_COMP_PLAIN_16000        // (A/B switch: the generic kernel on the plain [25, 20, 32] plan, what rounds 2 - 3 shipped)
 namespace gm { template <> struct CompPlanOf<Plan16000> { using type = Plan16000; }; }
 #endif
@@ -387,8 +388,22 @@ namespace gm {
 #define GM_COMP_ENTRY(PL)                                                                            \
     CompLaunch<PL, 2>::ops(), CompLaunch<PL, 3>::ops(), CompLaunch<PL, 4>::ops(), CompLaunch<PL, 5>::ops(), \
         CompLaunch<PL, 6>::ops(), CompLaunch<PL, 8>::ops(),
+#define GM_COMP_ONE(PL, Q) CompLaunch<PL, Q>::ops(),
+// find_comp takes the FIRST entry whose Q x base is the size, and a size with an in-LDS plan never comes here: of the 54 (base, Q)
+// pairs only 31 can be chosen — 2 x 8000 is 16000, 4 x 8000 is 2 x 16000, 6 x 6000 ... — and only those are instantiated (round 6: the
+// kernels nobody can launch were a fifth of this file's code objects, the most register-hungry ones among them: 8 x 6000, 8 x 8000).
+// GM_COMP_ALL_Q (a diagnostic build) brings every pair back for GM_COMP_BASE's A/B of two decompositions of one size.
+#ifdef GM_COMP_ALL_Q
 static const CompOps g_comp[] = {GM_COMP_ENTRY(Plan16384) GM_COMP_ENTRY(Plan16368) GM_COMP_ENTRY(Plan16000) GM_COMP_ENTRY(Plan8000) GM_COMP_ENTRY(Plan8192) GM_COMP_ENTRY(Plan8184)
                                      GM_COMP_ENTRY(Plan6000) GM_COMP_ENTRY(Plan5000) GM_COMP_ENTRY(Plan4000)};
+#else
+static const CompOps g_comp[] = {GM_COMP_ENTRY(Plan16384) GM_COMP_ENTRY(Plan16368) GM_COMP_ENTRY(Plan16000)
+                                 GM_COMP_ONE(Plan8000, 3) GM_COMP_ONE(Plan8000, 5) GM_COMP_ONE(Plan8192, 3) GM_COMP_ONE(Plan8192, 5)
+                                 GM_COMP_ONE(Plan8184, 3) GM_COMP_ONE(Plan8184, 5)
+                                 GM_COMP_ONE(Plan8184, 2)     /* reachable through GM_COMP_BASE only: the diagnostics-switch test runs 16368 as 2 x 8184 */
+                                 GM_COMP_ONE(Plan6000, 3) GM_COMP_ONE(Plan6000, 5) GM_COMP_ONE(Plan6000, 6)
+                                 GM_COMP_ONE(Plan5000, 4) GM_COMP_ONE(Plan5000, 5)};
+#endif
 
 // strict_sum_order on the composite path.  is_good_satellite's plane sum in the reference's own order (do_acquisition.rs:229-235): eight
 // running f32 sums over chunks_exact(8) — lane l adds power[8c + l] for c = 0, 1, ... — then reduce_sum, an ordered add of the eight

@@ -49,6 +49,7 @@ template <> struct MixPlanOf<Plan<16000, 1024, 25, 20, 32>> { using type = GM_MI
 #ifndef GM_NO_CORR_PLAN_8184
 template <> struct CorrPlanOf<Plan8184> { using type = Plan<8184, 384, 11, 24, 31>; };
 #endif
+template <> struct CorrPlanOf<Plan8192> { using type = Plan<8192, 512, 16, 32, 16>; };     // (fft_plans.h: why the two differ)
 #ifndef GM_NO_HYBRID_PLANS
 using CorrPlan8000 = HybridPlan<8000, 512, 5, 25, 4, 16>;     // 125 * 64: passes of radix 20 / 25 / 16
 template <> struct CorrPlanOf<Plan8000> { using type = CorrPlan8000; };

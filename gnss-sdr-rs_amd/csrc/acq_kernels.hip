@@ -832,6 +832,11 @@ template <class PL> struct Launch {
         fill_twiddles<PL>(tw, inverse, [](double a) { return ::cos(a); }, [](double a) { return ::sin(a); });
     }
     using CP = typename CorrPlanOf<PL>::type;      // the plan acq_corr_kernel's inverse runs on (acq_device.h)
+    static constexpr bool CORR_TW = !CorrMode<CP>::PFA && !CorrMode<CP>::HYBRID;     // the kernel loads a table (plain plan with twiddles)
+    static constexpr int corr_tw_total() { if constexpr (CORR_TW) return CP::TW_TOTAL; else return 0; }
+    static void fill_tw_corr(cf* tw) {
+        if constexpr (CORR_TW) fill_twiddles<CP>(tw, true, [](double a) { return ::cos(a); }, [](double a) { return ::sin(a); });
+    }
     static_assert(CP::T == PL::T && CP::N == PL::N, "the correlation plan keeps the size and the workgroup");
     using MP = typename MixPlanOf<PL>::type;       // the plan stage F's forward transform runs on (tw_fwd: ITS table, fill_tw_mix)
     static void fill_tw_mix(cf* tw, bool inverse) {
@@ -987,7 +992,7 @@ template <class PL> struct Launch {
                        CorrLayout<CP>::RELAYOUT ? 1 : 0,
                        &fill_tw, &fill_order, &mix_fft, &corr, &code_fft, &pair_codes, &fft_batch,
                        POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr, FineRows<PL>::RT,
-                       POW2 ? &big_cols : nullptr, POW2 ? &big_rows : nullptr, MP::TW_TOTAL, &fill_tw_mix};
+                       POW2 ? &big_cols : nullptr, POW2 ? &big_rows : nullptr, MP::TW_TOTAL, &fill_tw_mix, corr_tw_total(), &fill_tw_corr};
     }
 };
 

@@ -39,7 +39,10 @@ using Plan5000 = GM_PLAN_5000;     // 5 Msps (plan search, round 6: 134 -> 121 u
 #define GM_PLAN_6000 Plan<6000, 256, 25, 24, 10>
 #endif
 using Plan6000 = GM_PLAN_6000;     // 6 Msps (round 6 plan search, tools/corr_lab/plan_search.py: 162.6 -> 137.3 us at the 32 x 41 x 10 grid against [25, 15, 16] on 512 lanes)
-using Plan8192 = Plan<8192, 512, 16, 32, 16>;     // 8.192 Msps
+// 8192: the registered plan is what the forward transforms and the composite path (3 x, 5 x 8192) run — four passes of <= 16 values, which
+// leave the composite kernel 2 - 6 scratch instructions and 12 - 17 % less time than [16, 32, 16] (63 - 121 instructions) —; the in-LDS
+// inverse keeps [16, 32, 16] (acq_corr_plans.h CorrPlanOf<Plan8192>: 195 us at the 32 x 41 x 10 grid against 204 - 209 for any four-pass plan)
+using Plan8192 = Plan<8192, 512, 16, 8, 8, 8>;    // 8.192 Msps
 using Plan15000 = Plan<15000, 768, 25, 25, 24>;   // 15 Msps (768 lanes = 3 waves per SIMD, 170 registers: at 1024 lanes the same radices spilled 39 inside the loop, 561 -> 519 us)
 using Plan16384 = Plan<16384, 1024, 16, 8, 8, 16>; // 16.384 Msps (four passes of <= 16 values per lane under the 128-register cap: [32, 32, 16] was 830 us against 498 at configs[1]'s grid)
 using Plan512 = Plan<512, 64, 8, 8, 8>;           // factors of the long fine-Doppler FFT (2^16 .. 2^19) at low sample rates

@@ -752,9 +752,13 @@ int gm_acq_create(const gm_acq_cfg* cfg, gm_acq** out) {
         }
         if (rc) return fail(set_err(rc, "code resampling index out of range"));
     }
-    std::vector<cf> twf(size_t(pl->tw_total) + 1), twi(size_t(pl->tw_total) + 1);
+    // inverse twiddles: the in-LDS correlation kernel's own plan (CorrPlanOf) for a size that fits one LDS image, the registered plan's
+    // (what the composite kernels run on) for Q x base
+    const bool twi_corr = a->Q == 1;
+    std::vector<cf> twf(size_t(pl->tw_total) + 1), twi(size_t(twi_corr ? pl->tw_total_corr : pl->tw_total) + 1);
     pl->fill_tw(twf.data(), false);
-    pl->fill_tw(twi.data(), true);
+    if (twi_corr) pl->fill_tw_corr(twi.data());
+    else pl->fill_tw(twi.data(), true);
     std::vector<cf> twm(size_t(pl->tw_total_mix) + 1);
     pl->fill_tw_mix(twm.data(), false);
 

@@ -67,6 +67,10 @@ struct PlanOps {
     // stage F's forward transform may run on a plan of its own (MixPlanOf, acq_device.h): ITS base-twiddle table is what mix_fft takes
     int tw_total_mix;
     void (*fill_tw_mix)(cf* tw, bool inverse);
+    // the inverse base-twiddle table of acq_corr_kernel, built for ITS plan (CorrPlanOf, acq_device.h: a plain plan of other radices
+    // than the registered one since round 6, e.g. N = 8192; empty for prime-factor and hybrid correlation plans)
+    int tw_total_corr;
+    void (*fill_tw_corr)(cf* tw);
 };
 // mean of the snapshot (finer_doppler :236) and the final per-satellite reduction over the rows
 void launch_fine_mean(hipStream_t, const void* samples, int fmt, uint32_t n, float* d_mean);
