@@ -43,12 +43,6 @@ template <> struct MixPlanOf<Plan<16368, 768, 33, 16, 31>> { using type = GM_MIX
 #endif
 template <> struct MixPlanOf<Plan<16000, 1024, 25, 20, 32>> { using type = GM_MIX_PLAN_16000; };
 #endif
-// N = 8184 in LDS: the inverse on [11, 24, 31] (no scratch memory; the registered [24, 11, 31] spills 26 registers inside the integration
-// loop at the same speed, 365 against 370 us at the 32 x 41 x 10 grid).  Two pass-0 butterflies per lane, so the composite path keeps the
-// registered plan (acq_composite.hip: CompPlanOf<Plan8184>).
-#ifndef GM_NO_CORR_PLAN_8184
-template <> struct CorrPlanOf<Plan8184> { using type = Plan<8184, 384, 11, 24, 31>; };
-#endif
 template <> struct CorrPlanOf<Plan8192> { using type = Plan<8192, 512, 16, 32, 16>; };     // (fft_plans.h: why the two differ)
 #ifndef GM_NO_HYBRID_PLANS
 using CorrPlan8000 = HybridPlan<8000, 512, 5, 25, 4, 16>;     // 125 * 64: passes of radix 20 / 25 / 16

@@ -17,10 +17,12 @@ using Plan8000 = Plan<8000, 512, 25, 20, 16>;
 // radix-16 pass in the middle (two butterflies per thread), the radix-31 pass last: its 31 outputs go straight into the
 // power sums without an LDS scatter (order [33,31,16]: 0.52 ms per 32-PRN dwell; [33,16,31]: 0.47 before the prime-factor form)
 using Plan16368 = Plan<16368, 768, 33, 16, 31>;
-// 8184 = 24 * 11 * 31 (pairwise coprime): half of 16368 — the base of the 2 x 8184 composite form of the reference's own geometry
-// (two workgroups per CU: 65.5 KB each)
+// 8184 = 8 * 3 * 11 * 31 (pairwise coprime): half of 16368 — in LDS (two workgroups per CU: 65.5 KB each) and the base of 3 x / 5 x 8184.
+// Round 6's plan search: [11, 31, 8, 3] on 768 lanes — no scratch memory in LDS (352 us at the 32 x 41 x 10 grid against 370 for [24, 11, 31]
+// on 384 lanes, which spilled 26 registers inside the integration loop) and one pass-0 butterfly per lane, so the composites run it too
+// (3 x 8184 0.996 -> 0.705 ms, 5 x 8184 2.59 -> 1.79 ms at 32 x 41 x 4)
 #ifndef GM_PLAN_8184
-#define GM_PLAN_8184 Plan<8184, 384, 24, 11, 31>      // ([11, 24, 31] has no scratch at the same speed, 366 us at configs[1]'s grid, but two pass-0 butterflies per lane: not a composite base)
+#define GM_PLAN_8184 Plan<8184, 768, 11, 31, 8, 3>
 #endif
 using Plan8184 = GM_PLAN_8184;
 using Plan4096 = Plan<4096, 256, 16, 16, 16>;
