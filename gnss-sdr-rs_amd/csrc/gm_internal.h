@@ -186,8 +186,12 @@ void launch_trk_epoch(hipStream_t, const TrkDevCfg&, const int8_t* d_codes, gm_t
 // Persistent tracking geometry: workgroups of TRK_PERSIST_THREADS lanes, TRK_PERSIST_WG_PER_CU of them per CU.
 // Two independent workgroups per CU let one channel's serial exchange + loop-filter epilogue (one wave) overlap
 // the other's correlation phase.
-constexpr int TRK_PERSIST_THREADS = 512;
-constexpr int TRK_PERSIST_WG_PER_CU = 2;
+#ifndef GM_TRK_THREADS          // (A/B switch of the workgroup shape: 256 x 4 per CU and 1024 x 1 were measured in round 6, DESIGN_HISTORY R6.10)
+#define GM_TRK_THREADS 512
+#define GM_TRK_WG_PER_CU 2
+#endif
+constexpr int TRK_PERSIST_THREADS = GM_TRK_THREADS;
+constexpr int TRK_PERSIST_WG_PER_CU = GM_TRK_WG_PER_CU;
 
 inline int trk_persistent_slots(int n_channels) { return (n_channels + 7) / 8 * 8; }   // grid = slots * G workgroups
 int trk_persistent_blocks_per_cu(const TrkDevCfg&);   // resident workgroups per CU of the instantiation this config selects
