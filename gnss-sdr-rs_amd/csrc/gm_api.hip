@@ -1745,6 +1745,7 @@ int gm_trk_create(const gm_trk_cfg* cfg, gm_trk** out) {
             const size_t places = (size_t(cus) * per_cu) / (cfg->share_device ? 4 : 1);
             int gp = int(places / t->C < 16 ? places / t->C : 16);
             while (gp > 1 && gp * nv > 256) --gp;
+            { const int fp = gm::diag_int("GM_TRK_PACKED_G", 0); if (fp >= 1 && fp < gp) gp = fp; }      // diagnostic: fewer workgroups per channel in the packed layout
             const float nn = roundf(d.fs / (d.nominal_code_rate / d.code_len_f));
             const bool shaped = nn > 0 && gp >= 1 && nn / float(gp) / 512.0f >= 8.0f;
             if ((t->C % 8) != 0 && gp > g && shaped && gm::diag_int("GM_TRK_PACKED", 1) != 0) { g = gp; t->packed = true; }
