@@ -988,7 +988,7 @@ template <class PL> struct Launch {
         if constexpr (POW2) hipLaunchKernelGGL(fine_rows_kernel<PL>, dim3(a.N1 / FineRows<PL>::RT, n_sats), dim3(PL::T), 0, st, a);
     }
     static constexpr PlanOps ops() {
-        return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (PL::LDS_ELEMS + PL::TW_TOTAL), SPLIT_SLAB,
+        return PlanOps{PL::N, PL::T, PL::TW_TOTAL, int(sizeof(cf)) * (CP::LDS_ELEMS + corr_tw_total()), SPLIT_SLAB,
                        CorrLayout<CP>::RELAYOUT ? 1 : 0,
                        &fill_tw, &fill_order, &mix_fft, &corr, &code_fft, &pair_codes, &fft_batch,
                        POW2 ? &fine_cols : nullptr, POW2 ? &fine_rows : nullptr, FineRows<PL>::RT,
