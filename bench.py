@@ -1147,8 +1147,8 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
                                       "nav_bits": rep["seconds_nav_bits"], "feeder_held_back": rep["feeder_held_back_s"]},
            "frontend_block_seconds": {"first": rep["fe_block_first_s"], "median": rep["fe_block_median_s"], "max_after_first": rep["fe_block_max_after_first_s"]},
            "scene_generation_seconds": t_gen,
-           "bound": "the front-end per block of 2^19 samples: 1 MB host-to-device + the speculative front-end kernels (16 workgroups from guessed "
-                    "DC-remover states, verified and repaired: ~0.14 ms against 0.52 ms for the sequential form, DESIGN 4.4) ~ 0.18 ms per 32 ms of "
+           "bound": "the front-end per block of 2^19 samples: 1 MB host-to-device + the speculative front-end kernels (32 workgroups from guessed "
+                    "DC-remover states, verified and repaired: ~0.11 ms against 0.52 ms for the sequential form, DESIGN 4.4) ~ 0.15 ms per 32 ms of "
                     "signal; the feeder thread only enqueues (%d blocks; reclaiming a staging slot is its only wait), the tracking thread enqueues "
                     "process_channels behind each block ON THE DEVICE (gm_trk_update_all_async) and collects a block or two later, the acquisition "
                     "thread snapshots the published head when a round is due in signal time" % rep["blocks"]}
@@ -1210,7 +1210,7 @@ def receiver_cpu_chain(ca, xi8, fs, f_if, N, M, dop, sats):
 def frontend_leg(torch, dev, with_cpu):
     """DigitalFrontend::process_block (rf/frontend.rs:33-62) on 4 Mi samples of int8 IQ resident in HBM -> c32.  The
     two f32 recurrences (NCO phase, DC bias) are sequential by construction (bit-exactness): the NCO phase is a tabulated orbit,
-    the DC remover's sixteen chains run speculatively on 16 workgroups from guessed states and are verified / repaired (round 6,
+    the DC remover's sixteen chains run speculatively on 32 workgroups from guessed states and are verified / repaired (round 6,
     fe_kernels.hip) — exact, and several times the one-workgroup form; the requirement is the live sample rate (8-50 Msps)."""
     from gnss_sdr_rs_amd import frontend as F, _lib
     n = 1 << 22

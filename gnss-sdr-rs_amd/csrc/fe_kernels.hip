@@ -356,10 +356,21 @@ __device__ __forceinline__ float fs_guess(const FrontendArgs& a, const FrontendA
     const double c = double(a.con);
     const uint32_t ka = k0 + uint32_t(part) * pl, kb = (ka + pl < k0 + nw) ? ka + pl : k0 + nw;
     double are = 0.0, aim = 0.0;
-    for (uint32_t k = ka; k < kb; ++k) {
+    uint32_t k = ka;
+    for (; k + 16 <= kb; k += 16) {                              // sixteen loads requested before the first is used: the chain below
+        float re[16], im[16];                                    // is dependent, the loads are not (one at a time each paid a round trip)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) load_sample<FMT>(st.in, size_t(k + u) * 8 + j, re[u], im[u]);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            are = are * c + double(re[u] * a.alpha);             // x * alpha rounded to f32, as stage A hands it to the chain
+            aim = aim * c + double(im[u] * a.alpha);
+        }
+    }
+    for (; k < kb; ++k) {
         float re, im;
         load_sample<FMT>(st.in, size_t(k) * 8 + j, re, im);
-        are = are * c + double(re * a.alpha);                 // x * alpha rounded to f32, as stage A hands it to the chain
+        are = are * c + double(re * a.alpha);
         aim = aim * c + double(im * a.alpha);
     }
     const double w = ka < kb ? fs_pow(c, (k0 + nw) - kb) : 0.0;

@@ -2259,7 +2259,7 @@ static int frontend_launch(gm_frontend* f, hipStream_t st, const void* d_in, int
             HIPC(hipMemsetAsync(f->d_spec, 0, (size_t(FE_SPEC_K) * 32 + 1) * sizeof(float), st));
         }
         {
-            const int k = gm::diag_int("GM_FE_SPEC_K", 16);
+            const int k = gm::diag_int("GM_FE_SPEC_K", 32);      // 32 runs: 126 -> 113 us per 2^19-sample block against 16 (48, 64: 107 us, more runs to repair; DESIGN_HISTORY R6.5)
             a.spec_k = k < 2 ? 2 : (k > FE_SPEC_K ? FE_SPEC_K : k);
             a.spec_warm = gm::diag_int("GM_FE_SPEC_WARM", 0);
         }

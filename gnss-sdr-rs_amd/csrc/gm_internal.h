@@ -237,7 +237,7 @@ void launch_frontend_spec(hipStream_t, const FrontendArgs&, int fmt);
 void launch_frontend(hipStream_t, const FrontendArgs&, int n_streams, int fmt);
 // every stream carries a phase table: the pipelined kernel (DC chains on one wave, everything else data-parallel)
 void launch_frontend_fast(hipStream_t, const FrontendArgs&, int n_streams, int fmt);
-constexpr int FE_SPEC_K_MAX = 32;     // most workgroups (runs) per block in the speculative form: the record block's size (16 are used)
+constexpr int FE_SPEC_K_MAX = 64;     // most workgroups (runs) per block in the speculative form: the record block's size (32 are used)
 constexpr int FE_FAST_SEG = 3840;      // samples per pipeline segment of the fast kernel: 480 chain steps = 120 quads x 8 SIMD
                                        // lanes = 960 stage-C items = one per helper lane (the table period is padded to >= this)
 

@@ -361,7 +361,7 @@ int gm_frontend_synchronize(gm_frontend *f);
  * to 2^19 samples per copy + launch; the kernels run on a stream of the ring's own behind the copies (an event per staging slot). */
 int gm_frontend_write_ring(gm_frontend *f, gm_ring *ring, const void *samples, size_t n_samples, int fmt);
 /* Long blocks (>= 48 pipeline segments of 3840 samples, output not aliasing the input) run in the SPECULATIVE form since round 6: the
- * block is cut into 16 runs on 16 workgroups, each starting from a GUESSED DC-remover state (the recurrence in exact arithmetic over the
+ * block is cut into up to 32 runs on as many workgroups, each starting from a GUESSED DC-remover state (the recurrence in exact arithmetic over the
  * 16 384 steps before its warm-up) that an 8 640-step warm-up lets fall onto the true f32 chain; a second kernel verifies run by run
  * that the state a run entered with is bit for bit the state its predecessor left, and does a run again — sequentially, from the right
  * state — where it is not.  The results are those of the sequential front-end, word for word, whatever the guesses were
