@@ -214,17 +214,31 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    # one explicit stream for everything this process enqueues (library kernels through gm_*_set_stream, torch's copies and
-    # collectives through torch's current stream): nothing relies on the NULL stream's implicit ordering
-    bench_stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(bench_stream)
-
     from gnss_sdr_rs_amd import _lib, acquisition as A, synth, tracking as T
     _lib.init(local_rank)                      # raises if the HIP library is missing: no fallback
     # inputs: SURVEY §8 d2's C++ generator (splitmix64-seeded xoshiro256**, Box-Muller; gnss-sdr-rs_amd/synthgen) unless told
     # otherwise — identical bytes on every rank and every box for a given seed, no numpy version in the loop
     if "GM_SYNTH_GENERATOR" not in os.environ:
         synth.DEFAULT_GENERATOR = "xoshiro"
+
+    # ------------------------------------------------------------------ the whole receiver chain, informative — FIRST.
+    # The chain lives on four or five streams of its own (ring copies, front-end, tracking, acquisition + its side stream) that must
+    # run beside each other.  HIP deals a process's streams to its hardware queues in creation order (GPU_MAX_HW_QUEUES, 4), and the
+    # first torch.cuda.Stream() of a process creates torch's whole pool of them: measured on one box, the same chain runs at 217 x real
+    # time in a process that has created no other stream and at 118 - 190 x behind four torch streams (tools/rx_order_probe.py: two of
+    # the chain's streams then share a queue and the front-end kernel holds the tracking launches back).  A receiver process creates its
+    # receiver's streams first; so does this one.
+    receiver_first = None
+    if rank == 0 and world == 1 and os.environ.get("GM_BENCH_NO_RECEIVER") != "1":
+        try:
+            receiver_first = receiver_leg(A.ca_code_table(), A, T, synth, not args.no_cpu_baseline)
+        except Exception as e:
+            receiver_first = {"error": repr(e)}
+
+    # one explicit stream for everything this process enqueues (library kernels through gm_*_set_stream, torch's copies and
+    # collectives through torch's current stream): nothing relies on the NULL stream's implicit ordering
+    bench_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(bench_stream)
 
     # ------------------------------------------------------------------ acquisition workload (configs[1])
     ca = A.ca_code_table()
@@ -619,11 +633,8 @@ def main():
             out["frontend"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ the whole receiver chain, informative
-    if rank == 0 and world == 1 and os.environ.get("GM_BENCH_NO_RECEIVER") != "1":
-        try:
-            out["receiver"] = receiver_leg(ca, A, T, synth, not args.no_cpu_baseline)
-        except Exception as e:
-            out["receiver"] = {"error": repr(e)}
+    if receiver_first is not None:
+        out["receiver"] = receiver_first          # (measured at the start of this process: see there)
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1134,6 +1145,7 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
            "driver": "C++ stage drivers of host/gnss_sdr.hpp through host/receiver_harness.cpp: feeder on the calling thread, gnss::run_acquisition "
                      "and gnss::run_tracking (ticket loop) on threads of their own — the deliverable's loops, no Python in the timed region",
            "warmup_async_calls": WARM, "python_gc_disabled": False,
+           "measured_before_other_streams_exist": "bench.py runs this leg first: HIP deals streams to 4 hardware queues in creation order; behind torch's 32-stream pool the chain's own streams share queues (118-190 x on the same box, tools/rx_order_probe.py)",
            "signal_seconds": sig_s, "wall_seconds": wall, "x_real_time": sig_s / wall, "sustained_msps": n_ms * N / wall / 1e6,
            "dwells": rep["dwells"], "channel_epochs": rep["channel_epochs"], "tracking_passes": rep["tracking_passes"],
            "frontend_blocks": rep["blocks"], "frontend_speculated_runs_done_again": rep["fe_runs_repaired"],
