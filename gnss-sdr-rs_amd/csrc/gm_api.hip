@@ -250,7 +250,16 @@ static void ring_refresh_head(gm_ring* r, bool all = false) {
 }
 static int ring_async_init(gm_ring* r) {
     if (r->copy_stream) return GM_OK;
-    HIPC(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
+    {   // The writer's copies at the device's LOWEST stream priority, the front-end kernels (gm_frontend_write_ring) at the HIGHEST: HIP deals
+        // streams of one priority to that priority's hardware queues in creation order, and the normal-priority ones are where every other
+        // stream of the process lives (a first torch.cuda.Stream() creates 32 of them).  With both at the default priority the receiver
+        // chain ran at 218 x real time in a clean process and at 117 x behind four torch streams; low / high: 218 / 216 / 212 x with 0 / 4 / 16
+        // of them (tools/rx_order_probe.py, DESIGN_HISTORY R6.12).  GM_RING_COPY_PRIORITY / GM_RING_FE_PRIORITY: diagnostic overrides.
+        int least = 0, greatest = 0;
+        HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int pr = gm::diag_int("GM_RING_COPY_PRIORITY", 99);
+        HIPC(hipStreamCreateWithPriority(&r->copy_stream, hipStreamNonBlocking, pr == 99 ? least : pr));
+    }
     for (int i = 0; i < gm_ring::SLOTS; ++i) {
         HIPC(hipHostMalloc(reinterpret_cast<void**>(&r->staging[i]), r->slot_samples * 8, hipHostMallocDefault));
         HIPC(hipEventCreateWithFlags(&r->slot_done[i], hipEventDisableTiming));
@@ -2445,7 +2454,12 @@ int gm_frontend_write_ring(gm_frontend* f, gm_ring* r, const void* samples, size
     if (int rc = ring_async_init(r)) return rc;
     if (!r->fe_stream) {
         if (gm::diag_int("GM_RING_FE_STREAM", 1) == 0) r->fe_stream = r->copy_stream;      // diagnostic: kernels on the copy stream (round 4's form)
-        else HIPC(hipStreamCreateWithFlags(&r->fe_stream, hipStreamNonBlocking));
+        else {      // (highest priority: see ring_async_init)
+            int least = 0, greatest = 0;
+            HIPC(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const int pr = gm::diag_int("GM_RING_FE_PRIORITY", 99);
+            HIPC(hipStreamCreateWithPriority(&r->fe_stream, hipStreamNonBlocking, pr == 99 ? greatest : pr));
+        }
         for (int i = 0; i < gm_ring::SLOTS; ++i) HIPC(hipEventCreateWithFlags(&r->h2d_done[i], hipEventDisableTiming));
     }
     const size_t bps = fmt == GM_FMT_C32 ? 8 : 2;
