@@ -226,8 +226,9 @@ def main():
     # run beside each other.  HIP deals a process's streams to its hardware queues in creation order (GPU_MAX_HW_QUEUES, 4), and the
     # first torch.cuda.Stream() of a process creates torch's whole pool of them: measured on one box, the same chain runs at 217 x real
     # time in a process that has created no other stream and at 118 - 190 x behind four torch streams (tools/rx_order_probe.py: two of
-    # the chain's streams then share a queue and the front-end kernel holds the tracking launches back).  A receiver process creates its
-    # receiver's streams first; so does this one.
+    # the chain's streams then share a queue and the front-end kernel holds the tracking launches back).  The library now gives the ring's
+    # copy stream the lowest and the front-end stream the highest priority (their own queues: 216 x behind four torch streams, 220 x without);
+    # the leg still runs first — a receiver process creates its receiver's streams first.
     receiver_first = None
     if rank == 0 and world == 1 and os.environ.get("GM_BENCH_NO_RECEIVER") != "1":
         try:
@@ -1145,7 +1146,7 @@ def receiver_leg(ca, A, T, synth, with_cpu, n_ms=3200):
            "driver": "C++ stage drivers of host/gnss_sdr.hpp through host/receiver_harness.cpp: feeder on the calling thread, gnss::run_acquisition "
                      "and gnss::run_tracking (ticket loop) on threads of their own — the deliverable's loops, no Python in the timed region",
            "warmup_async_calls": WARM, "python_gc_disabled": False,
-           "measured_before_other_streams_exist": "bench.py runs this leg first: HIP deals streams to 4 hardware queues in creation order; behind torch's 32-stream pool the chain's own streams share queues (118-190 x on the same box, tools/rx_order_probe.py)",
+           "measured_before_other_streams_exist": "bench.py runs this leg first: HIP deals streams to hardware queues per priority in creation order; behind torch\'s 32-stream pool the chain ran at 118-190 x until its copy / front-end streams got priorities of their own (now 206-216 x there, 220 x here; tools/rx_order_probe.py)",
            "signal_seconds": sig_s, "wall_seconds": wall, "x_real_time": sig_s / wall, "sustained_msps": n_ms * N / wall / 1e6,
            "dwells": rep["dwells"], "channel_epochs": rep["channel_epochs"], "tracking_passes": rep["tracking_passes"],
            "frontend_blocks": rep["blocks"], "frontend_speculated_runs_done_again": rep["fe_runs_repaired"],
